@@ -1,0 +1,312 @@
+"""ORACLE -- test infrastructure only.  CPU restatement of the reference's CenterFace hot path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this file; the product (``lightweight-face-detection-centernet_amd/``) never does.
+
+Parity status: PINNED.  The reference ships no tests or golden vectors, so
+the pins are outputs of the reference itself, imported in the build container by
+``tools/gen_goldens.py`` and committed under ``tests/golden/``; ``tests/test_oracle_vs_golden.py``
+checks every function here against them.  Unpinned: ``cv2.resize`` (centerface.py:30) -- cv2 is not
+installed anywhere we can run, so only the identity-resize case (H, W multiples of 32) is covered.
+
+Third-party arithmetic: the reference's convolutions, batch-norm, max-pool and top-k are
+PyTorch calls (README.md:8 names torch 1.0.1, no lockfile).  The network restatement below calls
+the same torch *functional* ops on CPU in fp32; everything after the network (decode, NMS,
+rescale) is restated in numpy with explicit loops/ops so that integer/index results are exact.
+
+Each function cites the reference file:line it follows (paths relative to the reference root).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# model/centernet.py:211-219  (t, c, n, s, k)
+_SETTINGS = ((1, 16, 1, 1, 3), (6, 24, 2, 2, 3), (6, 32, 2, 2, 5), (6, 64, 2, 2, 3),
+             (6, 96, 2, 1, 5), (6, 160, 2, 2, 5), (6, 320, 1, 1, 3))
+_HEADS = ("hm", "wh", "lm", "reg")          # model/centernet.py:240-245 (dict order)
+MEAN = np.array([0.408, 0.447, 0.470], dtype=np.float32).reshape(1, 1, 3)   # centerface.py:12-13
+STD = np.array([0.289, 0.274, 0.278], dtype=np.float32).reshape(1, 1, 3)    # centerface.py:14-15
+
+
+# ----------------------------------------------------------------------------- network ---------
+def same_pad(x, k, s):
+    """ConvReLU._get_padding + nn.ZeroPad2d: model/centernet.py:63,68-70 (left,right,top,bottom)."""
+    p = max(k - s, 0)
+    return F.pad(x, [p // 2, p - p // 2, p // 2, p - p // 2])
+
+
+def swish(x):
+    """model/centernet.py:34-40."""
+    return x * torch.sigmoid(x)
+
+
+def conv_swish(x, w, k, s, groups=1):
+    """ConvReLU (despite the name: pad -> conv(bias=False) -> Swish): model/centernet.py:58-66."""
+    return swish(F.conv2d(same_pad(x, k, s), w, None, s, 0, 1, groups))
+
+
+def mbconv(x, sd, prefix, cin, cout, t, k, s):
+    """MBConvBlock with se=False: model/centernet.py:89-140 (layers :105-122, residual :134-140)."""
+    hid = cin * t
+    y = x
+    j = 0
+    if cin != hid:                                           # :109-110
+        y = conv_swish(y, sd["%s.conv.0.1.weight" % prefix], 1, 1)
+        j = 1
+    y = conv_swish(y, sd["%s.conv.%d.1.weight" % (prefix, j)], k, s, groups=hid)   # :111-113
+    y = F.conv2d(y, sd["%s.conv.%d.weight" % (prefix, j + 1)])                      # :117-118
+    if cin == cout and s == 1:                               # :101, eval-mode _drop_connect is identity
+        y = x + y
+    return y
+
+
+def _bn(x, sd, prefix, eps):
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                        sd[prefix + ".weight"], sd[prefix + ".bias"], False, 0.0, eps)
+
+
+def conv_1x1_bn(x, sd, prefix="conv_last"):
+    """model/centernet.py:179-184 (BN eps default 1e-5)."""
+    return swish(_bn(F.conv2d(x, sd[prefix + ".0.weight"]), sd, prefix + ".1", 1e-5))
+
+
+def idaup(x_low, x_skip, sd, prefix):
+    """IDAUp.forward: model/centernet.py:200-204 (BN eps 1e-3 at :193,197)."""
+    c = x_low.shape[1]
+    up = F.conv_transpose2d(x_low, sd[prefix + ".up.weight"], None, 2, 0, 0, c)
+    a = F.relu(_bn(up, sd, prefix + ".bn_up", 1e-3))
+    b = F.relu(_bn(F.conv2d(x_skip, sd[prefix + ".conv.0.weight"]), sd, prefix + ".conv.1", 1e-3))
+    return a + b
+
+
+def head(x, sd, name):
+    """conv3x3(p=1,bias) -> conv1x1(bias), nothing in between: model/centernet.py:247-256."""
+    y = F.conv2d(x, sd[name + ".0.weight"], sd[name + ".0.bias"], 1, 1)
+    return F.conv2d(y, sd[name + ".1.weight"], sd[name + ".1.bias"])
+
+
+def blocks_table():
+    cin = 32
+    for li, (t, c, n, s, k) in enumerate(_SETTINGS):
+        for i in range(n):
+            yield ("layer%d.%d" % (li, i), cin, c, t, k, s if i == 0 else 1)
+            cin = c
+
+
+def to_torch_sd(sd):
+    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
+                       for k, v in sd.items())
+
+
+@torch.no_grad()
+def forward(sd, x, return_features=False):
+    """EfficientNet.forward: model/centernet.py:263-280.  x: float32 [B,3,H,W], H,W % 32 == 0.
+    Returns dict hm/wh/lm/reg of NCHW float32 tensors (the reference returns ``[dict]``)."""
+    feats = {}
+    x = conv_swish(x, sd["first_conv.0.1.weight"], 3, 2)                 # :224,:264
+    feats["stem"] = x
+    skips = {}
+    for prefix, cin, cout, t, k, s in blocks_table():                    # :265-271
+        x = mbconv(x, sd, prefix, cin, cout, t, k, s)
+        feats[prefix] = x
+        if prefix in ("layer1.1", "layer2.1", "layer4.1"):
+            skips[prefix] = x
+    x = conv_1x1_bn(x, sd)                                               # :272
+    feats["conv_last"] = x
+    x = idaup(x, skips["layer4.1"], sd, "up1")                           # :273
+    x = idaup(x, skips["layer2.1"], sd, "up2")                           # :274
+    x = idaup(x, skips["layer1.1"], sd, "up3")                           # :275
+    feats["up3"] = x
+    out = OrderedDict((h, head(x, sd, h)) for h in _HEADS)               # :277-279
+    if return_features:
+        return out, feats
+    return out
+
+
+def sigmoid_clamp(hm):
+    """centerface.py:43 / eval_widerface.py:85: clamp(sigmoid(hm), 1e-4, 1-1e-4)."""
+    return torch.clamp(torch.sigmoid(hm), min=1e-4, max=1 - 1e-4)
+
+
+def shuffle_v2_block(x, sd, inp, oup, mid, ksize, stride, prefix=""):
+    """ShuffleV2Block.forward, eval mode: model/blocks.py:47-62 (layers :20-45)."""
+    def bn(v, p):
+        return _bn(v, sd, prefix + p, 1e-5)
+    pad = ksize // 2
+
+    def main(v):
+        v = F.relu(bn(F.conv2d(v, sd[prefix + "branch_main.0.weight"]), "branch_main.1"))
+        v = bn(F.conv2d(v, sd[prefix + "branch_main.3.weight"], None, stride, pad, 1, mid), "branch_main.4")
+        return F.relu(bn(F.conv2d(v, sd[prefix + "branch_main.5.weight"]), "branch_main.6"))
+    if stride == 1:
+        # channel_shuffle (:56-62): even channels pass through, odd channels feed branch_main
+        proj, v = x[:, 0::2], x[:, 1::2]
+        return torch.cat((proj, main(v)), 1)
+    p = bn(F.conv2d(x, sd[prefix + "branch_proj.0.weight"], None, stride, pad, 1, inp), "branch_proj.1")
+    p = F.relu(bn(F.conv2d(p, sd[prefix + "branch_proj.2.weight"]), "branch_proj.3"))
+    return torch.cat((p, main(x)), 1)
+
+
+# ----------------------------------------------------------------------------- API pre/post ----
+def transform(h, w):
+    """CenterFace.transform: centerface.py:68-71."""
+    h_new, w_new = int(np.ceil(h / 32) * 32), int(np.ceil(w / 32) * 32)
+    return h_new, w_new, h_new / h, w_new / w
+
+
+def preprocess(img_bgr_u8):
+    """centerface.py:32-37 for the identity-resize case (cv2.resize at :30 is unpinned):
+    /255, (x-mean)/std in BGR order, HWC->CHW, add batch dim.  Returns float32 [1,3,H,W]."""
+    img = img_bgr_u8.astype(np.float32) / 255.0
+    img = (img - MEAN) / STD
+    return np.ascontiguousarray(img.transpose(2, 0, 1))[None]
+
+
+# ----------------------------------------------------------------------------- decoder D3 ------
+def peak_nms(heat):
+    """_nms: centerface_ext.py:44-50.  heat float32 [B,C,H,W]; keep cells equal to their 3x3 max
+    (max_pool2d pads with -inf), zero the rest.  Every cell of a plateau survives."""
+    B, C, H, W = heat.shape
+    padded = np.full((B, C, H + 2, W + 2), -np.inf, dtype=np.float32)
+    padded[:, :, 1:-1, 1:-1] = heat
+    hmax = np.full_like(heat, -np.inf)
+    for dy in range(3):
+        for dx in range(3):
+            hmax = np.maximum(hmax, padded[:, :, dy:dy + H, dx:dx + W])
+    return heat * (hmax == heat).astype(np.float32)
+
+
+def topk(scores, K):
+    """_topk: centerface_ext.py:11-27 for one class (C == 1, which is all CenterFace uses; the
+    second top-k over classes is then the identity permutation).  torch.topk's order among equal
+    scores is unspecified; this restatement fixes it to *lower flat index first*, which is the
+    rule the HIP kernel implements.  Returns (score f32 [B,K], ind i64, cls i32, ys f32, xs f32)."""
+    B, C, H, W = scores.shape
+    assert C == 1
+    flat = scores.reshape(B, H * W)
+    order = np.argsort(-flat, axis=1, kind="stable")[:, :K]            # desc, ties -> lower index
+    sc = np.take_along_axis(flat, order, axis=1).astype(np.float32)
+    inds = order.astype(np.int64)
+    ys = (inds // W).astype(np.float32)                                # (inds / width).int().float()
+    xs = (inds % W).astype(np.float32)
+    return sc, inds, np.zeros((B, K), np.int32), ys, xs
+
+
+def gather_feat(feat, inds):
+    """_transpose_and_gather_feat: centerface_ext.py:28-42. feat [B,c,H,W], inds [B,K] -> [B,K,c]."""
+    B, c, H, W = feat.shape
+    f = feat.transpose(0, 2, 3, 1).reshape(B, H * W, c)
+    return np.take_along_axis(f, inds[:, :, None].repeat(c, 2), axis=1)
+
+
+def ctdet_decode(heat, wh, reg=None, K=100, lm=None):
+    """ctdet_decode: centerface_ext.py:52-82.  Returns detections [B,K,6] float32
+    (x1,y1,x2,y2,score,cls) in heat-map units; if ``lm`` is given also the gathered raw landmark
+    rows [B,K,10] (an addition -- the reference has no landmark gather on this path) and always
+    the flat indices [B,K] int64."""
+    heat = peak_nms(heat.astype(np.float32))
+    sc, inds, cls, ys, xs = topk(heat, K)
+    B = heat.shape[0]
+    if reg is not None:
+        r = gather_feat(reg.astype(np.float32), inds)
+        xs = xs + r[:, :, 0]
+        ys = ys + r[:, :, 1]
+    else:
+        xs = xs + np.float32(0.5)
+        ys = ys + np.float32(0.5)
+    w = gather_feat(wh.astype(np.float32), inds)
+    half = np.float32(2)
+    det = np.stack([xs - w[:, :, 0] / half, ys - w[:, :, 1] / half,
+                    xs + w[:, :, 0] / half, ys + w[:, :, 1] / half,
+                    sc, cls.astype(np.float32)], axis=2).astype(np.float32)
+    lms = gather_feat(lm.astype(np.float32), inds) if lm is not None else None
+    return det, lms, inds
+
+
+# ----------------------------------------------------------------------------- decoder D1 ------
+def nms_greedy(boxes, scores, nms_thresh):
+    """CenterFace.nms: centerface.py:111-151 (float32 arithmetic, +1 areas, ovr >= thresh).
+    Order: ``np.argsort(scores)[::-1]``; with a stable sort that is score-descending with the
+    HIGHER index first among equal scores, which is the tie rule fixed here."""
+    x1, y1, x2, y2 = (boxes[:, i].astype(np.float32) for i in range(4))
+    one = np.float32(1)
+    areas = (x2 - x1 + one) * (y2 - y1 + one)
+    order = np.argsort(scores, kind="stable")[::-1]
+    n = boxes.shape[0]
+    suppressed = np.zeros(n, dtype=bool)
+    thr = np.float32(nms_thresh)
+    keep = []
+    for _i in range(n):
+        i = order[_i]
+        if suppressed[i]:
+            continue
+        keep.append(int(i))
+        rest = order[_i + 1:]
+        xx1 = np.maximum(x1[i], x1[rest])
+        yy1 = np.maximum(y1[i], y1[rest])
+        xx2 = np.minimum(x2[i], x2[rest])
+        yy2 = np.minimum(y2[i], y2[rest])
+        w = np.maximum(np.float32(0), xx2 - xx1 + one)
+        h = np.maximum(np.float32(0), yy2 - yy1 + one)
+        inter = w * h
+        ovr = inter / (areas[i] + areas[rest] - inter)
+        suppressed[rest[ovr >= thr]] = True
+    return keep
+
+
+def decode_d1(heatmap, scale, offset, landmark, size, threshold=0.1, nms_thresh=0.3,
+              fixed_threshold=0.3):
+    """CenterFace.decode: centerface.py:73-109.  Quirks kept: the ``threshold`` argument is ignored
+    in favour of the constant 0.3 (:77), offsets are read but unused (:86,:88), x2 = min(x1c + w, W)
+    (:88-91).  Intermediates are Python/NumPy float64 built from float32 map values, cast to
+    float32 when the list becomes an array (:100,:104).  Returns (boxes [N,5] f32, lms [N,10] f32);
+    empty -> two empty lists like the reference (:79-82,:106-109)."""
+    del threshold
+    hm = np.squeeze(heatmap)
+    s0m, s1m = scale[0, 0], scale[0, 1]
+    c0, c1 = np.where(hm > fixed_threshold)
+    if len(c0) == 0:
+        return [], []
+    boxes, lms = [], []
+    for y, x in zip(c0, c1):
+        s0 = np.float32(s0m[y, x]) * np.float32(4)       # float32 * int stays float32
+        s1 = np.float32(s1m[y, x]) * np.float32(4)
+        s = hm[y, x]
+        x1 = max(0.0, (float(x) + 0.5) * 4 - float(s0) / 2)
+        y1 = max(0.0, (float(y) + 0.5) * 4 - float(s1) / 2)
+        x1, y1 = min(x1, float(size[1])), min(y1, float(size[0]))
+        boxes.append([x1, y1, min(x1 + float(s0), float(size[1])), min(y1 + float(s1), float(size[0])), float(s)])
+        lm = []
+        for j in range(5):
+            lm.append((float(landmark[0, 2 * j, y, x]) + float(x) + 0.5) * 4)
+            lm.append((float(landmark[0, 2 * j + 1, y, x]) + float(y) + 0.5) * 4)
+        lms.append(lm)
+    boxes = np.asarray(boxes, dtype=np.float32)
+    lms = np.asarray(lms, dtype=np.float32)
+    keep = nms_greedy(boxes[:, :4], boxes[:, 4], nms_thresh)
+    return boxes[keep, :], lms[keep, :]
+
+
+def rescale(dets, lms, scale_h, scale_w):
+    """centerface.py:55-62: floor-division rescale of boxes and landmarks; empty -> [0,5]/[0,10]."""
+    if len(dets) > 0:
+        dets = dets.copy()
+        lms = lms.copy()
+        dets[:, 0:4:2], dets[:, 1:4:2] = dets[:, 0:4:2] // scale_w, dets[:, 1:4:2] // scale_h
+        lms[:, 0:10:2], lms[:, 1:10:2] = lms[:, 0:10:2] // scale_w, lms[:, 1:10:2] // scale_h
+        return dets, lms
+    return np.empty((0, 5), np.float32), np.empty((0, 10), np.float32)
+
+
+def detect(sd, img_bgr_u8, threshold=0.2):
+    """CenterFace.__call__ (centerface.py:29-66) for images whose H, W are multiples of 32."""
+    h, w = img_bgr_u8.shape[:2]
+    h_new, w_new, sh, sw = transform(h, w)
+    assert (h_new, w_new) == (h, w), "cv2.resize is unpinned; oracle covers identity resize only"
+    out = forward(sd, torch.from_numpy(preprocess(img_bgr_u8)))
+    hm = sigmoid_clamp(out["hm"]).numpy()
+    dets, lms = decode_d1(hm, out["wh"].numpy(), out["reg"].numpy(), out["lm"].numpy(),
+                          (h_new, w_new), threshold)
+    return rescale(dets, lms, sh, sw)

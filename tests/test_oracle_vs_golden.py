@@ -1,0 +1,129 @@
+"""Pins the oracle (oracle/centerface_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, produced by tools/gen_goldens.py importing /root/reference)."""
+import numpy as np
+import torch
+
+import centerface_amd as cfa
+from oracle import centerface_oracle as O
+
+TOL = dict(rtol=1e-5, atol=2e-5)   # fp32 CPU vs fp32 CPU, same torch ops: only op-fusion level noise
+
+
+def _sub(d, prefix):
+    return {k[len(prefix):]: torch.from_numpy(v) for k, v in d.items() if k.startswith(prefix)}
+
+
+def test_synthetic_weights_are_reproducible(golden):
+    g = golden("net")
+    sd = cfa.weights.synthetic_state_dict(0)
+    assert cfa.weights.fingerprint(sd) == str(g["weights_fingerprint"])
+    assert list(sd) == list(cfa.schema.state_dict_schema())
+    assert sum(int(np.prod(v.shape)) for v in sd.values()) == 1308126
+
+
+def test_network_heads_match_reference(golden):
+    g = golden("net")
+    sd = O.to_torch_sd(cfa.weights.synthetic_state_dict(0))
+    for tag in "abc":
+        out = O.forward(sd, torch.from_numpy(g["x_" + tag]))
+        for h in ("hm", "wh", "lm", "reg"):
+            np.testing.assert_allclose(out[h].numpy(), g["%s_%s" % (h, tag)], **TOL, err_msg=h + tag)
+
+
+def test_preprocess_and_sigmoid_clamp(golden):
+    g = golden("net")
+    sd = O.to_torch_sd(cfa.weights.synthetic_state_dict(0))
+    out = O.forward(sd, torch.from_numpy(O.preprocess(g["img_u8"])))
+    np.testing.assert_allclose(O.sigmoid_clamp(out["hm"]).numpy(), g["img_hm_sigmoid"], rtol=1e-5, atol=1e-6)
+    for h in ("wh", "lm", "reg"):
+        np.testing.assert_allclose(out[h].numpy(), g["img_" + h], **TOL)
+
+
+def test_mbconv_blocks(golden):
+    g = golden("ops")
+    i = 0
+    while "mb%d_cfg" % i in g:
+        cin, cout, t, k, s = (int(v) for v in g["mb%d_cfg" % i])
+        sd = _sub(g, "mb%d_w_" % i)
+        sd = {"blk." + k_: v for k_, v in sd.items()}
+        y = O.mbconv(torch.from_numpy(g["mb%d_x" % i]), sd, "blk", cin, cout, t, k, s)
+        np.testing.assert_allclose(y.numpy(), g["mb%d_y" % i], **TOL, err_msg="mb%d" % i)
+        i += 1
+    assert i == 9
+
+
+def test_conv_swish_flavours(golden):
+    g = golden("ops")
+    for i in range(6):
+        cin, cout, k, s, groups = (int(v) for v in g["cr%d_cfg" % i])
+        y = O.conv_swish(torch.from_numpy(g["cr%d_x" % i]), torch.from_numpy(g["cr%d_w" % i]), k, s, groups)
+        np.testing.assert_allclose(y.numpy(), g["cr%d_y" % i], **TOL, err_msg="cr%d" % i)
+
+
+def test_conv_1x1_bn_idaup_head(golden):
+    g = golden("ops")
+    y = O.conv_1x1_bn(torch.from_numpy(g["c1bn_x"]), _sub(g, "c1bn_w_"))
+    np.testing.assert_allclose(y.numpy(), g["c1bn_y"], **TOL)
+    for i in range(3):
+        y = O.idaup(torch.from_numpy(g["ida%d_lo" % i]), torch.from_numpy(g["ida%d_skip" % i]),
+                    _sub(g, "ida%d_w_" % i), "up")
+        np.testing.assert_allclose(y.numpy(), g["ida%d_y" % i], **TOL)
+    sd = O.to_torch_sd(cfa.weights.synthetic_state_dict(0))
+    np.testing.assert_allclose(O.head(torch.from_numpy(g["head_x"]), sd, "lm").numpy(), g["head_y"], **TOL)
+    # fill_up_weights on a 2x2 kernel is [[1,0],[0,0]]
+    assert np.array_equal(g["fill_up_2x2"][0, 0], np.array([[1, 0], [0, 0]], np.float32))
+
+
+def test_shufflev2_blocks(golden):
+    g = golden("ops")
+    for i in range(4):
+        inp, oup, mid, k, s = (int(v) for v in g["sh%d_cfg" % i])
+        y = O.shuffle_v2_block(torch.from_numpy(g["sh%d_x" % i]), _sub(g, "sh%d_w_" % i), inp, oup, mid, k, s)
+        np.testing.assert_allclose(y.numpy(), g["sh%d_y" % i], **TOL, err_msg="sh%d" % i)
+
+
+def test_decode_d3_bit_exact(golden):
+    g = golden("decode_d3")
+    for tag in "smlx":
+        heat, wh, reg, K = g[tag + "_heat"], g[tag + "_wh"], g[tag + "_reg"], int(g[tag + "_K"])
+        assert np.array_equal(O.peak_nms(heat), g[tag + "_nms"])
+        sc, inds, cls, ys, xs = O.topk(O.peak_nms(heat), K)
+        # scores are strictly distinct above the zero plateau: exact wherever the score is > 0
+        pos = g[tag + "_topk_score"] > 0
+        assert pos.sum() > 0
+        assert np.array_equal(sc, g[tag + "_topk_score"])
+        assert np.array_equal(inds[pos], g[tag + "_topk_inds"][pos])
+        assert np.array_equal(ys[pos], g[tag + "_topk_ys"][pos]) and np.array_equal(xs[pos], g[tag + "_topk_xs"][pos])
+        assert cls.dtype == np.int32 and not cls.any()
+        det, _, _ = O.ctdet_decode(heat, wh, reg, K)
+        assert np.array_equal(det[pos], g[tag + "_det"][pos])          # bit-exact float32
+        det, _, _ = O.ctdet_decode(heat, wh, None, K)
+        assert np.array_equal(det[pos], g[tag + "_det_noreg"][pos])
+    assert np.array_equal(O.peak_nms(g["tie_heat"]), g["tie_nms"])
+    assert g["tie_nms"][0, 0, 2, 2] == g["tie_nms"][0, 0, 2, 3] == np.float32(0.7)   # plateau kept
+
+
+def test_decode_d1_and_nms(golden):
+    g = golden("decode_d1")
+    for tag in "ab":
+        b, l = O.decode_d1(g[tag + "_hm"], g[tag + "_wh"], g[tag + "_off"], g[tag + "_lm"],
+                           tuple(int(v) for v in g[tag + "_size"]), threshold=0.77)
+        assert np.array_equal(b, g[tag + "_boxes"]), tag
+        assert np.array_equal(l, g[tag + "_lms"]), tag
+    assert len(g["a_boxes"]) == 5 and len(g["b_boxes"]) > 20
+    b, l = O.decode_d1(np.full((1, 1, 8, 8), 0.2, np.float32), np.ones((1, 2, 8, 8), np.float32),
+                       np.zeros((1, 2, 8, 8), np.float32), np.zeros((1, 10, 8, 8), np.float32), (32, 32))
+    assert b == [] and l == [] and g["c_empty_is_list"].all()
+    for thr in (0.3, 0.5):
+        keep = O.nms_greedy(g["nms_boxes"], g["nms_scores"], thr)
+        assert np.array_equal(np.asarray(keep), g["nms_keep_%d" % int(thr * 10)])
+
+
+def test_transform_and_rescale(golden):
+    g = golden("decode_d1")
+    for (h, w), ref in zip(g["tf_in"], g["tf_out"]):
+        assert np.array_equal(np.asarray(O.transform(int(h), int(w)), np.float64), ref)
+    dets, lms = O.rescale(g["a_boxes"], g["a_lms"], g["f_scale"][0], g["f_scale"][1])
+    assert np.array_equal(dets, g["f_dets"]) and np.array_equal(lms, g["f_lms"])
+    d, l = O.rescale([], [], 1.0, 1.0)
+    assert d.shape == (0, 5) and l.shape == (0, 10) and d.dtype == np.float32
