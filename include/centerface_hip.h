@@ -1,0 +1,175 @@
+/*
+ * centerface_hip.h -- C ABI of libcenterface_hip.so: the MI355X (gfx950) CenterFace inference hot path.
+ *
+ * The reference has no FFI: its boundary is the Python class in centerface.py.  Every entry point
+ * below names the reference code it replaces; INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add to centerface.py to route through this library.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types cross the boundary (device pointers travel as void*).
+ *   - every function returns 0 (CF_OK) or a negative CF_E* code; cf_last_error(ctx) gives the text.
+ *     The library never aborts and never falls back to a CPU path.
+ *   - one cf_ctx = one GPU + one HIP stream; calls on a ctx are serialised by the caller; different
+ *     ctxs may be driven from different threads / processes (one process per GPU for multi-GPU).
+ *   - host outputs are written into CALLER-ALLOCATED buffers; nothing allocated here crosses back.
+ *   - activations live in HBM as NHWC (channels contiguous), fp32 or bf16 storage, fp32 accumulate.
+ */
+#ifndef CENTERFACE_HIP_H
+#define CENTERFACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_VERSION 100           /* 0.1.0 */
+
+/* error codes */
+#define CF_OK             0
+#define CF_EINVAL        -1      /* bad argument (shape not multiple of 32, K too large, ...) */
+#define CF_ENOMEM        -2
+#define CF_EHIP          -3      /* a HIP runtime call failed; see cf_last_error */
+#define CF_ESTATE        -4      /* call order violated (forward before load_weights, ...) */
+#define CF_ESCHEMA       -5      /* weight set does not match the 94-tensor checkpoint schema */
+#define CF_EOVERFLOW     -6      /* candidate capacity exceeded in threshold decode */
+
+/* storage dtype of activations and packed weights (accumulation is always fp32) */
+#define CF_F32   0               /* parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+#define CF_BF16  1               /* throughput mode: bf16 storage, bf16 MFMA, fp32 accumulate */
+
+/* network input formats accepted by cf_forward */
+#define CF_IN_U8_HWC_BGR  0      /* uint8 [B,H,W,3] BGR, as cv2 gives it; /255, -mean, /std fused
+                                    into the stem (replaces centerface.py:32-37) */
+#define CF_IN_F32_NCHW    1      /* float [B,3,H,W], already normalised: the tensor the reference
+                                    hands to net() at centerface.py:41 / eval_widerface.py:83 */
+
+/* cf_create flags */
+#define CF_FLAG_COLLAPSE_HEADS  1u   /* fold each head's conv3x3+b -> conv1x1+b (a linear pair,
+                                        model/centernet.py:249-256) into one 3x3 conv 24->15 */
+#define CF_FLAG_NO_GRAPH        2u   /* launch kernels eagerly instead of replaying a hipGraph */
+
+typedef struct cf_ctx cf_ctx;
+
+/* One checkpoint tensor, exactly as torch.save(model.state_dict()) holds it (train.py:165):
+ * conv weights OIHW float32; num_batches_tracked may be passed (int64) and is ignored. */
+typedef struct cf_tensor_desc {
+    const char* name;            /* state_dict key, e.g. "layer1.0.conv.1.1.weight" */
+    const void* data;            /* host pointer */
+    int32_t     ndim;
+    int64_t     dims[4];
+    int32_t     dtype;           /* 0 = float32, 1 = int64 */
+} cf_tensor_desc;
+
+int         cf_version(void);
+const char* cf_strerror(int code);
+const char* cf_last_error(const cf_ctx* ctx);          /* ctx may be NULL: last create error */
+int         cf_device_count(int* n);
+
+/* ---- lifetime: replaces CenterFace.__init__ (centerface.py:16-27) -------------------------- */
+/* H, W must be multiples of 32 (CenterFace.transform guarantees it, centerface.py:69). */
+int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags, cf_ctx** out);
+int cf_destroy(cf_ctx* ctx);
+/* strict load of the 94-tensor state_dict (centerface.py:23-24): validates names and shapes,
+ * folds BatchNorm (eval mode, centerface.py:25), repacks to kernel layouts, uploads. */
+int cf_load_weights(cf_ctx* ctx, const cf_tensor_desc* tensors, int n);
+
+/* ---- forward: replaces net(img)[0] (centerface.py:41, eval_widerface.py:83-84) ------------- */
+/* `in` is a host pointer (in_on_device = 0; copied H2D on the ctx stream) or a device pointer on
+ * ctx's GPU (in_on_device = 1).  Asynchronous: returns after enqueueing. */
+int cf_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B);
+/* copies the four head maps of the last forward to host as NCHW float32: hm [B,1,h,w] raw logits
+ * (what net() returns), wh [B,2,h,w], lm [B,10,h,w], reg [B,2,h,w]; h=H/4, w=W/4 (model/centernet.py
+ * :277-280).  Any pointer may be NULL.  hm_sigmoid (optional) receives clamp(sigmoid(hm),1e-4,1-1e-4)
+ * (centerface.py:43).  Synchronises. */
+int cf_get_heads(cf_ctx* ctx, float* hm, float* wh, float* lm, float* reg, float* hm_sigmoid);
+
+/* ---- decode D3: replaces ctdet_decode / _nms / _topk / _transpose_and_gather_feat
+ *      (centerface_ext.py:11-82) on the last forward's heads --------------------------------- */
+/* dets [B,K,6] = x1,y1,x2,y2,score,cls in heat-map units; lms [B,K,10] raw landmark rows at the
+ * same cells (may be NULL); inds [B,K] flat cell index y*w+x (may be NULL).  Equal scores are
+ * ordered lower-index-first (torch.topk leaves it unspecified).  use_reg = 0 gives the +0.5
+ * branch (centerface_ext.py:65-67).  out_on_device selects host or device destination buffers.
+ * K <= 1024 and K <= h*w. */
+int cf_decode_topk(cf_ctx* ctx, int K, int use_reg, float* dets, float* lms, int64_t* inds,
+                   int out_on_device);
+
+/* ---- decode D1: replaces CenterFace.decode + nms (centerface.py:73-151) -------------------- */
+/* For each image: cells with hm > score_thresh in row-major order, boxes/landmarks with the
+ * reference's arithmetic (offsets ignored, x2 = min(x1c + w, W)), greedy IoU >= nms_thresh
+ * suppression in descending score order.  dets [B,max_out,5], lms [B,max_out,10] (may be NULL),
+ * counts [B] = number of valid rows (kept boxes, in the reference's keep order).  Host buffers.
+ * The reference ignores its `threshold` argument and uses 0.3 (centerface.py:77); pass 0.3f. */
+int cf_decode_threshold(cf_ctx* ctx, float score_thresh, float nms_thresh, int max_out,
+                        float* dets, float* lms, int32_t* counts);
+
+/* ---- fused convenience: forward + D3 decode in one enqueue (eval_widerface.py:76-90 shape) -- */
+int cf_detect_topk(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int K,
+                   float* dets, float* lms, int64_t* inds, int out_on_device);
+
+/* ---- stream / timing plumbing -------------------------------------------------------------- */
+int cf_synchronize(cf_ctx* ctx);
+/* HIP events on the ctx stream (the stream the kernels are launched on). slot in [0, 64). */
+int cf_event_record(cf_ctx* ctx, int slot);
+int cf_event_elapsed_ms(cf_ctx* ctx, int slot_begin, int slot_end, float* ms);
+/* Per-kernel timing of one forward (+ optional top-K decode when K > 0): runs the launches eagerly
+ * with an event pair around each, returns up to `cap` records.  Replaces the datetime prints at
+ * centerface.py:38,47,49. */
+typedef struct cf_op_time {
+    char    name[48];            /* e.g. "layer1.0.dw" */
+    char    kind[16];            /* stem | pw | dw | head | decode */
+    char    kernel[160];         /* demangled kernel symbol, as rocprofv3 --kernel-trace prints it */
+    float   ms;
+    double  algo_bytes;          /* algorithmic HBM bytes of this launch: unpadded in + out */
+    double  flops;               /* 2 * MACs */
+} cf_op_time;
+int cf_profile_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int K,
+                       cf_op_time* out, int cap, int* n_out);
+/* device memory helpers so a host language without a GPU allocator can keep inputs resident */
+int cf_device_alloc(cf_ctx* ctx, uint64_t bytes, void** dptr);
+int cf_device_free(cf_ctx* ctx, void* dptr);
+int cf_memcpy_h2d(cf_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int cf_memcpy_d2h(cf_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+
+/* ---- per-op entry points (tests; host pointers; NCHW float32 like the torch ops they replace) */
+const char* cf_op_last_error(void);      /* text of the last failing cf_op_* call on this thread */
+/* ConvReLU depthwise / ShuffleV2 dw: pad -> conv2d(groups=C, bias=False) -> act.
+ * x [B,C,H,W], w [C,1,k,k], y [B,C,Ho,Wo]; pad_lo/pad_hi as ZeroPad2d (model/centernet.py:63,68-70;
+ * model/blocks.py:28); act: 0 none, 1 swish.  bias may be NULL (folded BN shift, blocks.py:29). */
+int cf_op_dwconv(int device, int dtype, const float* x, const float* w, const float* bias, float* y,
+                 int B, int C, int H, int W, int k, int stride, int pad_lo, int pad_hi, int act);
+/* 1x1 conv [+bias] [+act] [+residual]: x [B,Cin,H,W], w [Cout,Cin], y [B,Cout,H,W]
+ * (model/centernet.py:109-110,117-118,134-137,179-184; blocks.py:22-24,31-33). act 0/1 swish/2 relu */
+int cf_op_pwconv(int device, int dtype, const float* x, const float* w, const float* bias,
+                 const float* residual, float* y, int B, int Cin, int Cout, int H, int W, int act);
+/* stem: ConvReLU(3,32,3,stride 2) on a normalised float NCHW tensor or a uint8 HWC BGR image
+ * (model/centernet.py:224 ; centerface.py:32-37). y [B,32,H/2,W/2] */
+int cf_op_stem(int device, int dtype, const void* x, int in_format, const float* w, float* y,
+               int B, int H, int W);
+/* IDAUp.forward (model/centernet.py:200-204) with raw (unfolded) BN parameters, 5 floats rows:
+ * bn_up[4][C] / bn_cv[4][C] = weight, bias, running_mean, running_var. lo [B,C,h,w], skip [B,Cs,2h,2w] */
+int cf_op_idaup(int device, int dtype, const float* lo, const float* skip, const float* w_up,
+                const float* bn_up, const float* w_cv, const float* bn_cv, float eps, float* y,
+                int B, int C, int Cs, int h, int w);
+/* the four heads (model/centernet.py:247-261,277-279) on x [B,24,h,w]; weights concatenated in
+ * head order hm,wh,lm,reg: w0 [4][24,24,3,3], b0 [4][24], w1 [15,24], b1 [15].
+ * out [B,15,h,w] = hm(raw),wh(2),lm(10),reg(2).  collapse != 0 uses the folded 3x3 24->15 conv. */
+int cf_op_heads(int device, int dtype, const float* x, const float* w0, const float* b0,
+                const float* w1, const float* b1, float* out, int B, int h, int w, int collapse);
+/* ctdet_decode (centerface_ext.py:52-82) on explicit maps: heat [B,1,h,w] (already sigmoid'ed),
+ * wh [B,2,h,w], reg [B,2,h,w] or NULL, lm [B,10,h,w] or NULL. */
+int cf_op_ctdet_decode(int device, const float* heat, const float* wh, const float* reg,
+                       const float* lm, int B, int h, int w, int K,
+                       float* dets, float* lms, int64_t* inds);
+/* CenterFace.decode + nms (centerface.py:73-151) on explicit maps for ONE image size (H,W). */
+int cf_op_decode_threshold(int device, const float* hm, const float* wh, const float* lm,
+                           int B, int h, int w, int img_h, int img_w, float score_thresh,
+                           float nms_thresh, int max_out, float* dets, float* lms, int32_t* counts);
+/* CenterFace.nms alone (centerface.py:111-151): keep[] receives kept indices in keep order. */
+int cf_op_nms(int device, const float* boxes, const float* scores, int n, float nms_thresh,
+              int32_t* keep, int32_t* n_keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CENTERFACE_HIP_H */

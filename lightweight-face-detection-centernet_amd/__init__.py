@@ -1,4 +1,9 @@
-"""MI355X-native CenterFace inference hot path (drop-in for the reference's ``centerface.py``)."""
-from . import schema, weights  # noqa: F401
+"""MI355X-native CenterFace inference hot path (drop-in for the reference's ``centerface.py``).
 
-__all__ = ["schema", "weights"]
+    from centerface_amd import CenterFace
+    dets, lms = CenterFace(640, 640)(img_bgr_u8)
+"""
+from . import schema, weights, _lib, ops  # noqa: F401
+from .centerface import CenterFace, Engine  # noqa: F401
+
+__all__ = ["CenterFace", "Engine", "schema", "weights", "ops"]

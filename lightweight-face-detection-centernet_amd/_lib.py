@@ -1,0 +1,127 @@
+"""ctypes binding of libcenterface_hip.so (include/centerface_hip.h).  No CPU fallback: if the
+library is missing or a call fails this module raises."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcenterface_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+CF_OK = 0
+CF_F32, CF_BF16 = 0, 1
+CF_IN_U8_HWC_BGR, CF_IN_F32_NCHW = 0, 1
+CF_FLAG_COLLAPSE_HEADS, CF_FLAG_NO_GRAPH = 1, 2
+CF_EOVERFLOW = -6
+
+# every symbol include/centerface_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "cf_version", "cf_strerror", "cf_last_error", "cf_device_count", "cf_create", "cf_destroy",
+    "cf_load_weights", "cf_forward", "cf_get_heads", "cf_decode_topk", "cf_decode_threshold",
+    "cf_detect_topk", "cf_synchronize", "cf_event_record", "cf_event_elapsed_ms",
+    "cf_profile_forward", "cf_device_alloc", "cf_device_free", "cf_memcpy_h2d", "cf_memcpy_d2h",
+    "cf_op_last_error", "cf_op_dwconv", "cf_op_pwconv", "cf_op_stem", "cf_op_idaup", "cf_op_heads",
+    "cf_op_ctdet_decode", "cf_op_decode_threshold", "cf_op_nms",
+)
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32),
+                ("dims", C.c_int64 * 4), ("dtype", C.c_int32)]
+
+
+class OpTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("kind", C.c_char * 16), ("kernel", C.c_char * 160), ("ms", C.c_float),
+                ("algo_bytes", C.c_double), ("flops", C.c_double)]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    res = subprocess.run(args, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libcenterface_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.cf_strerror.restype = C.c_char_p
+        L.cf_last_error.restype = C.c_char_p
+        L.cf_last_error.argtypes = [C.c_void_p]
+        L.cf_op_last_error.restype = C.c_char_p
+        L.cf_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.cf_destroy.argtypes = [C.c_void_p]
+        L.cf_load_weights.argtypes = [C.c_void_p, C.POINTER(TensorDesc), C.c_int]
+        L.cf_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.cf_get_heads.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.cf_decode_topk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.cf_decode_threshold.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cf_detect_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.cf_synchronize.argtypes = [C.c_void_p]
+        L.cf_event_record.argtypes = [C.c_void_p, C.c_int]
+        L.cf_event_elapsed_ms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.cf_profile_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(OpTime), C.c_int, C.POINTER(C.c_int)]
+        L.cf_device_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.cf_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.cf_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.cf_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        fp, vp, i = C.c_void_p, C.c_void_p, C.c_int
+        L.cf_op_dwconv.argtypes = [i, i, fp, fp, fp, fp] + [i] * 9
+        L.cf_op_pwconv.argtypes = [i, i, fp, fp, fp, fp, fp] + [i] * 6
+        L.cf_op_stem.argtypes = [i, i, vp, i, fp, fp, i, i, i]
+        L.cf_op_idaup.argtypes = [i, i, fp, fp, fp, fp, fp, fp, C.c_float, fp] + [i] * 5
+        L.cf_op_heads.argtypes = [i, i, fp, fp, fp, fp, fp, fp, i, i, i, i]
+        L.cf_op_ctdet_decode.argtypes = [i, fp, fp, fp, fp, i, i, i, i, fp, fp, vp]
+        L.cf_op_decode_threshold.argtypes = [i, fp, fp, fp, i, i, i, i, i, C.c_float, C.c_float, i, fp, fp, vp]
+        L.cf_op_nms.argtypes = [i, fp, fp, i, C.c_float, vp, vp]
+        _lib = L
+    return _lib
+
+
+def ptr(a):
+    """Host pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+class CenterFaceError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libcenterface_hip: %s (code %d)" % (text, code))
+        self.code = code
+
+
+def check(code, ctx=None, op=False):
+    if code == CF_OK:
+        return
+    L = lib()
+    detail = (L.cf_op_last_error() if op else L.cf_last_error(ctx)) or b""
+    text = L.cf_strerror(code).decode()
+    if detail:
+        text += ": " + detail.decode(errors="replace")
+    if code == -1:
+        raise ValueError("libcenterface_hip: " + text)
+    raise CenterFaceError(code, text)

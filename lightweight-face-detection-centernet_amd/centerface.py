@@ -1,0 +1,294 @@
+"""Drop-in host API: the reference's ``centerface.py`` surface on top of libcenterface_hip.so.
+
+``CenterFace(height, width, landmarks=True)`` / ``__call__(img, threshold)`` / ``transform`` /
+``decode`` / ``nms`` keep the reference's names, argument meaning, return types and quirks
+(centerface.py:11-151); all arithmetic on the hot path runs in hand-written HIP kernels behind the
+C ABI (``include/centerface_hip.h``).  This module only marshals numpy arrays; there is no CPU
+compute fallback -- if the library is absent every entry point raises.
+
+Additions over the reference (keyword-only, defaults reproduce the reference):
+``weights=`` (checkpoint path or state_dict; default: deterministic synthetic weights because the
+reference's ``weight/model_epoch_100.pt`` is not distributed), ``dtype=`` ('fp32' parity mode or
+'bf16' throughput mode), ``device=``, ``max_batch=``, ``collapse_heads=``; methods ``forward``,
+``detect_batch``, ``decode_topk`` (the ``ctdet_decode`` path of centerface_ext.py:52-82).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import weights as _weights
+
+_DTYPES = {"fp32": _lib.CF_F32, "float32": _lib.CF_F32, "f32": _lib.CF_F32,
+           "bf16": _lib.CF_BF16, "bfloat16": _lib.CF_BF16}
+
+
+class Engine(object):
+    """One cf_ctx: one GPU, one stream, fixed (H, W), batch up to ``max_batch``."""
+
+    def __init__(self, height, width, max_batch=1, dtype="fp32", device=0, weights=None,
+                 collapse_heads=False):
+        L = _lib.lib()
+        if dtype not in _DTYPES:
+            raise ValueError("dtype must be one of %s" % sorted(_DTYPES))
+        self.H, self.W, self.max_batch, self.device = int(height), int(width), int(max_batch), int(device)
+        self.h, self.w = self.H // 4, self.W // 4
+        self.dtype = dtype
+        flags = _lib.CF_FLAG_COLLAPSE_HEADS if collapse_heads else 0
+        handle = C.c_void_p()
+        _lib.check(L.cf_create(self.device, self.max_batch, self.H, self.W, _DTYPES[dtype], flags, C.byref(handle)))
+        self._h = handle
+        self._L = L
+        self.last_B = 0
+        if weights is None:
+            weights = _weights.synthetic_state_dict(0)
+        elif isinstance(weights, str):
+            weights = _weights.load_checkpoint(weights)
+        self.load_state_dict(weights)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, code):
+        _lib.check(code, self._h)
+
+    def load_state_dict(self, sd):
+        """Strict load (centerface.py:24)."""
+        sd = _weights.validate_state_dict(sd)
+        descs = (_lib.TensorDesc * len(sd))()
+        keep = []
+        for i, (k, v) in enumerate(sd.items()):
+            name = k.encode()
+            keep.append((name, v))
+            descs[i].name = name
+            descs[i].data = v.ctypes.data
+            descs[i].ndim = v.ndim
+            for j, d in enumerate(v.shape):
+                descs[i].dims[j] = d
+            descs[i].dtype = 1 if v.dtype == np.int64 else 0
+        self._chk(self._L.cf_load_weights(self._h, descs, len(sd)))
+
+    # -- forward ----------------------------------------------------------------------------
+    def forward_enqueue(self, x, on_device=False, B=None, in_format=None):
+        """Enqueue one forward.  ``x``: uint8 [B,H,W,3] BGR or float32 [B,3,H,W] numpy array, or an
+        int device pointer with ``on_device=True`` (then ``B`` and ``in_format`` are required)."""
+        if on_device:
+            p = C.c_void_p(int(x))
+        else:
+            x = np.ascontiguousarray(x)
+            if x.dtype == np.uint8:
+                if x.ndim != 4 or x.shape[1:] != (self.H, self.W, 3):
+                    raise ValueError("uint8 input must be [B,%d,%d,3], got %s" % (self.H, self.W, x.shape))
+                in_format = _lib.CF_IN_U8_HWC_BGR
+            else:
+                x = np.ascontiguousarray(x, dtype=np.float32)
+                if x.ndim != 4 or x.shape[1:] != (3, self.H, self.W):
+                    raise ValueError("float input must be [B,3,%d,%d], got %s" % (self.H, self.W, x.shape))
+                in_format = _lib.CF_IN_F32_NCHW
+            B = x.shape[0]
+            self._keep_in = x
+            p = _lib.ptr(x)
+        self._chk(self._L.cf_forward(self._h, p, int(in_format), 1 if on_device else 0, int(B)))
+        self.last_B = int(B)
+
+    def synchronize(self):
+        self._chk(self._L.cf_synchronize(self._h))
+
+    def heads(self, sigmoid_hm=False):
+        """The four head maps of the last forward as NCHW float32 (model/centernet.py:277-280)."""
+        B, h, w = self.last_B, self.h, self.w
+        out = {"hm": np.empty((B, 1, h, w), np.float32), "wh": np.empty((B, 2, h, w), np.float32),
+               "lm": np.empty((B, 10, h, w), np.float32), "reg": np.empty((B, 2, h, w), np.float32)}
+        sg = np.empty((B, 1, h, w), np.float32) if sigmoid_hm else None
+        self._chk(self._L.cf_get_heads(self._h, _lib.ptr(out["hm"]), _lib.ptr(out["wh"]), _lib.ptr(out["lm"]),
+                                       _lib.ptr(out["reg"]), _lib.ptr(sg)))
+        if sigmoid_hm:
+            out["hm_sigmoid"] = sg
+        return out
+
+    def forward(self, x):
+        """net(x)[0] (centerface.py:41): dict of hm (raw logits), wh, lm, reg."""
+        self.forward_enqueue(x)
+        return self.heads()
+
+    # -- decode -----------------------------------------------------------------------------
+    def decode_topk(self, K=100, use_reg=True, landmarks=True):
+        """ctdet_decode on the last forward's heads: (dets [B,K,6], lms [B,K,10] | None, inds [B,K])."""
+        B = self.last_B
+        dets = np.empty((B, K, 6), np.float32)
+        lms = np.empty((B, K, 10), np.float32) if landmarks else None
+        inds = np.empty((B, K), np.int64)
+        self._chk(self._L.cf_decode_topk(self._h, int(K), 1 if use_reg else 0, _lib.ptr(dets), _lib.ptr(lms),
+                                         _lib.ptr(inds), 0))
+        return dets, lms, inds
+
+    def decode_topk_device(self, K, dets_ptr, lms_ptr=None, inds_ptr=None, use_reg=True):
+        """Same, writing into caller-owned DEVICE buffers (asynchronous)."""
+        self._chk(self._L.cf_decode_topk(self._h, int(K), 1 if use_reg else 0, C.c_void_p(int(dets_ptr)),
+                                         C.c_void_p(int(lms_ptr)) if lms_ptr else None,
+                                         C.c_void_p(int(inds_ptr)) if inds_ptr else None, 1))
+
+    def decode_threshold(self, score_thresh=0.3, nms_thresh=0.3, max_out=1024):
+        """CenterFace.decode + nms on the last forward: list of (boxes [n,5], lms [n,10]) per image."""
+        B = self.last_B
+        dets = np.empty((B, max_out, 5), np.float32)
+        lms = np.empty((B, max_out, 10), np.float32)
+        counts = np.empty((B,), np.int32)
+        self._chk(self._L.cf_decode_threshold(self._h, float(score_thresh), float(nms_thresh), int(max_out),
+                                              _lib.ptr(dets), _lib.ptr(lms), _lib.ptr(counts)))
+        return [(dets[b, :counts[b]].copy(), lms[b, :counts[b]].copy()) for b in range(B)]
+
+    # -- timing -----------------------------------------------------------------------------
+    def event_record(self, slot):
+        self._chk(self._L.cf_event_record(self._h, int(slot)))
+
+    def event_elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self._chk(self._L.cf_event_elapsed_ms(self._h, int(a), int(b), C.byref(ms)))
+        return ms.value
+
+    def profile_forward(self, x, on_device=False, B=None, in_format=None, K=0):
+        """Per-kernel times of one forward: list of dicts name/kind/ms/algo_bytes/flops."""
+        if on_device:
+            p = C.c_void_p(int(x))
+        else:
+            x = np.ascontiguousarray(x)
+            in_format = _lib.CF_IN_U8_HWC_BGR if x.dtype == np.uint8 else _lib.CF_IN_F32_NCHW
+            B = x.shape[0]
+            p = _lib.ptr(x)
+        rec = (_lib.OpTime * 64)()
+        n = C.c_int()
+        self._chk(self._L.cf_profile_forward(self._h, p, int(in_format), 1 if on_device else 0, int(B), int(K),
+                                             rec, 64, C.byref(n)))
+        self.last_B = int(B)
+        return [dict(name=r.name.decode(), kind=r.kind.decode(), kernel=r.kernel.decode(), ms=r.ms, algo_bytes=r.algo_bytes, flops=r.flops)
+                for r in rec[:n.value]]
+
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self._L.cf_device_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def device_free(self, p):
+        self._chk(self._L.cf_device_free(self._h, C.c_void_p(int(p))))
+
+    def memcpy_h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self._L.cf_memcpy_h2d(self._h, C.c_void_p(int(dptr)), _lib.ptr(arr), arr.nbytes))
+
+
+def _resize_bilinear_u8(img, new_h, new_w):
+    """Stand-in for cv2.resize(img, (w, h)) (centerface.py:30) -- bilinear with half-pixel centres.
+    cv2 is not installed where this was built, so parity with cv2's fixed-point INTER_LINEAR is
+    UNPINNED; for inputs whose sides are already multiples of 32 the resize is the identity."""
+    h, w = img.shape[:2]
+    if (h, w) == (new_h, new_w):
+        return img
+    ys = (np.arange(new_h, dtype=np.float64) + 0.5) * (h / new_h) - 0.5
+    xs = (np.arange(new_w, dtype=np.float64) + 0.5) * (w / new_w) - 0.5
+    y0 = np.clip(np.floor(ys).astype(np.int64), 0, h - 1); y1 = np.clip(y0 + 1, 0, h - 1)
+    x0 = np.clip(np.floor(xs).astype(np.int64), 0, w - 1); x1 = np.clip(x0 + 1, 0, w - 1)
+    fy = np.clip(ys - np.floor(ys), 0, 1)[:, None, None]
+    fx = np.clip(xs - np.floor(xs), 0, 1)[None, :, None]
+    fy = np.where(ys[:, None, None] < 0, 0.0, fy); fx = np.where(xs[None, :, None] < 0, 0.0, fx)
+    im = img.astype(np.float64)
+    top = im[y0][:, x0] * (1 - fx) + im[y0][:, x1] * fx
+    bot = im[y1][:, x0] * (1 - fx) + im[y1][:, x1] * fx
+    return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8)
+
+
+class CenterFace(object):
+    """Same construction and call surface as the reference class (centerface.py:11-66)."""
+    mean = np.array([0.408, 0.447, 0.470], dtype=np.float32).reshape(1, 1, 3)   # centerface.py:12-13
+    std = np.array([0.289, 0.274, 0.278], dtype=np.float32).reshape(1, 1, 3)    # centerface.py:14-15
+
+    def __init__(self, height, width, landmarks=True, *, weights=None, dtype="fp32", device=0,
+                 max_batch=1, collapse_heads=False, nms_thresh=0.3, max_dets=1024):
+        self.landmarks = landmarks
+        self.img_h_new, self.img_w_new, self.scale_h, self.scale_w = self.transform(height, width)
+        self.nms_thresh = nms_thresh
+        self.max_dets = max_dets
+        self.device = device
+        self.engine = Engine(self.img_h_new, self.img_w_new, max_batch=max_batch, dtype=dtype,
+                             device=device, weights=weights, collapse_heads=collapse_heads)
+
+    # centerface.py:68-71
+    def transform(self, h, w):
+        img_h_new, img_w_new = int(np.ceil(h / 32) * 32), int(np.ceil(w / 32) * 32)
+        scale_h, scale_w = img_h_new / h, img_w_new / w
+        return img_h_new, img_w_new, scale_h, scale_w
+
+    def _postprocess(self, dets, lms):
+        # centerface.py:55-62: floor-division rescale, empty -> [0,5] / [0,10]
+        if len(dets) > 0:
+            dets[:, 0:4:2], dets[:, 1:4:2] = dets[:, 0:4:2] // self.scale_w, dets[:, 1:4:2] // self.scale_h
+            if self.landmarks:
+                lms[:, 0:10:2], lms[:, 1:10:2] = lms[:, 0:10:2] // self.scale_w, lms[:, 1:10:2] // self.scale_h
+        else:
+            dets = np.empty(shape=[0, 5], dtype=np.float32)
+            if self.landmarks:
+                lms = np.empty(shape=[0, 10], dtype=np.float32)
+        return (dets, lms) if self.landmarks else dets
+
+    def __call__(self, img, threshold=0.2):
+        """img: BGR uint8 HWC (what cv2.imread returns).  Returns (dets [N,5], lms [N,10]) or dets."""
+        return self.detect_batch([img], threshold)[0]
+
+    def detect_batch(self, imgs, threshold=0.2):
+        """Batched ``__call__`` (the shape of eval_widerface.get_detections, :76-90).  The reference's
+        decode ignores ``threshold`` and uses 0.3 (centerface.py:77); so does this."""
+        del threshold
+        batch = np.stack([_resize_bilinear_u8(np.asarray(im, dtype=np.uint8), self.img_h_new, self.img_w_new)
+                          for im in imgs])
+        out = []
+        for i in range(0, len(batch), self.engine.max_batch):
+            self.engine.forward_enqueue(batch[i:i + self.engine.max_batch])
+            for dets, lms in self.engine.decode_threshold(0.3, self.nms_thresh, self.max_dets):
+                out.append(self._postprocess(dets, lms))
+        return out
+
+    def forward(self, x):
+        return self.engine.forward(x)
+
+    def decode_topk(self, K=100):
+        return self.engine.decode_topk(K)
+
+    # centerface.py:73-109 on explicit arrays
+    def decode(self, heatmap, scale, offset, landmark, size, threshold=0.1):
+        del offset, threshold       # read but unused / ignored by the reference (:77,:86-88)
+        L = _lib.lib()
+        hm = _lib.f32(np.asarray(heatmap).reshape((1, 1) + np.squeeze(heatmap).shape))
+        h, w = hm.shape[2:]
+        wh = _lib.f32(scale)
+        lm = _lib.f32(landmark) if landmark is not None else np.zeros((1, 10, h, w), np.float32)
+        cap = max(1, min(h * w, 4096))
+        dets = np.empty((1, cap, 5), np.float32)
+        lms = np.empty((1, cap, 10), np.float32)
+        cnt = np.zeros((1,), np.int32)
+        _lib.check(L.cf_op_decode_threshold(self.device, _lib.ptr(hm), _lib.ptr(wh), _lib.ptr(lm), 1, h, w,
+                                            int(size[0]), int(size[1]), 0.3, float(self.nms_thresh), cap,
+                                            _lib.ptr(dets), _lib.ptr(lms), _lib.ptr(cnt)), op=True)
+        n = int(cnt[0])
+        if n == 0:
+            return ([], []) if self.landmarks else []
+        return (dets[0, :n].copy(), lms[0, :n].copy()) if self.landmarks else dets[0, :n].copy()
+
+    # centerface.py:111-151
+    def nms(self, boxes, scores, nms_thresh):
+        L = _lib.lib()
+        boxes, scores = _lib.f32(boxes), _lib.f32(scores)
+        n = boxes.shape[0]
+        keep = np.empty((max(n, 1),), np.int32)
+        nk = C.c_int32()
+        _lib.check(L.cf_op_nms(self.device, _lib.ptr(boxes), _lib.ptr(scores), n, float(nms_thresh),
+                               _lib.ptr(keep), C.byref(nk)), op=True)
+        return [int(k) for k in keep[:nk.value]]

@@ -1,0 +1,82 @@
+// Shared device helpers for the gfx950 CenterFace kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits in HBM
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA bf16 operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define CF_WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ float bf16lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+
+// two fp32 -> packed bf16x2, round-to-nearest-even (v_cvt_pk_bf16_f32 has no builtin on gfx950)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Swish (model/centernet.py:34-40): x * sigmoid(x) = x / (1 + exp(-x)); v_exp_f32 + v_rcp_f32
+__device__ __forceinline__ float swish_f(float x) {
+    return x * fast_rcp(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float relu_f(float x) { return fmaxf(x, 0.0f); }
+template <int ACT> __device__ __forceinline__ float act_f(float x) {
+    if constexpr (ACT == 1) return swish_f(x);
+    else if constexpr (ACT == 2) return relu_f(x);
+    else return x;
+}
+
+// element <-> storage traits ------------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int PER16 = 4;   // elements per 16-byte chunk
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int PER16 = 8;
+};
+
+// unpack one 16-byte chunk to fp32 values
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4& c, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4& c, float* f) {
+    f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y);
+    f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4& c, float* f) {
+    f[0] = bf16lo(c.x); f[1] = bf16hi(c.x); f[2] = bf16lo(c.y); f[3] = bf16hi(c.y);
+    f[4] = bf16lo(c.z); f[5] = bf16hi(c.z); f[6] = bf16lo(c.w); f[7] = bf16hi(c.w);
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float* f);
+template <> __device__ __forceinline__ u32x4 pack16<float>(const float* f) {
+    u32x4 c; c.x = __float_as_uint(f[0]); c.y = __float_as_uint(f[1]);
+    c.z = __float_as_uint(f[2]); c.w = __float_as_uint(f[3]); return c;
+}
+template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
+    u32x4 c; c.x = pack_bf16x2(f[0], f[1]); c.y = pack_bf16x2(f[2], f[3]);
+    c.z = pack_bf16x2(f[4], f[5]); c.w = pack_bf16x2(f[6], f[7]); return c;
+}
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+__device__ __forceinline__ u32x4 zero16() { u32x4 z; z.x = z.y = z.z = z.w = 0u; return z; }
+
+// host-side fp32 -> bf16 (RNE), identical rounding to the device instruction for finite values
+static inline uint16_t host_f32_to_bf16(float f) {
+    uint32_t u; __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);   // inf / nan: truncate
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float host_bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16; float f; __builtin_memcpy(&f, &u, 4); return f;
+}

@@ -1,0 +1,121 @@
+// Host-callable launchers for the gfx950 kernels + weight packers.  dtype: 0 = fp32, 1 = bf16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cf {
+
+// Demangled symbol of the kernel the last launch_* call on this thread selected, in the form
+// rocprofv3 prints it -- lets cf_profile_forward attribute times to kernel symbols.
+const char* last_kernel_tag();
+void set_kernel_tag(const char* fmt, ...);
+template <typename T> inline const char* type_tag() { return sizeof(T) == 4 ? "float" : "unsigned short"; }
+
+inline size_t elem_size(int dtype) { return dtype == 0 ? 4 : 2; }
+inline int per16(int dtype) { return dtype == 0 ? 4 : 8; }
+
+// ------------------------------------------------------------------ pointwise (1x1) conv, MFMA
+// y[m][n] = act( sum_k x[m][k] * w[n][k] + bias[n] ) (+ residual[m][n]) (+ IDAUp up-branch)
+struct PwParams {
+    const void* x;        // [M][K]  T
+    const void* wp;       // packed weights, see pw_pack_weights
+    const float* bias;    // [N] fp32 or nullptr
+    const void* res;      // [M][N] T residual (added after act) or nullptr
+    void* y;              // [M][N] T
+    long long M;
+    int K, N;
+    int act;              // 0 none, 1 swish, 2 relu
+    // IDAUp fusion (model/centernet.py:200-204): y += relu(low[b][y/2][x/2][n] * upw[tap][n] + upb[n])
+    const void* low;      // [B][Ho/2][Wo/2][N] T or nullptr
+    const float* upw;     // [4][N]  deconv tap * BN scale
+    const float* upb;     // [N]     BN shift
+    int Ho, Wo;           // spatial dims of y (only for the IDAUp fusion)
+};
+size_t pw_packed_bytes(int dtype, int K, int N);
+void pw_pack_weights(int dtype, const float* w /*[N][K]*/, int K, int N, void* out_host);
+hipError_t launch_pw(hipStream_t s, int dtype, const PwParams& p);
+
+// ------------------------------------------------------------------ depthwise k x k conv
+struct DwParams {
+    const void* x;        // [B][H][W][C] T
+    const float* w;       // [k][k][C] fp32 (tap-major, channel contiguous)
+    const float* bias;    // [C] fp32 or nullptr
+    void* y;              // [B][Ho][Wo][C] T
+    int B, C, H, W, Ho, Wo;
+    int k, s, pad_lo;     // pad_hi is implied by Ho/Wo
+    int act;              // 0 none, 1 swish
+};
+void dw_pack_weights(const float* w /*[C][1][k][k]*/, int C, int k, float* out_host /*[k][k][C]*/);
+hipError_t launch_dw(hipStream_t s, int dtype, const DwParams& p);
+
+// ------------------------------------------------------------------ stem 3x3 s2 3->32 + Swish
+struct StemParams {
+    const void* x;        // u8 [B][H][W][3] (BGR) or f32 [B][3][H][W]
+    int in_format;        // CF_IN_U8_HWC_BGR / CF_IN_F32_NCHW
+    const float* w;       // [3][3][3][32] fp32 (ky,kx,ci,co)
+    void* y;              // [B][H/2][W/2][32] T
+    int B, H, W;
+};
+void stem_pack_weights(const float* w /*[32][3][3][3]*/, float* out_host /*[3][3][3][32]*/);
+hipError_t launch_stem(hipStream_t s, int dtype, const StemParams& p);
+
+// ------------------------------------------------------------------ heads: 3x3 conv (MFMA) + 1x1
+struct HeadParams {
+    const void* x;        // [B][h][w][24] T
+    const void* w0p;      // packed 3x3 weights (96 or 16 output slots), see head_pack_weights
+    const float* b0;      // [96] (two-stage) or [16] (collapsed)
+    const float* w1d;     // [96][16] dense second-stage table (two-stage only)
+    const float* b1;      // [16]
+    float* heads;         // [B][h][w][16] fp32: hm_sigmoid, wh0, wh1, lm0..9, reg0, reg1, hm_raw
+    int B, h, w;
+    int collapsed;
+};
+size_t head_packed_bytes(int dtype, int collapsed);
+// w0 [4][24][24][3][3], b0 [4][24], w1 [15][24] (rows: hm, wh0, wh1, lm0..9, reg0, reg1), b1 [15]
+void head_pack_weights(int dtype, int collapsed, const float* w0, const float* b0, const float* w1,
+                       const float* b1, void* w0p_host, float* b0_host /*[96]|[16]*/,
+                       float* w1d_host /*[96][16]*/, float* b1_host /*[16]*/);
+hipError_t launch_heads(hipStream_t s, int dtype, const HeadParams& p);
+
+// ------------------------------------------------------------------ decode
+// D3: 3x3 peak test + top-K (radix select + bitonic sort) + gather, one workgroup per image.
+struct TopkParams {
+    const float* heads;   // [B][h*w][16]
+    unsigned long long* scratch;   // [B][h*w] composite keys
+    int B, h, w, K, use_reg;
+    float* dets;          // [B][K][6]
+    float* lms;           // [B][K][10] or nullptr
+    long long* inds;      // [B][K] or nullptr
+};
+hipError_t launch_peak_topk(hipStream_t s, const TopkParams& p);
+
+// D1: threshold compaction (row-major) + box/landmark arithmetic + greedy NMS
+struct ThreshParams {
+    const float* heads;   // [B][h*w][16]
+    int B, h, w, img_h, img_w;
+    float score_thresh, nms_thresh;
+    int cap;              // candidate capacity per image
+    // workspace (device)
+    float* cand;          // [B][cap][16]: x1,y1,x2,y2,score, lm[10], pad
+    int* cand_count;      // [B]
+    int* order;           // [B][cap] candidate indices sorted by score desc
+    unsigned long long* mask;   // [B][cap][cap/64]
+    // outputs (device)
+    int max_out;
+    float* dets;          // [B][max_out][5]
+    float* lms;           // [B][max_out][10] or nullptr
+    int* counts;          // [B]
+    int* overflow;        // [1] set to 1 when some image exceeded cap
+};
+hipError_t launch_decode_threshold(hipStream_t s, const ThreshParams& p);
+// rank + suppression matrix + greedy sweep only (candidates already collected)
+hipError_t launch_nms_stages(hipStream_t s, const ThreshParams& p);
+
+// layout converters used by cf_get_heads and the per-op test entry points
+hipError_t launch_nchw_to_nhwc(hipStream_t s, int dtype, const float* src /*f32 NCHW*/, void* dst /*T NHWC*/,
+                               int B, int C, int H, int W);
+hipError_t launch_nhwc_to_nchw(hipStream_t s, int dtype, const void* src /*T NHWC*/, float* dst /*f32 NCHW*/,
+                               int B, int C, int H, int W);
+
+}  // namespace cf

@@ -1,0 +1,309 @@
+// Per-op C-ABI entry points (cf_op_*): each runs ONE production kernel on host NCHW float32
+// arrays, exactly as the torch op it replaces would be called, so the parity tests can check every
+// kernel in isolation against the oracle / the reference's golden vectors.  Layout conversion
+// NCHW<->NHWC happens on the device around the kernel; there is no CPU compute path here.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "centerface_hip.h"
+#include "cf_common.h"
+#include "cf_kernels.h"
+
+using namespace cf;
+
+namespace {
+
+thread_local std::string g_op_error;
+
+struct Scope {
+    hipStream_t s = nullptr;
+    std::vector<void*> ptrs;
+    hipError_t err = hipSuccess;
+    explicit Scope(int device) {
+        err = hipSetDevice(device);
+        if (err == hipSuccess) err = hipStreamCreate(&s);
+    }
+    ~Scope() {
+        if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
+        for (void* p : ptrs) hipFree(p);
+    }
+    void* alloc(size_t bytes) {
+        if (err != hipSuccess) return nullptr;
+        void* p = nullptr;
+        err = hipMalloc(&p, bytes + 256);
+        if (err == hipSuccess) { ptrs.push_back(p); hipMemsetAsync(p, 0, bytes + 256, s); }
+        return p;
+    }
+    void* up(const void* host, size_t bytes) {
+        void* p = alloc(bytes);
+        if (p && err == hipSuccess) err = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, s);
+        return p;
+    }
+    template <typename T> T* upv(const std::vector<T>& v) { return (T*)up(v.data(), v.size() * sizeof(T)); }
+    void chk(hipError_t e) { if (err == hipSuccess) err = e; }
+    // host f32 NCHW -> device T NHWC
+    void* to_nhwc(int dtype, const float* host, int B, int C, int H, int W) {
+        size_t n = (size_t)B * C * H * W;
+        float* src = (float*)up(host, n * 4);
+        void* dst = alloc(n * elem_size(dtype));
+        if (err == hipSuccess) chk(launch_nchw_to_nhwc(s, dtype, src, dst, B, C, H, W));
+        return dst;
+    }
+    // device T NHWC -> host f32 NCHW
+    void to_host_nchw(int dtype, const void* dev, float* host, int B, int C, int H, int W) {
+        size_t n = (size_t)B * C * H * W;
+        float* tmp = (float*)alloc(n * 4);
+        if (err == hipSuccess) chk(launch_nhwc_to_nchw(s, dtype, dev, tmp, B, C, H, W));
+        if (err == hipSuccess) chk(hipMemcpyAsync(host, tmp, n * 4, hipMemcpyDeviceToHost, s));
+        if (err == hipSuccess) chk(hipStreamSynchronize(s));
+    }
+    int result(const char* what) {
+        if (err == hipSuccess) err = hipStreamSynchronize(s);
+        if (err == hipSuccess) return CF_OK;
+        g_op_error = std::string(what) + ": " + hipGetErrorString(err);
+        return CF_EHIP;
+    }
+};
+
+bool bad_dtype(int d) { return d != CF_F32 && d != CF_BF16; }
+
+void fold(const float* bn /*[4][C]: weight,bias,mean,var*/, int C, float eps, std::vector<double>& sc, std::vector<double>& sh) {
+    sc.resize(C); sh.resize(C);
+    for (int c = 0; c < C; ++c) {
+        sc[c] = (double)bn[c] / std::sqrt((double)bn[3 * C + c] + (double)eps);
+        sh[c] = (double)bn[C + c] - (double)bn[2 * C + c] * sc[c];
+    }
+}
+
+// explicit maps (NCHW) -> the 16-float head record layout the decode kernels read
+std::vector<float> make_records(const float* hm, const float* wh, const float* reg, const float* lm, int B, int h, int w) {
+    const size_t HW = (size_t)h * w;
+    std::vector<float> rec((size_t)B * HW * 16, 0.0f);
+    for (int b = 0; b < B; ++b)
+        for (size_t i = 0; i < HW; ++i) {
+            float* r = &rec[((size_t)b * HW + i) * 16];
+            r[0] = hm[(size_t)b * HW + i];
+            if (wh) { r[1] = wh[((size_t)b * 2 + 0) * HW + i]; r[2] = wh[((size_t)b * 2 + 1) * HW + i]; }
+            if (lm) for (int c = 0; c < 10; ++c) r[3 + c] = lm[((size_t)b * 10 + c) * HW + i];
+            if (reg) { r[13] = reg[((size_t)b * 2 + 0) * HW + i]; r[14] = reg[((size_t)b * 2 + 1) * HW + i]; }
+        }
+    return rec;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cf_op_last_error(void) { return g_op_error.c_str(); }
+
+int cf_op_dwconv(int device, int dtype, const float* x, const float* w, const float* bias, float* y,
+                 int B, int C, int H, int W, int k, int stride, int pad_lo, int pad_hi, int act) {
+    if (bad_dtype(dtype) || !x || !w || !y || (C % 8) || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return CF_EINVAL;
+    const int Ho = (H + pad_lo + pad_hi - k) / stride + 1, Wo = (W + pad_lo + pad_hi - k) / stride + 1;
+    if (Ho < 1 || Wo < 1) return CF_EINVAL;
+    Scope sc(device);
+    std::vector<float> wp((size_t)k * k * C);
+    dw_pack_weights(w, C, k, wp.data());
+    DwParams p{};
+    p.x = sc.to_nhwc(dtype, x, B, C, H, W);
+    p.w = sc.upv(wp);
+    p.bias = bias ? (const float*)sc.up(bias, (size_t)C * 4) : nullptr;
+    p.y = sc.alloc((size_t)B * Ho * Wo * C * elem_size(dtype));
+    p.B = B; p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.k = k; p.s = stride; p.pad_lo = pad_lo; p.act = act;
+    if (sc.err == hipSuccess) sc.chk(launch_dw(sc.s, dtype, p));
+    sc.to_host_nchw(dtype, p.y, y, B, C, Ho, Wo);
+    return sc.result("cf_op_dwconv");
+}
+
+int cf_op_pwconv(int device, int dtype, const float* x, const float* w, const float* bias,
+                 const float* residual, float* y, int B, int Cin, int Cout, int H, int W, int act) {
+    if (bad_dtype(dtype) || !x || !w || !y || (Cin % 8) || (Cout % 8) || act < 0 || act > 2) return CF_EINVAL;
+    Scope sc(device);
+    std::vector<char> packed(pw_packed_bytes(dtype, Cin, Cout));
+    pw_pack_weights(dtype, w, Cin, Cout, packed.data());
+    PwParams p{};
+    p.x = sc.to_nhwc(dtype, x, B, Cin, H, W);
+    p.wp = sc.up(packed.data(), packed.size());
+    p.bias = bias ? (const float*)sc.up(bias, (size_t)Cout * 4) : nullptr;
+    p.res = residual ? sc.to_nhwc(dtype, residual, B, Cout, H, W) : nullptr;
+    p.y = sc.alloc((size_t)B * H * W * Cout * elem_size(dtype));
+    p.M = (long long)B * H * W; p.K = Cin; p.N = Cout; p.act = act;
+    if (sc.err == hipSuccess) sc.chk(launch_pw(sc.s, dtype, p));
+    sc.to_host_nchw(dtype, p.y, y, B, Cout, H, W);
+    return sc.result("cf_op_pwconv");
+}
+
+int cf_op_stem(int device, int dtype, const void* x, int in_format, const float* w, float* y, int B, int H, int W) {
+    if (bad_dtype(dtype) || !x || !w || !y || (H % 2) || (W % 2)) return CF_EINVAL;
+    if (in_format != CF_IN_U8_HWC_BGR && in_format != CF_IN_F32_NCHW) return CF_EINVAL;
+    Scope sc(device);
+    std::vector<float> wp(27 * 32);
+    stem_pack_weights(w, wp.data());
+    StemParams p{};
+    p.x = sc.up(x, (size_t)B * 3 * H * W * (in_format == CF_IN_U8_HWC_BGR ? 1 : 4));
+    p.in_format = in_format; p.w = sc.upv(wp);
+    p.y = sc.alloc((size_t)B * (H / 2) * (W / 2) * 32 * elem_size(dtype));
+    p.B = B; p.H = H; p.W = W;
+    if (sc.err == hipSuccess) sc.chk(launch_stem(sc.s, dtype, p));
+    sc.to_host_nchw(dtype, p.y, y, B, 32, H / 2, W / 2);
+    return sc.result("cf_op_stem");
+}
+
+int cf_op_idaup(int device, int dtype, const float* lo, const float* skip, const float* w_up,
+                const float* bn_up, const float* w_cv, const float* bn_cv, float eps, float* y,
+                int B, int C, int Cs, int h, int w) {
+    if (bad_dtype(dtype) || !lo || !skip || !w_up || !bn_up || !w_cv || !bn_cv || !y || (C % 8) || (Cs % 8)) return CF_EINVAL;
+    Scope sc(device);
+    std::vector<double> s1, h1, s2, h2;
+    fold(bn_cv, C, eps, s1, h1);
+    fold(bn_up, C, eps, s2, h2);
+    std::vector<float> wf((size_t)C * Cs), bias(C), uw(4 * C), ub(C);
+    for (int n = 0; n < C; ++n) {
+        for (int k = 0; k < Cs; ++k) wf[(size_t)n * Cs + k] = (float)((double)w_cv[(size_t)n * Cs + k] * s1[n]);
+        bias[n] = (float)h1[n];
+        for (int t = 0; t < 4; ++t) uw[(size_t)t * C + n] = (float)((double)w_up[n * 4 + t] * s2[n]);
+        ub[n] = (float)h2[n];
+    }
+    std::vector<char> packed(pw_packed_bytes(dtype, Cs, C));
+    pw_pack_weights(dtype, wf.data(), Cs, C, packed.data());
+    const int Ho = 2 * h, Wo = 2 * w;
+    PwParams p{};
+    p.x = sc.to_nhwc(dtype, skip, B, Cs, Ho, Wo);
+    p.low = sc.to_nhwc(dtype, lo, B, C, h, w);
+    p.wp = sc.up(packed.data(), packed.size());
+    p.bias = sc.upv(bias); p.upw = sc.upv(uw); p.upb = sc.upv(ub);
+    p.y = sc.alloc((size_t)B * Ho * Wo * C * elem_size(dtype));
+    p.M = (long long)B * Ho * Wo; p.K = Cs; p.N = C; p.act = 2; p.Ho = Ho; p.Wo = Wo;
+    if (sc.err == hipSuccess) sc.chk(launch_pw(sc.s, dtype, p));
+    sc.to_host_nchw(dtype, p.y, y, B, C, Ho, Wo);
+    return sc.result("cf_op_idaup");
+}
+
+int cf_op_heads(int device, int dtype, const float* x, const float* w0, const float* b0,
+                const float* w1, const float* b1, float* out, int B, int h, int w, int collapse) {
+    if (bad_dtype(dtype) || !x || !w0 || !b0 || !w1 || !b1 || !out) return CF_EINVAL;
+    Scope sc(device);
+    std::vector<char> packed(head_packed_bytes(dtype, collapse ? 1 : 0));
+    std::vector<float> b0h(96), w1d(96 * 16), b1h(16);
+    head_pack_weights(dtype, collapse ? 1 : 0, w0, b0, w1, b1, packed.data(), b0h.data(), w1d.data(), b1h.data());
+    HeadParams p{};
+    p.x = sc.to_nhwc(dtype, x, B, 24, h, w);
+    p.w0p = sc.up(packed.data(), packed.size());
+    p.b0 = sc.upv(b0h); p.w1d = sc.upv(w1d); p.b1 = sc.upv(b1h);
+    const size_t HW = (size_t)h * w;
+    p.heads = (float*)sc.alloc((size_t)B * HW * 16 * 4);
+    p.B = B; p.h = h; p.w = w; p.collapsed = collapse ? 1 : 0;
+    if (sc.err == hipSuccess) sc.chk(launch_heads(sc.s, dtype, p));
+    std::vector<float> rec((size_t)B * HW * 16);
+    if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(rec.data(), p.heads, rec.size() * 4, hipMemcpyDeviceToHost, sc.s));
+    int r = sc.result("cf_op_heads");
+    if (r) return r;
+    for (int b = 0; b < B; ++b)
+        for (size_t i = 0; i < HW; ++i) {
+            const float* rr = &rec[((size_t)b * HW + i) * 16];
+            out[((size_t)b * 15 + 0) * HW + i] = rr[15];                      // raw hm logit
+            for (int c = 1; c < 15; ++c) out[((size_t)b * 15 + c) * HW + i] = rr[c];
+        }
+    return CF_OK;
+}
+
+int cf_op_ctdet_decode(int device, const float* heat, const float* wh, const float* reg, const float* lm,
+                       int B, int h, int w, int K, float* dets, float* lms, int64_t* inds) {
+    if (!heat || !wh || !dets || B < 1 || K < 1 || K > 1024 || K > h * w || h * w > (1 << 17)) return CF_EINVAL;
+    Scope sc(device);
+    std::vector<float> rec = make_records(heat, wh, reg, lm, B, h, w);
+    TopkParams p{};
+    p.heads = sc.upv(rec);
+    p.scratch = (unsigned long long*)sc.alloc((size_t)B * h * w * 8);
+    p.B = B; p.h = h; p.w = w; p.K = K; p.use_reg = reg ? 1 : 0;
+    p.dets = (float*)sc.alloc((size_t)B * K * 6 * 4);
+    p.lms = (lms && lm) ? (float*)sc.alloc((size_t)B * K * 10 * 4) : nullptr;
+    p.inds = inds ? (long long*)sc.alloc((size_t)B * K * 8) : nullptr;
+    if (sc.err == hipSuccess) sc.chk(launch_peak_topk(sc.s, p));
+    if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(dets, p.dets, (size_t)B * K * 6 * 4, hipMemcpyDeviceToHost, sc.s));
+    if (p.lms && sc.err == hipSuccess) sc.chk(hipMemcpyAsync(lms, p.lms, (size_t)B * K * 10 * 4, hipMemcpyDeviceToHost, sc.s));
+    if (p.inds && sc.err == hipSuccess) sc.chk(hipMemcpyAsync(inds, p.inds, (size_t)B * K * 8, hipMemcpyDeviceToHost, sc.s));
+    return sc.result("cf_op_ctdet_decode");
+}
+
+static int run_threshold(Scope& sc, const float* d_heads, int B, int h, int w, int img_h, int img_w,
+                         float score_thresh, float nms_thresh, int cap, int max_out,
+                         float* dets, float* lms, int32_t* counts, int* overflow_out) {
+    const size_t words = (cap + 63) / 64;
+    ThreshParams p{};
+    p.heads = d_heads; p.B = B; p.h = h; p.w = w; p.img_h = img_h; p.img_w = img_w;
+    p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = cap;
+    p.cand = (float*)sc.alloc((size_t)B * cap * 16 * 4);
+    p.cand_count = (int*)sc.alloc((size_t)B * 4);
+    p.order = (int*)sc.alloc((size_t)B * cap * 4);
+    p.mask = (unsigned long long*)sc.alloc((size_t)B * cap * words * 8);
+    p.max_out = max_out;
+    p.dets = (float*)sc.alloc((size_t)B * max_out * 5 * 4);
+    p.lms = lms ? (float*)sc.alloc((size_t)B * max_out * 10 * 4) : nullptr;
+    p.counts = (int*)sc.alloc((size_t)B * 4);
+    p.overflow = (int*)sc.alloc(4);
+    if (sc.err == hipSuccess) sc.chk(launch_decode_threshold(sc.s, p));
+    if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(dets, p.dets, (size_t)B * max_out * 5 * 4, hipMemcpyDeviceToHost, sc.s));
+    if (lms && sc.err == hipSuccess) sc.chk(hipMemcpyAsync(lms, p.lms, (size_t)B * max_out * 10 * 4, hipMemcpyDeviceToHost, sc.s));
+    if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(counts, p.counts, (size_t)B * 4, hipMemcpyDeviceToHost, sc.s));
+    if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(overflow_out, p.overflow, 4, hipMemcpyDeviceToHost, sc.s));
+    return sc.result("decode_threshold");
+}
+
+int cf_op_decode_threshold(int device, const float* hm, const float* wh, const float* lm,
+                           int B, int h, int w, int img_h, int img_w, float score_thresh,
+                           float nms_thresh, int max_out, float* dets, float* lms, int32_t* counts) {
+    if (!hm || !wh || !dets || !counts || B < 1 || max_out < 1) return CF_EINVAL;
+    Scope sc(device);
+    std::vector<float> rec = make_records(hm, wh, nullptr, lm, B, h, w);
+    const float* d_heads = sc.upv(rec);
+    const int HW = h * w;
+    const int cap = HW < 4096 ? (HW + 63) / 64 * 64 : 4096;
+    int overflow = 0;
+    int r = run_threshold(sc, d_heads, B, h, w, img_h, img_w, score_thresh, nms_thresh, cap, max_out, dets, lms, counts, &overflow);
+    if (r) return r;
+    if (overflow) { g_op_error = "candidate capacity exceeded"; return CF_EOVERFLOW; }
+    return CF_OK;
+}
+
+int cf_op_nms(int device, const float* boxes, const float* scores, int n, float nms_thresh, int32_t* keep, int32_t* n_keep) {
+    // CenterFace.nms alone: feed the candidates through the D1 kernels' rank/mask/sweep stages by
+    // presenting them as pre-collected candidates.
+    if (!boxes || !scores || !keep || !n_keep || n < 0) return CF_EINVAL;
+    if (n == 0) { *n_keep = 0; return CF_OK; }
+    Scope sc(device);
+    const int cap = (n + 63) / 64 * 64;
+    const size_t words = cap / 64;
+    std::vector<float> cand((size_t)cap * 16, 0.0f);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < 4; ++j) cand[(size_t)i * 16 + j] = boxes[i * 4 + j];
+        cand[(size_t)i * 16 + 4] = scores[i];
+        cand[(size_t)i * 16 + 5] = (float)i;           // carried through as "landmark 0" = original index
+    }
+    ThreshParams p{};
+    p.B = 1; p.cap = cap; p.nms_thresh = nms_thresh;
+    p.cand = sc.upv(cand);
+    p.cand_count = (int*)sc.up(&n, 4);
+    p.order = (int*)sc.alloc((size_t)cap * 4);
+    p.mask = (unsigned long long*)sc.alloc((size_t)cap * words * 8);
+    p.max_out = n;
+    p.dets = (float*)sc.alloc((size_t)n * 5 * 4);
+    p.lms = (float*)sc.alloc((size_t)n * 10 * 4);
+    p.counts = (int*)sc.alloc(4);
+    p.overflow = (int*)sc.alloc(4);
+    if (sc.err == hipSuccess) sc.chk(launch_nms_stages(sc.s, p));
+    std::vector<float> l((size_t)n * 10);
+    int cnt = 0;
+    if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(l.data(), p.lms, l.size() * 4, hipMemcpyDeviceToHost, sc.s));
+    if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(&cnt, p.counts, 4, hipMemcpyDeviceToHost, sc.s));
+    int r = sc.result("cf_op_nms");
+    if (r) return r;
+    for (int i = 0; i < cnt; ++i) keep[i] = (int32_t)l[(size_t)i * 10];
+    *n_keep = cnt;
+    return CF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+// Pointwise (1x1) convolution on MFMA for gfx950: y[M][N] = epi(x[M][K] . w[N][K]^T).
+//
+// Replaces every nn.Conv2d(kernel_size=1) instance on the hot path: MBConv expand (+Swish,
+// model/centernet.py:109-110), MBConv project (+residual, :117-118,:134-137), conv_1x1_bn (:179-184),
+// IDAUp.conv + the whole IDAUp up-branch as an epilogue (:186-204), ShuffleV2 pw convs
+// (model/blocks.py:22-24,31-33).
+//
+// Design (MI355X-first, not a GEMM library call):
+//  * The op is HBM-bound (AI ~ 29 flop/B at bf16 vs machine balance ~312), so the kernel is a
+//    streaming kernel that happens to use the matrix core.  No LDS: the activation operand is read
+//    exactly once, straight into MFMA operand registers; weights (<= 307 KB) are pre-packed on the
+//    host in fragment order so that every wave-load is one contiguous 1 KiB line burst from L2.
+//  * Computes D^T = W . X^T with v_mfma_f32_32x32x16_bf16 (bf16 storage) or the exact-fp32
+//    v_mfma_f32_32x32x2_f32 (fp32 parity mode): the pixel index is the MFMA column, so each lane ends
+//    up owning one pixel, and -- because the output-channel <-> MFMA-row assignment is free (weights
+//    are repacked) -- 16 CONTIGUOUS output channels of it: epilogue and stores are 16-byte vectors.
+//  * The K <-> MFMA k-slot assignment is free as well (sum over k): lane half h owns the contiguous
+//    half [h*K/2, (h+1)*K/2) of its pixel's row, so successive 16-byte loads of a lane walk one
+//    cache line instead of striding across rows.
+#include "cf_common.h"
+#include "cf_kernels.h"
+
+namespace cf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+// channel held by MFMA row-slot i of n-block nb (see header comment): lane (pixel, h) accumulator
+// register r  <->  row i = (r&3) + 8*(r>>2) + 4*h  <->  channel nb*32 + h*16 + r
+static inline int slot_channel(int nb, int i) {
+    int h = (i >> 2) & 1;
+    int r = (i & 3) + 4 * (i >> 3);
+    return nb * 32 + h * 16 + r;
+}
+
+static inline int pw_chunks(int dtype, int K) { return (int)((size_t)K * elem_size(dtype) / 16); }
+
+size_t pw_packed_bytes(int dtype, int K, int N) {
+    int NC = pw_chunks(dtype, K), NCh = (NC + 1) / 2;
+    int NB = (N + 31) / 32;
+    int NBpad = (NB + 7) / 8 * 8;                  // kernels may touch up to NBW-1 blocks past NB
+    return (size_t)NBpad * NCh * 64 * 16;
+}
+
+void pw_pack_weights(int dtype, const float* w, int K, int N, void* out_host) {
+    const int P = per16(dtype);
+    int NC = pw_chunks(dtype, K), NCh = (NC + 1) / 2;
+    int NB = (N + 31) / 32;
+    size_t total = pw_packed_bytes(dtype, K, N);
+    __builtin_memset(out_host, 0, total);
+    for (int nb = 0; nb < NB; ++nb)
+        for (int j = 0; j < NCh; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                int i = lane & 31, h = lane >> 5;
+                int ch = slot_channel(nb, i);
+                int c = h * NCh + j;
+                if (ch >= N || c >= NC) continue;
+                char* dst = (char*)out_host + (((size_t)nb * NCh + j) * 64 + lane) * 16;
+                const float* src = w + (size_t)ch * K + (size_t)c * P;
+                if (dtype == 0) {
+                    __builtin_memcpy(dst, src, 16);
+                } else {
+                    uint16_t* d = (uint16_t*)dst;
+                    for (int e = 0; e < 8; ++e) d[e] = host_f32_to_bf16(src[e]);
+                }
+            }
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w),
+                                                      __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+    }
+};
+
+// RES: 0 none, 1 residual add, 2 IDAUp up-branch add
+template <typename T, int NBW, int ACT, int RES, bool BIAS>
+__global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
+    constexpr int P = Elem<T>::PER16;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int pl = lane & 31, h = lane >> 5;
+    const long long pb = (long long)blockIdx.x * 4 + wave;
+    if (pb * 32 >= p.M) return;                               // wave-uniform
+    const long long m = pb * 32 + pl;
+    const bool mvalid = m < p.M;
+    const long long mr = mvalid ? m : p.M - 1;
+    const int NC = (int)((size_t)p.K * sizeof(T) / 16), NCh = (NC + 1) >> 1;
+    const int NB = (p.N + 31) >> 5;
+    const int nb0 = blockIdx.y * NBW;
+
+    const char* xrow = (const char*)p.x + (size_t)mr * p.K * sizeof(T) + (size_t)h * NCh * 16;
+    const char* wbase = (const char*)p.wp + ((size_t)nb0 * NCh * 64 + lane) * 16;
+    const int jmax = (h == 0) ? NCh : NC - NCh;               // valid chunks of this half
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    for (int j = 0; j < NCh; ++j) {
+        u32x4 xc = (j < jmax) ? ld16(xrow + (size_t)j * 16) : zero16();
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            if (nb0 + i < NB) {                               // uniform
+                u32x4 wc = ld16(wbase + ((size_t)i * NCh + j) * 1024);
+                Mma<T>::run(acc[i], wc, xc);
+            }
+        }
+    }
+
+    if (!mvalid) return;
+    // ---- epilogue: this lane owns pixel m, channels (nb0+i)*32 + h*16 + [0,16)
+    size_t low_row = 0; int tap = 0;
+    if constexpr (RES == 2) {
+        long long hw = (long long)p.Ho * p.Wo;
+        long long b = m / hw; int rem = (int)(m - b * hw);
+        int yy = rem / p.Wo, xx = rem - yy * p.Wo;
+        low_row = ((size_t)b * (p.Ho >> 1) + (yy >> 1)) * (p.Wo >> 1) + (xx >> 1);
+        tap = ((yy & 1) << 1) | (xx & 1);
+    }
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        if (nb0 + i >= NB) break;
+        const int cb = (nb0 + i) * 32 + h * 16;
+#pragma unroll
+        for (int g = 0; g < 16 / P; ++g) {
+            const int ch = cb + g * P;
+            if (ch >= p.N) break;
+            float v[P];
+#pragma unroll
+            for (int e = 0; e < P; ++e) {
+                float t = acc[i][g * P + e];
+                if constexpr (BIAS) t += p.bias[ch + e];
+                v[e] = act_f<ACT>(t);
+            }
+            if constexpr (RES == 1) {
+                float r[P];
+                unpack16<T>(ld16((const char*)p.res + ((size_t)m * p.N + ch) * sizeof(T)), r);
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] += r[e];
+            } else if constexpr (RES == 2) {
+                float r[P];
+                unpack16<T>(ld16((const char*)p.low + (low_row * p.N + ch) * sizeof(T)), r);
+#pragma unroll
+                for (int e = 0; e < P; ++e)
+                    v[e] += relu_f(r[e] * p.upw[tap * p.N + ch + e] + p.upb[ch + e]);
+            }
+            st16((char*)p.y + ((size_t)m * p.N + ch) * sizeof(T), pack16<T>(v));
+        }
+    }
+}
+
+template <typename T, int NBW>
+static hipError_t dispatch_epi(hipStream_t s, const PwParams& p, dim3 grid) {
+    dim3 blk(256);
+    const bool bias = p.bias != nullptr;
+    const int res = p.low ? 2 : (p.res ? 1 : 0);
+#define CF_PW_LAUNCH(ACT, RES, BIAS) \
+    set_kernel_tag("void cf::pw_kernel<%s, %d, %d, %d, %s>(cf::PwParams)", type_tag<T>(), NBW, ACT, RES, BIAS ? "true" : "false"); \
+    hipLaunchKernelGGL((pw_kernel<T, NBW, ACT, RES, BIAS>), grid, blk, 0, s, p); return hipGetLastError();
+    if (p.act == 1 && res == 0 && !bias) { CF_PW_LAUNCH(1, 0, false) }   // expand + Swish
+    if (p.act == 0 && res == 0 && !bias) { CF_PW_LAUNCH(0, 0, false) }   // project
+    if (p.act == 0 && res == 1 && !bias) { CF_PW_LAUNCH(0, 1, false) }   // project + residual
+    if (p.act == 1 && res == 0 && bias)  { CF_PW_LAUNCH(1, 0, true) }    // conv_1x1_bn
+    if (p.act == 2 && res == 2 && bias)  { CF_PW_LAUNCH(2, 2, true) }    // IDAUp
+    if (p.act == 2 && res == 0 && bias)  { CF_PW_LAUNCH(2, 0, true) }    // ShuffleV2 pw+BN+ReLU
+    if (p.act == 0 && res == 0 && bias)  { CF_PW_LAUNCH(0, 0, true) }    // plain conv + bias
+#undef CF_PW_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+template <typename T>
+static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
+    const int NB = (p.N + 31) / 32;
+    const long long gx = (p.M + 127) / 128;
+    // n-blocks per wave: as many as fit 64..128 accumulator VGPRs, fewer when the grid would be
+    // too small to fill 256 CUs x 8 waves.
+    int nbw = NB >= 4 ? 4 : NB;
+    if (NB > 4 && (NB % 3 == 0) && (NB % 4 != 0)) nbw = 3;
+    if (NB == 5) nbw = 5;
+    while (nbw > 1 && gx * ((NB + nbw - 1) / nbw) < 1024) nbw = (nbw + 1) / 2;
+    dim3 grid((unsigned)gx, (unsigned)((NB + nbw - 1) / nbw));
+    switch (nbw) {
+        case 1: return dispatch_epi<T, 1>(s, p, grid);
+        case 2: return dispatch_epi<T, 2>(s, p, grid);
+        case 3: return dispatch_epi<T, 3>(s, p, grid);
+        case 4: return dispatch_epi<T, 4>(s, p, grid);
+        default: return dispatch_epi<T, 5>(s, p, grid);
+    }
+}
+
+hipError_t launch_pw(hipStream_t s, int dtype, const PwParams& p) {
+    if (p.M <= 0) return hipSuccess;
+    if (p.K % 8 || p.N % 8) return hipErrorInvalidValue;
+    return dtype == 0 ? dispatch_nbw<float>(s, p) : dispatch_nbw<bf16_t>(s, p);
+}
+
+}  // namespace cf
