@@ -53,11 +53,12 @@ hipError_t launch_dw(hipStream_t s, int dtype, const DwParams& p);
 struct StemParams {
     const void* x;        // u8 [B][H][W][3] (BGR) or f32 [B][3][H][W]
     int in_format;        // CF_IN_U8_HWC_BGR / CF_IN_F32_NCHW
-    const float* w;       // [3][3][3][32] fp32 (ky,kx,ci,co)
+    const void* w;        // packed MFMA fragments, see stem_pack_weights
     void* y;              // [B][H/2][W/2][32] T
     int B, H, W;
 };
-void stem_pack_weights(const float* w /*[32][3][3][3]*/, float* out_host /*[3][3][3][32]*/);
+size_t stem_packed_bytes(int dtype);
+void stem_pack_weights(int dtype, const float* w /*[32][3][3][3]*/, void* out_host);
 hipError_t launch_stem(hipStream_t s, int dtype, const StemParams& p);
 
 // ------------------------------------------------------------------ heads: 3x3 conv (MFMA) + 1x1

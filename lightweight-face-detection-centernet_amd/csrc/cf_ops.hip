@@ -140,11 +140,11 @@ int cf_op_stem(int device, int dtype, const void* x, int in_format, const float*
     if (bad_dtype(dtype) || !x || !w || !y || (H % 2) || (W % 2)) return CF_EINVAL;
     if (in_format != CF_IN_U8_HWC_BGR && in_format != CF_IN_F32_NCHW) return CF_EINVAL;
     Scope sc(device);
-    std::vector<float> wp(27 * 32);
-    stem_pack_weights(w, wp.data());
+    std::vector<char> wp(stem_packed_bytes(dtype));
+    stem_pack_weights(dtype, w, wp.data());
     StemParams p{};
     p.x = sc.up(x, (size_t)B * 3 * H * W * (in_format == CF_IN_U8_HWC_BGR ? 1 : 4));
-    p.in_format = in_format; p.w = sc.upv(wp);
+    p.in_format = in_format; p.w = sc.up(wp.data(), wp.size());
     p.y = sc.alloc((size_t)B * (H / 2) * (W / 2) * 32 * elem_size(dtype));
     p.B = B; p.H = H; p.W = W;
     if (sc.err == hipSuccess) sc.chk(launch_stem(sc.s, dtype, p));

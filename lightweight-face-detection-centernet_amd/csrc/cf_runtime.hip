@@ -346,10 +346,9 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
 
     for (auto& op : c->ops) {
         if (op.kind == OP_STEM) {
-            std::vector<float> w(27 * 32);
-            stem_pack_weights(ws.f(op.wkey), w.data());
-            float* d; int r = upload(c, w, &d); if (r) return r;
-            op.wp = d;
+            std::vector<char> w(stem_packed_bytes(dt));
+            stem_pack_weights(dt, ws.f(op.wkey), w.data());
+            int r = upload_bytes(c, w, &op.wp); if (r) return r;
         } else if (op.kind == OP_DW) {
             std::vector<float> w((size_t)op.k * op.k * op.Cin);
             dw_pack_weights(ws.f(op.wkey), op.Cin, op.k, w.data());
@@ -416,7 +415,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
     auto bp = [&](int id) -> void* { return id < 0 ? nullptr : c->bufs[id].p; };
     switch (op.kind) {
         case OP_STEM: {
-            StemParams p{}; p.x = net_in; p.in_format = in_format; p.w = (const float*)op.wp; p.y = bp(op.out);
+            StemParams p{}; p.x = net_in; p.in_format = in_format; p.w = op.wp; p.y = bp(op.out);
             p.B = B; p.H = op.Hin; p.W = op.Win;
             return launch_stem(c->stream, c->dtype, p);
         }

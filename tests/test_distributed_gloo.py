@@ -1,0 +1,59 @@
+"""N > 1 path on CPU: world_size-2 gloo process group, batch sharded by rank, records gathered
+rank-major -> identical to the unsharded order."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(repo)r)
+import centerface_amd as cfa
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B, K = 6, 5
+full_d = np.random.default_rng(0).standard_normal((B, K, 6)).astype(np.float32)
+full_l = np.random.default_rng(1).standard_normal((B, K, 10)).astype(np.float32)
+lo, hi = cfa.distributed.shard_range(B, rank, world)
+rec = cfa.distributed.pack_records(torch.from_numpy(full_d[lo:hi]), torch.from_numpy(full_l[lo:hi]))
+out = cfa.distributed.gather_records(rec)
+ref = np.concatenate([full_d, full_l], axis=2)
+assert out.shape == (B, K, 16), out.shape
+assert np.array_equal(out.numpy(), ref)
+dist.barrier()
+dist.destroy_process_group()
+print("rank %%d ok" %% rank)
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_gather_records_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"repo": REPO})
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
+
+
+def test_gather_records_single_process_is_identity():
+    import torch
+    import centerface_amd as cfa
+    x = torch.arange(2 * 3 * 16, dtype=torch.float32).reshape(2, 3, 16)
+    assert cfa.distributed.gather_records(x) is x
+    d, l = np.zeros((2, 3, 6), np.float32), np.ones((2, 3, 10), np.float32)
+    assert cfa.distributed.pack_records(d, l).shape == (2, 3, 16)
