@@ -48,6 +48,8 @@ extern "C" {
 #define CF_FLAG_COLLAPSE_HEADS  1u   /* fold each head's conv3x3+b -> conv1x1+b (a linear pair,
                                         model/centernet.py:249-256) into one 3x3 conv 24->15 */
 #define CF_FLAG_NO_GRAPH        2u   /* launch kernels eagerly instead of replaying a hipGraph */
+#define CF_FLAG_NO_FUSE         4u   /* run every MBConv block as three kernels (expand, dw, project)
+                                        instead of the fused kernel that keeps the 6x tensor in LDS */
 
 typedef struct cf_ctx cf_ctx;
 
@@ -142,6 +144,12 @@ int cf_op_dwconv(int device, int dtype, const float* x, const float* w, const fl
  * (model/centernet.py:109-110,117-118,134-137,179-184; blocks.py:22-24,31-33). act 0/1 swish/2 relu */
 int cf_op_pwconv(int device, int dtype, const float* x, const float* w, const float* bias,
                  const float* residual, float* y, int B, int Cin, int Cout, int H, int W, int act);
+/* MBConvBlock.forward, se=False (model/centernet.py:89-140) as ONE fused kernel: x [B,Cin,H,W],
+ * w_exp [hid,Cin], w_dw [hid,1,k,k], w_proj [Cout,hid]; residual when Cin==Cout and stride==1.
+ * Returns CF_EINVAL for shapes the fused kernel does not cover (t == 1, Cout > 96). */
+int cf_op_mbconv(int device, int dtype, const float* x, const float* w_exp, const float* w_dw,
+                 const float* w_proj, float* y, int B, int Cin, int hid, int Cout, int H, int W,
+                 int k, int stride);
 /* stem: ConvReLU(3,32,3,stride 2) on a normalised float NCHW tensor or a uint8 HWC BGR image
  * (model/centernet.py:224 ; centerface.py:32-37). y [B,32,H/2,W/2] */
 int cf_op_stem(int device, int dtype, const void* x, int in_format, const float* w, float* y,

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 CF_OK = 0
 CF_F32, CF_BF16 = 0, 1
 CF_IN_U8_HWC_BGR, CF_IN_F32_NCHW = 0, 1
-CF_FLAG_COLLAPSE_HEADS, CF_FLAG_NO_GRAPH = 1, 2
+CF_FLAG_COLLAPSE_HEADS, CF_FLAG_NO_GRAPH, CF_FLAG_NO_FUSE = 1, 2, 4
 CF_EOVERFLOW = -6
 
 # every symbol include/centerface_hip.h declares (checked by tests/test_abi.py)
@@ -22,7 +22,7 @@ EXPORTS = (
     "cf_load_weights", "cf_forward", "cf_get_heads", "cf_decode_topk", "cf_decode_threshold",
     "cf_detect_topk", "cf_synchronize", "cf_event_record", "cf_event_elapsed_ms",
     "cf_profile_forward", "cf_device_alloc", "cf_device_free", "cf_memcpy_h2d", "cf_memcpy_d2h",
-    "cf_op_last_error", "cf_op_dwconv", "cf_op_pwconv", "cf_op_stem", "cf_op_idaup", "cf_op_heads",
+    "cf_op_last_error", "cf_op_mbconv", "cf_op_dwconv", "cf_op_pwconv", "cf_op_stem", "cf_op_idaup", "cf_op_heads",
     "cf_op_ctdet_decode", "cf_op_decode_threshold", "cf_op_nms",
 )
 
@@ -87,6 +87,7 @@ def lib():
         L.cf_op_dwconv.argtypes = [i, i, fp, fp, fp, fp] + [i] * 9
         L.cf_op_pwconv.argtypes = [i, i, fp, fp, fp, fp, fp] + [i] * 6
         L.cf_op_stem.argtypes = [i, i, vp, i, fp, fp, i, i, i]
+        L.cf_op_mbconv.argtypes = [i, i, fp, fp, fp, fp, fp] + [i] * 8
         L.cf_op_idaup.argtypes = [i, i, fp, fp, fp, fp, fp, fp, C.c_float, fp] + [i] * 5
         L.cf_op_heads.argtypes = [i, i, fp, fp, fp, fp, fp, fp, i, i, i, i]
         L.cf_op_ctdet_decode.argtypes = [i, fp, fp, fp, fp, i, i, i, i, fp, fp, vp]

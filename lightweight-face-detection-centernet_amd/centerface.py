@@ -27,14 +27,14 @@ class Engine(object):
     """One cf_ctx: one GPU, one stream, fixed (H, W), batch up to ``max_batch``."""
 
     def __init__(self, height, width, max_batch=1, dtype="fp32", device=0, weights=None,
-                 collapse_heads=False):
+                 collapse_heads=False, fuse=True):
         L = _lib.lib()
         if dtype not in _DTYPES:
             raise ValueError("dtype must be one of %s" % sorted(_DTYPES))
         self.H, self.W, self.max_batch, self.device = int(height), int(width), int(max_batch), int(device)
         self.h, self.w = self.H // 4, self.W // 4
         self.dtype = dtype
-        flags = _lib.CF_FLAG_COLLAPSE_HEADS if collapse_heads else 0
+        flags = (_lib.CF_FLAG_COLLAPSE_HEADS if collapse_heads else 0) | (0 if fuse else _lib.CF_FLAG_NO_FUSE)
         handle = C.c_void_p()
         _lib.check(L.cf_create(self.device, self.max_batch, self.H, self.W, _DTYPES[dtype], flags, C.byref(handle)))
         self._h = handle

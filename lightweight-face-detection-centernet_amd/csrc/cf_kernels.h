@@ -49,6 +49,28 @@ struct DwParams {
 void dw_pack_weights(const float* w /*[C][1][k][k]*/, int C, int k, float* out_host /*[k][k][C]*/);
 hipError_t launch_dw(hipStream_t s, int dtype, const DwParams& p);
 
+// ------------------------------------------------------------------ fused MBConv block
+struct MbGeom {
+    bool ok;              // false: this block shape is not supported by the fused kernel
+    int HC, nq;           // hidden-channel chunk and number of chunks (hid = HC * nq)
+    int NBE, JX, HALF, NBO, rowb;
+    size_t lds_bytes, wexp_bytes, wdw_floats, wproj_bytes;
+};
+MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s);
+void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int k,
+                     const float* we /*[hid][Cin]*/, const float* wd /*[hid][k*k]*/, const float* wp /*[Cout][hid]*/,
+                     void* wexp_host, float* wdw_host, void* wproj_host);
+struct MbParams {
+    const void* x;        // [B][Hin][Win][Cin] T
+    void* y;              // [B][Hout][Wout][Cout] T
+    const void* wexp; const float* wdw; const void* wproj;
+    int B, Hin, Win, Hout, Wout, Cin, hid, Cout;
+    int k, s, pad_lo, residual;
+    int HC, nq, NBE, JX, HALF, rowb;
+    size_t lds_bytes;
+};
+hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p);
+
 // ------------------------------------------------------------------ stem 3x3 s2 3->32 + Swish
 struct StemParams {
     const void* x;        // u8 [B][H][W][3] (BGR) or f32 [B][3][H][W]

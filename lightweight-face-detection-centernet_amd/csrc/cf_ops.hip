@@ -136,6 +136,29 @@ int cf_op_pwconv(int device, int dtype, const float* x, const float* w, const fl
     return sc.result("cf_op_pwconv");
 }
 
+int cf_op_mbconv(int device, int dtype, const float* x, const float* w_exp, const float* w_dw,
+                 const float* w_proj, float* y, int B, int Cin, int hid, int Cout, int H, int W, int k, int stride) {
+    if (bad_dtype(dtype) || !x || !w_exp || !w_dw || !w_proj || !y || B < 1) return CF_EINVAL;
+    MbGeom g = mb_geometry(dtype, Cin, hid, Cout, k, stride);
+    if (!g.ok || hid == Cin) { g_op_error = "shape not covered by the fused MBConv kernel"; return CF_EINVAL; }
+    const int pd = k - stride > 0 ? k - stride : 0;
+    const int Ho = (H + pd - k) / stride + 1, Wo = (W + pd - k) / stride + 1;
+    Scope sc(device);
+    std::vector<char> we(g.wexp_bytes), wp(g.wproj_bytes);
+    std::vector<float> wd(g.wdw_floats);
+    mb_pack_weights(dtype, g, Cin, hid, Cout, k, w_exp, w_dw, w_proj, we.data(), wd.data(), wp.data());
+    MbParams p{};
+    p.x = sc.to_nhwc(dtype, x, B, Cin, H, W);
+    p.y = sc.alloc((size_t)B * Ho * Wo * Cout * elem_size(dtype));
+    p.wexp = sc.up(we.data(), we.size()); p.wdw = sc.upv(wd); p.wproj = sc.up(wp.data(), wp.size());
+    p.B = B; p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.Cin = Cin; p.hid = hid; p.Cout = Cout;
+    p.k = k; p.s = stride; p.pad_lo = pd / 2; p.residual = (Cin == Cout && stride == 1) ? 1 : 0;
+    p.HC = g.HC; p.nq = g.nq; p.NBE = g.NBE; p.JX = g.JX; p.HALF = g.HALF; p.rowb = g.rowb; p.lds_bytes = g.lds_bytes;
+    if (sc.err == hipSuccess) sc.chk(launch_mbconv(sc.s, dtype, p));
+    sc.to_host_nchw(dtype, p.y, y, B, Cout, Ho, Wo);
+    return sc.result("cf_op_mbconv");
+}
+
 int cf_op_stem(int device, int dtype, const void* x, int in_format, const float* w, float* y, int B, int H, int W) {
     if (bad_dtype(dtype) || !x || !w || !y || (H % 2) || (W % 2)) return CF_EINVAL;
     if (in_format != CF_IN_U8_HWC_BGR && in_format != CF_IN_F32_NCHW) return CF_EINVAL;

@@ -31,8 +31,8 @@ const int kSettings[7][5] = {  // t, c, n, s, k -- model/centernet.py:211-219
     {1, 16, 1, 1, 3}, {6, 24, 2, 2, 3}, {6, 32, 2, 2, 5}, {6, 64, 2, 2, 3},
     {6, 96, 2, 1, 5}, {6, 160, 2, 2, 5}, {6, 320, 1, 1, 3}};
 
-enum OpKind { OP_STEM = 0, OP_PW, OP_DW, OP_HEAD };
-const char* kKindName[] = {"stem", "pw", "dw", "head"};
+enum OpKind { OP_STEM = 0, OP_PW, OP_DW, OP_HEAD, OP_MB };
+const char* kKindName[] = {"stem", "pw", "dw", "head", "mbconv"};
 
 struct Op {
     OpKind kind;
@@ -46,6 +46,9 @@ struct Op {
     // device weights
     void* wp = nullptr; float* bias = nullptr; float* upw = nullptr; float* upb = nullptr;
     float* b1 = nullptr; float* w1d = nullptr;
+    // fused MBConv (OP_MB): Cin -> hid -> Cout
+    int hid = 0; bool residual = false; std::string wkey_dw, wkey_proj;
+    MbGeom geo{}; void* wexp = nullptr; float* wdw = nullptr; void* wproj = nullptr;
     double macs = 0;                                  // per image
 };
 
@@ -117,6 +120,26 @@ void build_plan(cf_ctx* c) {
             const int s = (i == 0) ? kSettings[li][3] : 1;
             const int hid = cin * t;
             char pre[32]; snprintf(pre, sizeof pre, "layer%d.%d", li, i);
+            const int p = std::max(k - s, 0);      // _get_padding (:68-70)
+            const int Ho = (curH + p - k) / s + 1, Wo = (curW + p - k) / s + 1;
+            const bool residual = (cin == cout && s == 1);      // :101
+            int dst = (cur == A) ? B : A;
+            if (li == 1 && i == n - 1) dst = S1;                 // x1 (:266)
+            if (li == 2 && i == n - 1) dst = S2;                 // x2 (:267)
+            if (li == 4 && i == n - 1) dst = S4;                 // x4 (:269)
+            MbGeom geo = mb_geometry(c->dtype, cin, hid, cout, k, s);
+            if (t != 1 && geo.ok && !(c->flags & CF_FLAG_NO_FUSE)) {
+                // fused expand -> dw -> project (cf_mbconv.hip): one launch, expanded tensor stays in LDS
+                Op m; m.kind = OP_MB; m.name = std::string(pre) + ".mbconv"; m.in = cur; m.out = dst;
+                m.Hin = curH; m.Win = curW; m.Cin = cin; m.hid = hid; m.Hout = Ho; m.Wout = Wo; m.Cout = cout;
+                m.k = k; m.s = s; m.pad_lo = p / 2; m.residual = residual; m.geo = geo;
+                m.wkey = std::string(pre) + ".conv.0.1.weight"; m.wkey_dw = std::string(pre) + ".conv.1.1.weight";
+                m.wkey_proj = std::string(pre) + ".conv.2.weight";
+                m.macs = (double)curH * curW * cin * hid + (double)Ho * Wo * hid * (k * k + cout);
+                push(m);
+                cur = dst; curH = Ho; curW = Wo; cin = cout;
+                continue;
+            }
             int src = cur, j = 0;
             if (t != 1) {                         // expand pw + Swish (:109-110)
                 Op e; e.kind = OP_PW; e.name = std::string(pre) + ".expand"; e.in = cur; e.out = E;
@@ -124,19 +147,12 @@ void build_plan(cf_ctx* c) {
                 e.wkey = std::string(pre) + ".conv.0.1.weight"; e.macs = (double)curH * curW * cin * hid;
                 push(e); src = E; j = 1;
             }
-            const int p = std::max(k - s, 0);      // _get_padding (:68-70)
-            const int Ho = (curH + p - k) / s + 1, Wo = (curW + p - k) / s + 1;
             Op d; d.kind = OP_DW; d.name = std::string(pre) + ".dw"; d.in = src; d.out = D;
             d.Hin = curH; d.Win = curW; d.Cin = d.Cout = hid; d.Hout = Ho; d.Wout = Wo; d.k = k; d.s = s;
             d.pad_lo = p / 2; d.act = 1;
             d.wkey = std::string(pre) + ".conv." + std::to_string(j) + ".1.weight";
             d.macs = (double)Ho * Wo * hid * k * k;
             push(d);
-            const bool residual = (cin == cout && s == 1);      // :101
-            int dst = (cur == A) ? B : A;
-            if (li == 1 && i == n - 1) dst = S1;                 // x1 (:266)
-            if (li == 2 && i == n - 1) dst = S2;                 // x2 (:267)
-            if (li == 4 && i == n - 1) dst = S4;                 // x4 (:269)
             Op pr; pr.kind = OP_PW; pr.name = std::string(pre) + ".project"; pr.in = D; pr.out = dst;
             pr.res = residual ? cur : -1;
             pr.Hin = pr.Hout = Ho; pr.Win = pr.Wout = Wo; pr.Cin = hid; pr.Cout = cout; pr.act = 0;
@@ -318,6 +334,12 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
         int r = CF_OK;
         if (op.kind == OP_STEM) { r = expect(c, ws, op.wkey, {32, 3, 3, 3}); expected_keys += 1; }
         else if (op.kind == OP_DW) { r = expect(c, ws, op.wkey, {op.Cin, 1, op.k, op.k}); expected_keys += 1; }
+        else if (op.kind == OP_MB) {
+            r = expect(c, ws, op.wkey, {op.hid, op.Cin, 1, 1});
+            if (!r) r = expect(c, ws, op.wkey_dw, {op.hid, 1, op.k, op.k});
+            if (!r) r = expect(c, ws, op.wkey_proj, {op.Cout, op.hid, 1, 1});
+            expected_keys += 3;
+        }
         else if (op.kind == OP_PW) {
             r = expect(c, ws, op.wkey, {op.Cout, op.Cin, 1, 1}); expected_keys += 1;
             if (!r && !op.bnkey.empty()) { r = expect_bn(c, ws, op.bnkey, op.Cout); expected_keys += 5; }
@@ -349,6 +371,14 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
             std::vector<char> w(stem_packed_bytes(dt));
             stem_pack_weights(dt, ws.f(op.wkey), w.data());
             int r = upload_bytes(c, w, &op.wp); if (r) return r;
+        } else if (op.kind == OP_MB) {
+            std::vector<char> we(op.geo.wexp_bytes), wp(op.geo.wproj_bytes);
+            std::vector<float> wd(op.geo.wdw_floats);
+            mb_pack_weights(dt, op.geo, op.Cin, op.hid, op.Cout, op.k, ws.f(op.wkey), ws.f(op.wkey_dw), ws.f(op.wkey_proj),
+                            we.data(), wd.data(), wp.data());
+            int r = upload_bytes(c, we, &op.wexp); if (r) return r;
+            r = upload(c, wd, &op.wdw); if (r) return r;
+            r = upload_bytes(c, wp, &op.wproj); if (r) return r;
         } else if (op.kind == OP_DW) {
             std::vector<float> w((size_t)op.k * op.k * op.Cin);
             dw_pack_weights(ws.f(op.wkey), op.Cin, op.k, w.data());
@@ -430,6 +460,14 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
             p.M = (long long)B * op.Hout * op.Wout; p.K = op.Cin; p.N = op.Cout; p.act = op.act;
             p.low = bp(op.low); p.upw = op.upw; p.upb = op.upb; p.Ho = op.Hout; p.Wo = op.Wout;
             return launch_pw(c->stream, c->dtype, p);
+        }
+        case OP_MB: {
+            MbParams p{}; p.x = bp(op.in); p.y = bp(op.out); p.wexp = op.wexp; p.wdw = op.wdw; p.wproj = op.wproj;
+            p.B = B; p.Hin = op.Hin; p.Win = op.Win; p.Hout = op.Hout; p.Wout = op.Wout; p.Cin = op.Cin; p.hid = op.hid; p.Cout = op.Cout;
+            p.k = op.k; p.s = op.s; p.pad_lo = op.pad_lo; p.residual = op.residual ? 1 : 0;
+            p.HC = op.geo.HC; p.nq = op.geo.nq; p.NBE = op.geo.NBE; p.JX = op.geo.JX; p.HALF = op.geo.HALF; p.rowb = op.geo.rowb;
+            p.lds_bytes = op.geo.lds_bytes;
+            return launch_mbconv(c->stream, c->dtype, p);
         }
         case OP_HEAD: {
             HeadParams p{}; p.x = bp(op.in); p.w0p = op.wp; p.b0 = op.bias; p.w1d = op.w1d; p.b1 = op.b1;

@@ -39,6 +39,23 @@ def conv_pw(x, w, act="none", bias=None, residual=None, dtype="fp32", device=0):
     return y
 
 
+def mbconv(x, w_exp, w_dw, w_proj, k, stride, dtype="fp32", device=0):
+    """MBConvBlock.forward (model/centernet.py:89-140, se=False) as the single fused kernel."""
+    x = f32(x)
+    B, Cin, H, W = x.shape
+    w_exp = f32(np.asarray(w_exp).reshape(w_exp.shape[0], -1))
+    hid = w_exp.shape[0]
+    w_dw = f32(np.asarray(w_dw).reshape(hid, k * k))
+    w_proj = f32(np.asarray(w_proj).reshape(w_proj.shape[0], -1))
+    Cout = w_proj.shape[0]
+    p = max(k - stride, 0)
+    Ho, Wo = (H + p - k) // stride + 1, (W + p - k) // stride + 1
+    y = np.empty((B, Cout, Ho, Wo), np.float32)
+    _lib.check(_lib.lib().cf_op_mbconv(device, _DT[dtype], ptr(x), ptr(w_exp), ptr(w_dw), ptr(w_proj), ptr(y),
+                                       B, Cin, hid, Cout, H, W, k, stride), op=True)
+    return y
+
+
 def stem(x, w, dtype="fp32", device=0):
     """first_conv (model/centernet.py:224): x uint8 [B,H,W,3] BGR (normalisation fused) or float32 [B,3,H,W]."""
     x = np.ascontiguousarray(x)

@@ -74,6 +74,42 @@ def test_mbconv_blocks_vs_reference(golden, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_mbconv_vs_reference(golden, dtype):
+    """The fused expand->dw->project kernel (cf_mbconv.hip) on every golden block shape it covers
+    (small, non-square maps: every tile is an edge tile)."""
+    g = golden("ops")
+    done = 0
+    for i in range(9):
+        cin, cout, t, k, s = (int(v) for v in g["mb%d_cfg" % i])
+        if t == 1 or cout > 96:
+            continue
+        sd = _sub(g, "mb%d_w_" % i)
+        y = ops.mbconv(g["mb%d_x" % i], sd["conv.0.1.weight"], sd["conv.1.1.weight"], sd["conv.2.weight"], k, s, dtype=dtype)
+        tol = dict(rtol=1e-4, atol=1e-4) if dtype == "fp32" else dict(rtol=6e-2, atol=6e-2)
+        np.testing.assert_allclose(y, g["mb%d_y" % i], **tol, err_msg="mb%d" % i)
+        done += 1
+    assert done == 6
+
+
+@pytest.mark.parametrize("cfg", [(16, 24, 3, 2, 70, 90), (24, 24, 3, 1, 41, 37), (24, 32, 5, 2, 64, 48),
+                                 (32, 32, 5, 1, 33, 50), (64, 96, 5, 1, 40, 40), (96, 96, 5, 1, 24, 17)])
+def test_fused_mbconv_multi_tile_vs_oracle(cfg):
+    """Interior + edge tiles, odd sizes, batch > 1, against the oracle's MBConv restatement (fp32)."""
+    cin, cout, k, s, H, W = cfg
+    rng = np.random.default_rng(cin * 1000 + k * 10 + s)
+    hid = cin * 6
+    sd = {"b.conv.0.1.weight": (rng.standard_normal((hid, cin, 1, 1)) * 1.5 / np.sqrt(cin)).astype(np.float32),
+          "b.conv.1.1.weight": (rng.standard_normal((hid, 1, k, k)) * 1.5 / k).astype(np.float32),
+          "b.conv.2.weight": (rng.standard_normal((cout, hid, 1, 1)) / np.sqrt(hid)).astype(np.float32)}
+    x = rng.standard_normal((2, cin, H, W)).astype(np.float32)
+    ref = O.mbconv(torch.from_numpy(x), {k_: torch.from_numpy(v) for k_, v in sd.items()}, "b", cin, cout, 6, k, s).numpy()
+    y = ops.mbconv(x, sd["b.conv.0.1.weight"], sd["b.conv.1.1.weight"], sd["b.conv.2.weight"], k, s, dtype="fp32")
+    np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+    yb = ops.mbconv(x, sd["b.conv.0.1.weight"], sd["b.conv.1.1.weight"], sd["b.conv.2.weight"], k, s, dtype="bf16")
+    assert np.abs(yb - ref).max() < 0.15 and np.abs(yb - ref).mean() < 0.02
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_conv1x1bn_idaup_heads_vs_reference(golden, dtype):
     g = golden("ops")
     sd = _sub(g, "c1bn_w_")
@@ -138,6 +174,17 @@ def test_network_fp32_vs_reference_goldens(golden):
         for h in ("hm", "wh", "lm", "reg"):
             np.testing.assert_allclose(out[h], g["%s_%s" % (h, tag)], rtol=1e-3, atol=1e-3, err_msg=h + tag)
         eng.close()
+
+
+def test_network_unfused_path_fp32(golden):
+    """CF_FLAG_NO_FUSE: the three-kernel MBConv path stays parity-green too."""
+    g = golden("net")
+    x = g["x_b"]
+    eng = cfa.Engine(64, 96, max_batch=2, dtype="fp32", fuse=False)
+    out = eng.forward(x)
+    for h in ("hm", "wh", "lm", "reg"):
+        np.testing.assert_allclose(out[h], g["%s_b" % h], rtol=1e-3, atol=1e-3)
+    eng.close()
 
 
 def test_network_collapsed_heads_fp32(golden):
