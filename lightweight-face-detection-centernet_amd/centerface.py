@@ -27,13 +27,18 @@ class Engine(object):
     """One cf_ctx: one GPU, one stream, fixed (H, W), batch up to ``max_batch``."""
 
     def __init__(self, height, width, max_batch=1, dtype="fp32", device=0, weights=None,
-                 collapse_heads=False, fuse=True):
+                 collapse_heads=None, fuse=True):
         L = _lib.lib()
         if dtype not in _DTYPES:
             raise ValueError("dtype must be one of %s" % sorted(_DTYPES))
         self.H, self.W, self.max_batch, self.device = int(height), int(width), int(max_batch), int(device)
         self.h, self.w = self.H // 4, self.W // 4
         self.dtype = dtype
+        if collapse_heads is None:
+            # the head pair conv3x3+b -> conv1x1+b is linear (model/centernet.py:249-256): folding it
+            # into one 3x3 24->15 conv is exact algebra; default on in the throughput mode, off in
+            # the fp32 parity mode so that mode keeps the reference's operation order
+            collapse_heads = (dtype not in ("fp32", "float32", "f32"))
         flags = (_lib.CF_FLAG_COLLAPSE_HEADS if collapse_heads else 0) | (0 if fuse else _lib.CF_FLAG_NO_FUSE)
         handle = C.c_void_p()
         _lib.check(L.cf_create(self.device, self.max_batch, self.H, self.W, _DTYPES[dtype], flags, C.byref(handle)))
@@ -212,7 +217,7 @@ class CenterFace(object):
     std = np.array([0.289, 0.274, 0.278], dtype=np.float32).reshape(1, 1, 3)    # centerface.py:14-15
 
     def __init__(self, height, width, landmarks=True, *, weights=None, dtype="fp32", device=0,
-                 max_batch=1, collapse_heads=False, nms_thresh=0.3, max_dets=1024):
+                 max_batch=1, collapse_heads=None, nms_thresh=0.3, max_dets=1024):
         self.landmarks = landmarks
         self.img_h_new, self.img_w_new, self.scale_h, self.scale_w = self.transform(height, width)
         self.nms_thresh = nms_thresh

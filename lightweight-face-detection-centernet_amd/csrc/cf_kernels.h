@@ -68,6 +68,7 @@ struct MbParams {
     int k, s, pad_lo, residual;
     int HC, nq, NBE, JX, HALF, rowb;
     size_t lds_bytes;
+    int nw;               // 0 = auto, 4 = force 4-wave workgroups (A/B switch)
 };
 hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p);
 

@@ -57,8 +57,10 @@ MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
     const int sz = (int)elem_size(dtype);
     g.ok = (Cin % 8 == 0) && (hid % 48 == 0) && (Cout % 8 == 0) && Cout <= 96 && Cin <= 96 && (k == 3 || k == 5) && (s == 1 || s == 2);
     if (!g.ok) return g;
-    if (dtype == 0) g.HC = 48;
-    else if (s == 2) g.HC = 48;
+    // hidden chunk: whole 32-channel MFMA blocks where hid allows; smaller chunks for the stride-2
+    // tiles (4.6x more input pixels per output pixel in LDS) and for fp32 storage
+    if (dtype == 0) g.HC = (hid % 32 == 0) ? 32 : 48;
+    else if (s == 2) g.HC = (hid % 32 == 0) ? 32 : 48;
     else g.HC = (hid % 96 == 0) ? 96 : 48;
     g.nq = hid / g.HC;
     g.NBE = (g.HC + 31) / 32;
@@ -67,7 +69,7 @@ MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
     g.NBO = (Cout + 31) / 32;
     const int IH = (MB_TOH - 1) * s + k, IW = (MB_TOW - 1) * s + k;
     g.rowb = g.HC * sz + 16;
-    g.lds_bytes = (size_t)((IH * IW * g.rowb + 15) / 16 * 16) + (size_t)k * k * g.HC * 4;
+    g.lds_bytes = (size_t)((IH * IW * g.rowb + 15) / 16 * 16) + 2 * ((size_t)g.NBE * g.JX * 1024 + (size_t)k * k * g.HC * 4);
     g.wexp_bytes = (size_t)g.nq * g.NBE * g.JX * 64 * 16;
     g.wdw_floats = (size_t)g.nq * k * k * g.HC;
     g.wproj_bytes = (size_t)g.NBO * g.nq * g.HALF * 64 * 16;
@@ -113,28 +115,35 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
 }
 
 // ---------------------------------------------------------------- device
-template <typename T, int KS, int S, int NBO, bool RESID>
-__global__ __launch_bounds__(256) void mbconv_kernel(MbParams p) {
+// NW waves per workgroup (4 or 8).  With 8 waves the tile still has 4 pixel blocks: waves w and w+4
+// share pixel block w&3 and split the k-steps of every hidden chunk between them; their partial
+// project sums are combined once, through LDS, in the epilogue.  Twice the waves per LDS byte.
+template <typename T, int KS, int S, int NBO, bool RESID, int NW>
+__global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
     constexpr int P = Elem<T>::PER16;
     constexpr int IH = (MB_TOH - 1) * S + KS, IW = (MB_TOW - 1) * S + KS, IPX = IH * IW;
     constexpr int NIB = (IPX + 31) / 32;
     constexpr int MAXJX = sizeof(T) == 4 ? 12 : 6;               // Cin <= 96
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ROWB = p.rowb;
     char* E = smem;
-    float* Wd = reinterpret_cast<float*>(smem + ((IPX * ROWB + 15) / 16 * 16));
+    const int WXB = p.NBE * p.JX * 1024;                         // expand fragments per chunk (bytes)
+    const int WSTAGE = WXB + KS * KS * p.HC * 4;                 // + depthwise taps (fp32)
+    char* Wst = smem + ((IPX * ROWB + 15) / 16 * 16);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
     const int ox0 = blockIdx.x * MB_TOW, oy0 = blockIdx.y * MB_TOH, b = blockIdx.z;
-    const int NCx = p.Cin * (int)sizeof(T) / 16;
-    const int JX = p.JX, jxmax = h ? NCx - JX : JX;
-    const int HC = p.HC, NBE = p.NBE, HALF = p.HALF, nq = p.nq;
+    const int JX = p.JX, HC = p.HC, NBE = p.NBE, HALF = p.HALF, nq = p.nq;
 
-    // this lane's output pixel (phase 2/3 and epilogue)
-    const int o = wave * 32 + pl;
+    // this lane's output pixel (phase 2/3 and epilogue) and its share of the k-steps
+    const int pbk = wave & 3, jg = wave >> 2;
+    const int o = pbk * 32 + pl;
     const int oy = o / MB_TOW, ox = o % MB_TOW;
-    const int ipo = (oy * S) * IW + ox * S;
+    const unsigned e_pix = (unsigned)((oy * S) * IW + ox * S) * (unsigned)ROWB;
+    const int jsplit = NW == 8 ? (HALF + 1) / 2 : HALF;
+    const int j0 = jg ? jsplit : 0, j1 = jg ? HALF : jsplit;
 
     f32x16 acc[NBO];
 #pragma unroll
@@ -143,75 +152,155 @@ __global__ __launch_bounds__(256) void mbconv_kernel(MbParams p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
     const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * sizeof(T);
+    const unsigned rowbytes = (unsigned)p.Cin * sizeof(T);
 
-    for (int q = 0; q < nq; ++q) {
-        // stage this chunk's depthwise weights [tap][HC] (fp32)
-        for (int i = tid; i < KS * KS * HC; i += 256) Wd[i] = p.wdw[(size_t)q * KS * KS * HC + i];
-
-        // ---- phase 1: expand + Swish -> E
-        for (int ib = wave; ib < NIB; ib += 4) {
-            const int ip = ib * 32 + pl;
-            const int ipc = ip < IPX ? ip : IPX - 1;
-            const int iy = ipc / IW, ix = ipc - iy * IW;
-            const int gy = oy0 * S - p.pad_lo + iy, gx = ox0 * S - p.pad_lo + ix;
-            const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
-            const char* xrow = xbase + ((size_t)(valid ? gy : 0) * p.Win + (valid ? gx : 0)) * p.Cin * sizeof(T) + (size_t)h * JX * 16;
-            u32x4 xf[MAXJX];
+    auto stage_weights = [&](int q) {
+        char* dst = Wst + (q & 1) * WSTAGE;
+        const char* srcx = (const char*)p.wexp + (size_t)q * WXB;
+        for (int i = tid * 16; i < WXB; i += NT * 16) st16(dst + i, ld16(srcx + i));
+        const char* srcd = (const char*)(p.wdw + (size_t)q * KS * KS * HC);
+        for (int i = tid * 16; i < KS * KS * HC * 4; i += NT * 16) st16(dst + WXB + i, ld16(srcd + i));
+    };
+    // input-tile pixel block ib -> this lane's X fragments; zero outside the image (= ZeroPad2d).
+    // A row whose 16-byte chunk count is odd is over-read by one chunk on the h=1 half: the matching
+    // weight fragment is zero and activation buffers are zero-initialised with slack, so it is inert.
+    auto load_x = [&](int ib, u32x4* xf) {
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < IPX ? ip : IPX - 1;
+        const int iy = ipc / IW, ix = ipc - iy * IW;
+        const int gy = oy0 * S - p.pad_lo + iy, gx = ox0 * S - p.pad_lo + ix;
+        const bool valid = ib < NIB && ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+        const unsigned off = ((unsigned)gy * (unsigned)p.Win + (unsigned)gx) * rowbytes + (unsigned)(h * JX * 16);
+        if (valid) {
 #pragma unroll
-            for (int j = 0; j < MAXJX; ++j) xf[j] = (valid && j < jxmax) ? ld16(xrow + j * 16) : zero16();
-            for (int nbl = 0; nbl < NBE; ++nbl) {
+            for (int j = 0; j < MAXJX; ++j) if (j < JX) xf[j] = ld16(xbase + off + j * 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < MAXJX; ++j) xf[j] = zero16();
+        }
+    };
+    auto expand_block = [&](int ib, const u32x4* xf, const char* wx) {
+        const int ip = ib * 32 + pl;
+        const bool ipok = ip < IPX;
+        char* erow = E + (unsigned)(ipok ? ip : 0) * (unsigned)ROWB;
+#pragma unroll
+        for (int nbl = 0; nbl < 3; ++nbl) {
+            if (nbl < NBE) {
                 f32x16 a;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[r] = 0.0f;
-                const char* wb = (const char*)p.wexp + ((((size_t)q * NBE + nbl) * JX) * 64 + lane) * 16;
+                const char* wb = wx + (nbl * JX * 64 + lane) * 16;
+                MbMma<T>::run(a, ld16(wb), xf[0]);
 #pragma unroll
-                for (int j = 0; j < MAXJX; ++j)
-                    if (j < JX) MbMma<T>::run(a, ld16(wb + (size_t)j * 1024), xf[j]);
-                if (ip < IPX) {
-                    const int ch0 = nbl * 32 + h * 16;
+                for (int j = 1; j < MAXJX; ++j)
+                    if (j < JX) MbMma<T>::run(a, ld16(wb + j * 1024), xf[j]);
+                const int ch0 = nbl * 32 + h * 16;
 #pragma unroll
-                    for (int g = 0; g < 16 / P; ++g) {
-                        const int ch = ch0 + g * P;
-                        if (ch < HC) {
-                            float v[P];
+                for (int g = 0; g < 16 / P; ++g) {
+                    float v[P];
 #pragma unroll
-                            for (int e = 0; e < P; ++e) v[e] = swish_f(a[g * P + e]);
-                            st16(E + (size_t)ip * ROWB + (size_t)ch * sizeof(T), pack16<T>(v));
-                        }
-                    }
+                    for (int e = 0; e < P; ++e) v[e] = swish_f(a[g * P + e]);
+                    const u32x4 pk = pack16<T>(v);
+                    const int ch = ch0 + g * P;
+                    if (ipok && ch < HC) st16(erow + ch * (int)sizeof(T), pk);
                 }
             }
         }
+    };
+
+    stage_weights(0);
+    for (int q = 0; q < nq; ++q) {
+        const char* wx = Wst + (q & 1) * WSTAGE;
+        const char* wdq = wx + WXB;
+        __syncthreads();      // previous chunk's phase 2 done with E; this stage's weights landed
+
+        // ---- phase 1: expand + Swish -> E ; X fragments prefetched one pixel block ahead
+        {
+            u32x4 xa[MAXJX], xb[MAXJX];
+            int ib = wave;
+            load_x(ib, xa);
+            while (ib < NIB) {
+                load_x(ib + NW, xb);
+                expand_block(ib, xa, wx);
+                ib += NW;
+                if (ib >= NIB) break;
+                load_x(ib + NW, xa);
+                expand_block(ib, xb, wx);
+                ib += NW;
+            }
+        }
         __syncthreads();
+        if (q + 1 < nq) stage_weights(q + 1);       // streams in under this chunk's depthwise
 
         // ---- phase 2 + 3: depthwise + Swish in registers, straight into the project MFMA
-        for (int j = 0; j < HALF; ++j) {
+        u32x4 wpn[NBO];
+        if (j0 < j1) {
+#pragma unroll
+            for (int i = 0; i < NBO; ++i)
+                wpn[i] = ld16((const char*)p.wproj + ((((size_t)i * nq + q) * HALF + j0) * 64 + lane) * 16);
+        }
+        for (int j = j0; j < j1; ++j) {
+            u32x4 wpc[NBO];
+#pragma unroll
+            for (int i = 0; i < NBO; ++i) wpc[i] = wpn[i];
+            if (j + 1 < j1) {
+#pragma unroll
+                for (int i = 0; i < NBO; ++i)
+                    wpn[i] = ld16((const char*)p.wproj + ((((size_t)i * nq + q) * HALF + j + 1) * 64 + lane) * 16);
+            }
             const int c = h * HALF + j;                               // 16-byte chunk within HC
             float d[P];
 #pragma unroll
             for (int e = 0; e < P; ++e) d[e] = 0.0f;
-            const char* eb = E + (size_t)ipo * ROWB + (size_t)c * 16;
-            const float* wdb = Wd + c * P;
+            const char* eb = E + e_pix + c * 16;
+            const char* wdb = wdq + c * (P * 4);
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
                     float ev[P];
-                    unpack16<T>(ld16(eb + (size_t)(ky * IW + kx) * ROWB), ev);
-                    const float* wt = wdb + (ky * KS + kx) * HC;
+                    unpack16<T>(ld16(eb + (ky * IW + kx) * ROWB), ev);
+                    const char* wt = wdb + (ky * KS + kx) * HC * 4;
+                    float wv[P];
+                    unpack16<float>(ld16(wt), wv);
+                    if constexpr (P == 8) unpack16<float>(ld16(wt + 16), wv + 4);
 #pragma unroll
-                    for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wt[e], d[e]);
+                    for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
                 }
 #pragma unroll
             for (int e = 0; e < P; ++e) d[e] = swish_f(d[e]);
             const u32x4 xc = pack16<T>(d);
 #pragma unroll
-            for (int i = 0; i < NBO; ++i) {
-                const char* wb = (const char*)p.wproj + ((((size_t)i * nq + q) * HALF + j) * 64 + lane) * 16;
-                MbMma<T>::run(acc[i], ld16(wb), xc);
-            }
+            for (int i = 0; i < NBO; ++i) MbMma<T>::run(acc[i], wpc[i], xc);
+        }
+    }
+
+    // ---- combine the two k-halves (NW == 8): waves 4..7 hand their partial sums over through LDS
+    if constexpr (NW == 8) {
+        __syncthreads();                                  // everyone is done with E
+        float* red = reinterpret_cast<float*>(smem) + (size_t)(pbk * 64 + lane) * (NBO * 16);
+        if (jg == 1) {
+#pragma unroll
+            for (int i = 0; i < NBO; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = acc[i][g * 4 + e];
+                    st16(red + i * 16 + g * 4, pack16<float>(t));
+                }
         }
         __syncthreads();
+        if (jg == 1) return;
+#pragma unroll
+        for (int i = 0; i < NBO; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float t[4];
+                unpack16<float>(ld16(red + i * 16 + g * 4), t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][g * 4 + e] += t[e];
+            }
     }
 
     // ---- epilogue: (+ residual) -> y
@@ -239,19 +328,29 @@ __global__ __launch_bounds__(256) void mbconv_kernel(MbParams p) {
     }
 }
 
-template <typename T, int KS, int S, int NBO, bool RESID>
-static hipError_t mb_launch(hipStream_t s, const MbParams& p) {
-    auto kfn = mbconv_kernel<T, KS, S, NBO, RESID>;
+template <typename T, int KS, int S, int NBO, bool RESID, int NW>
+static hipError_t mb_launch_nw(hipStream_t s, const MbParams& p) {
+    auto kfn = mbconv_kernel<T, KS, S, NBO, RESID, NW>;
     static thread_local size_t configured = 0;
     if (p.lds_bytes > 64 * 1024 && configured < p.lds_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
         configured = p.lds_bytes;
     }
-    dim3 grid((p.Wout + MB_TOW - 1) / MB_TOW, (p.Hout + MB_TOH - 1) / MB_TOH, p.B), blk(256);
-    set_kernel_tag("void cf::mbconv_kernel<%s, %d, %d, %d, %s>(cf::MbParams)", type_tag<T>(), KS, S, NBO, RESID ? "true" : "false");
+    dim3 grid((p.Wout + MB_TOW - 1) / MB_TOW, (p.Hout + MB_TOH - 1) / MB_TOH, p.B), blk(NW * 64);
+    set_kernel_tag("void cf::mbconv_kernel<%s, %d, %d, %d, %s, %d>(cf::MbParams)", type_tag<T>(), KS, S, NBO, RESID ? "true" : "false", NW);
     hipLaunchKernelGGL(kfn, grid, blk, p.lds_bytes, s, p);
     return hipGetLastError();
+}
+
+template <typename T, int KS, int S, int NBO, bool RESID>
+static hipError_t mb_launch(hipStream_t s, const MbParams& p) {
+    // 8 waves need >= 2 k-steps per hidden chunk and room in the E region for the 4 partial-sum slabs
+    const size_t red_bytes = (size_t)4 * 64 * NBO * 16 * 4;
+    constexpr int IPX = ((MB_TOH - 1) * S + KS) * ((MB_TOW - 1) * S + KS);
+    const bool want8 = p.nw == 8 || (p.nw == 0 && KS == 5);
+    const bool can8 = want8 && p.HALF >= 2 && red_bytes <= (size_t)IPX * p.rowb;
+    return can8 ? mb_launch_nw<T, KS, S, NBO, RESID, 8>(s, p) : mb_launch_nw<T, KS, S, NBO, RESID, 4>(s, p);
 }
 
 template <typename T, int KS, int S>

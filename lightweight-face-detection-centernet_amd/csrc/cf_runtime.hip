@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -299,6 +300,8 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
     for (auto& b : c->bufs) {
         size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256;
         if ((e = hipMalloc(&b.p, bytes)) != hipSuccess) return bail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "hipMalloc(activations)", e);
+        // zero-initialised incl. the slack: kernels may over-read (never write) one 16-byte chunk
+        if ((e = hipMemset(b.p, 0, bytes)) != hipSuccess) return bail(CF_EHIP, "hipMemset(activations)", e);
     }
     *out = c;
     return CF_OK;
@@ -467,6 +470,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
             p.k = op.k; p.s = op.s; p.pad_lo = op.pad_lo; p.residual = op.residual ? 1 : 0;
             p.HC = op.geo.HC; p.nq = op.geo.nq; p.NBE = op.geo.NBE; p.JX = op.geo.JX; p.HALF = op.geo.HALF; p.rowb = op.geo.rowb;
             p.lds_bytes = op.geo.lds_bytes;
+            { static const int nw_env = getenv("CF_MB_NW") ? atoi(getenv("CF_MB_NW")) : 0; p.nw = nw_env; }
             return launch_mbconv(c->stream, c->dtype, p);
         }
         case OP_HEAD: {
