@@ -84,6 +84,22 @@ size_t stem_packed_bytes(int dtype);
 void stem_pack_weights(int dtype, const float* w /*[32][3][3][3]*/, void* out_host);
 hipError_t launch_stem(hipStream_t s, int dtype, const StemParams& p);
 
+// ------------------------------------------------------------------ fused stem + layer0 (dw 3x3 + project 32->16)
+struct Stem0Params {
+    const void* x;        // u8 [B][H][W][3] (BGR) or f32 [B][3][H][W]
+    int in_format;
+    const float* lut;     // [3][256] normalisation table (u8 input only)
+    const void* wstem;    // stem_pack_weights
+    const float* wdw;     // [9][32] fp32
+    const void* wproj;    // stem0_pack_proj
+    void* y;              // [B][H/2][W/2][16] T
+    int B, H, W;
+};
+void stem0_lut(float* lut /*[3][256]*/);
+size_t stem0_proj_bytes(int dtype);
+void stem0_pack_proj(int dtype, const float* wp /*[16][32]*/, void* out_host);
+hipError_t launch_stem0(hipStream_t s, int dtype, const Stem0Params& p);
+
 // ------------------------------------------------------------------ heads: 3x3 conv (MFMA) + 1x1
 struct HeadParams {
     const void* x;        // [B][h][w][24] T

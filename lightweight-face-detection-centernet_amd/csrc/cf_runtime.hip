@@ -32,8 +32,8 @@ const int kSettings[7][5] = {  // t, c, n, s, k -- model/centernet.py:211-219
     {1, 16, 1, 1, 3}, {6, 24, 2, 2, 3}, {6, 32, 2, 2, 5}, {6, 64, 2, 2, 3},
     {6, 96, 2, 1, 5}, {6, 160, 2, 2, 5}, {6, 320, 1, 1, 3}};
 
-enum OpKind { OP_STEM = 0, OP_PW, OP_DW, OP_HEAD, OP_MB };
-const char* kKindName[] = {"stem", "pw", "dw", "head", "mbconv"};
+enum OpKind { OP_STEM = 0, OP_PW, OP_DW, OP_HEAD, OP_MB, OP_STEM0 };
+const char* kKindName[] = {"stem", "pw", "dw", "head", "mbconv", "stem0"};
 
 struct Op {
     OpKind kind;
@@ -108,14 +108,24 @@ void build_plan(cf_ctx* c) {
         need(c, op.out, (size_t)op.Hout * op.Wout * (op.kind == OP_HEAD ? 16 : op.Cout));
         c->ops.push_back(op);
     };
+    const bool fuse = !(c->flags & CF_FLAG_NO_FUSE);
+    if (fuse) {
+        // first_conv + layer0.0 (dw 3x3 + project 32->16) fused: cf_stem0.hip
+        Op st; st.kind = OP_STEM0; st.name = "first_conv+layer0.0"; st.in = -1; st.out = A;
+        st.Hin = H; st.Win = W; st.Cin = 3; st.Hout = H / 2; st.Wout = W / 2; st.Cout = 16; st.k = 3; st.s = 2; st.act = 1;
+        st.wkey = "first_conv.0.1.weight"; st.wkey_dw = "layer0.0.conv.0.1.weight"; st.wkey_proj = "layer0.0.conv.1.weight";
+        st.macs = (double)st.Hout * st.Wout * (32 * 27 + 32 * 9 + 32 * 16);
+        push(st);
+    } else {
     // stem: first_conv (model/centernet.py:224)
     Op st; st.kind = OP_STEM; st.name = "first_conv"; st.in = -1; st.out = A;
     st.Hin = H; st.Win = W; st.Cin = 3; st.Hout = H / 2; st.Wout = W / 2; st.Cout = 32; st.k = 3; st.s = 2; st.act = 1;
     st.wkey = "first_conv.0.1.weight"; st.macs = (double)st.Hout * st.Wout * 32 * 27;
     push(st);
+    }
 
-    int cur = A, curH = H / 2, curW = W / 2, cin = 32;
-    for (int li = 0; li < 7; ++li) {
+    int cur = A, curH = H / 2, curW = W / 2, cin = fuse ? 16 : 32;
+    for (int li = fuse ? 1 : 0; li < 7; ++li) {
         const int t = kSettings[li][0], cout = kSettings[li][1], n = kSettings[li][2], k = kSettings[li][4];
         for (int i = 0; i < n; ++i) {
             const int s = (i == 0) ? kSettings[li][3] : 1;
@@ -337,6 +347,12 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
         int r = CF_OK;
         if (op.kind == OP_STEM) { r = expect(c, ws, op.wkey, {32, 3, 3, 3}); expected_keys += 1; }
         else if (op.kind == OP_DW) { r = expect(c, ws, op.wkey, {op.Cin, 1, op.k, op.k}); expected_keys += 1; }
+        else if (op.kind == OP_STEM0) {
+            r = expect(c, ws, op.wkey, {32, 3, 3, 3});
+            if (!r) r = expect(c, ws, op.wkey_dw, {32, 1, 3, 3});
+            if (!r) r = expect(c, ws, op.wkey_proj, {16, 32, 1, 1});
+            expected_keys += 3;
+        }
         else if (op.kind == OP_MB) {
             r = expect(c, ws, op.wkey, {op.hid, op.Cin, 1, 1});
             if (!r) r = expect(c, ws, op.wkey_dw, {op.hid, 1, op.k, op.k});
@@ -374,6 +390,17 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
             std::vector<char> w(stem_packed_bytes(dt));
             stem_pack_weights(dt, ws.f(op.wkey), w.data());
             int r = upload_bytes(c, w, &op.wp); if (r) return r;
+        } else if (op.kind == OP_STEM0) {
+            std::vector<char> w(stem_packed_bytes(dt)), wp(stem0_proj_bytes(dt));
+            std::vector<float> wd(9 * 32), lut(768);
+            stem_pack_weights(dt, ws.f(op.wkey), w.data());
+            dw_pack_weights(ws.f(op.wkey_dw), 32, 3, wd.data());
+            stem0_pack_proj(dt, ws.f(op.wkey_proj), wp.data());
+            stem0_lut(lut.data());
+            int r = upload_bytes(c, w, &op.wp); if (r) return r;
+            r = upload(c, wd, &op.wdw); if (r) return r;
+            r = upload_bytes(c, wp, &op.wproj); if (r) return r;
+            r = upload(c, lut, &op.upw); if (r) return r;
         } else if (op.kind == OP_MB) {
             std::vector<char> we(op.geo.wexp_bytes), wp(op.geo.wproj_bytes);
             std::vector<float> wd(op.geo.wdw_floats);
@@ -464,6 +491,11 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
             p.low = bp(op.low); p.upw = op.upw; p.upb = op.upb; p.Ho = op.Hout; p.Wo = op.Wout;
             return launch_pw(c->stream, c->dtype, p);
         }
+        case OP_STEM0: {
+            Stem0Params p{}; p.x = net_in; p.in_format = in_format; p.lut = op.upw; p.wstem = op.wp; p.wdw = op.wdw;
+            p.wproj = op.wproj; p.y = bp(op.out); p.B = B; p.H = op.Hin; p.W = op.Win;
+            return launch_stem0(c->stream, c->dtype, p);
+        }
         case OP_MB: {
             MbParams p{}; p.x = bp(op.in); p.y = bp(op.out); p.wexp = op.wexp; p.wdw = op.wdw; p.wproj = op.wproj;
             p.B = B; p.Hin = op.Hin; p.Win = op.Win; p.Hout = op.Hout; p.Wout = op.Wout; p.Cin = op.Cin; p.hid = op.hid; p.Cout = op.Cout;
@@ -487,7 +519,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
 double op_bytes(const cf_ctx* c, const Op& op, int in_format, int B) {
     const double es = (double)elem_size(c->dtype);
     double in_b, out_b;
-    if (op.kind == OP_STEM) in_b = (double)op.Hin * op.Win * 3 * (in_format == CF_IN_U8_HWC_BGR ? 1 : 4);
+    if (op.kind == OP_STEM || op.kind == OP_STEM0) in_b = (double)op.Hin * op.Win * 3 * (in_format == CF_IN_U8_HWC_BGR ? 1 : 4);
     else in_b = (double)op.Hin * op.Win * op.Cin * es;
     if (op.kind == OP_HEAD) out_b = (double)op.Hout * op.Wout * 16 * 4;
     else out_b = (double)op.Hout * op.Wout * op.Cout * es;

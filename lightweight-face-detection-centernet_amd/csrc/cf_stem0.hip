@@ -1,0 +1,238 @@
+// Fused network entry for gfx950: uint8 image -> normalise -> stem 3x3 s2 3->32 + Swish ->
+// layer0 depthwise 3x3 + Swish -> layer0 project 32->16, in ONE kernel.
+//
+// Replaces centerface.py:32-37 (x/255, (x-mean)/std, HWC->CHW), first_conv (model/centernet.py:224)
+// and layer0.0 = MBConvBlock(32, 16, expand_ratio=1, k=3, s=1) (model/centernet.py:213, :105-122).
+// Layer by layer these three ops move 1.2 + 6.6 | 6.6 + 6.6 | 6.6 + 3.3 MB per image (bf16); fused,
+// only the uint8 image (1.2 MB) is read and the 16-channel map (3.3 MB) is written: the 32-channel
+// stem output lives only in LDS.
+//
+// One workgroup = one 8x16 tile of the H/2 x W/2 map:
+//   stage   the (2*10+1) x (2*18+1) image patch behind the tile is read with coalesced byte loads,
+//           mapped through the 3x256 normalisation table (computed on the host with the reference's
+//           exact float32 arithmetic) and stored in LDS in the storage type; outside the image: 0
+//           (the stem's own ZeroPad2d(0,1,0,1)).
+//   phase 1 stem: lane (pixel, h) gathers its half of the 27 taps from LDS, D^T = Ws . X^T on MFMA
+//           (as cf_stem.hip), Swish -> E[pixel][32] in LDS; pixels outside the map are written as 0
+//           (the depthwise conv's ZeroPad2d(1,1,1,1) acts on the stem OUTPUT).
+//   phase 2 depthwise 3x3 + Swish per lane from LDS, feeding the project MFMA directly (cf_mbconv.hip).
+#include "cf_common.h"
+#include "cf_kernels.h"
+#include "centerface_hip.h"
+
+namespace cf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+static inline int slot_channel(int nb, int i) {
+    int h = (i >> 2) & 1;
+    int r = (i & 3) + 4 * (i >> 3);
+    return nb * 32 + h * 16 + r;
+}
+
+constexpr int S0_TOH = 8, S0_TOW = 16;
+constexpr int S0_IH = S0_TOH + 2, S0_IW = S0_TOW + 2, S0_IPX = S0_IH * S0_IW;     // 10 x 18 = 180
+constexpr int S0_PH = 2 * S0_IH + 1, S0_PW = 2 * S0_IW + 1;                         // 21 x 37 image patch
+constexpr int S0_PROW = S0_PW * 3 + 1;                                              // 112 elements per patch row
+
+void stem0_lut(float* lut /*[3][256]*/) {
+    // centerface.py:12-15 (BGR), :32-33 -- float32 arithmetic, IEEE division, exactly as numpy
+    const float mean[3] = {0.408f, 0.447f, 0.470f};
+    const float stdv[3] = {0.289f, 0.274f, 0.278f};
+    for (int c = 0; c < 3; ++c)
+        for (int u = 0; u < 256; ++u) {
+            volatile float a = (float)u / 255.0f;
+            volatile float b = a - mean[c];
+            lut[c * 256 + u] = b / stdv[c];
+        }
+}
+
+size_t stem0_proj_bytes(int dtype) { return (size_t)(32 * elem_size(dtype) / 16 / 2) * 64 * 16; }
+
+// project weights wp [16][32] -> [j][lane][16 B]; hidden chunk = all 32 stem channels
+void stem0_pack_proj(int dtype, const float* wp, void* out_host) {
+    const int P = per16(dtype), HALF = 32 * (int)elem_size(dtype) / 16 / 2;
+    __builtin_memset(out_host, 0, stem0_proj_bytes(dtype));
+    for (int j = 0; j < HALF; ++j)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, h = lane >> 5, co = slot_channel(0, i);
+            if (co >= 16) continue;
+            char* dst = (char*)out_host + ((size_t)j * 64 + lane) * 16;
+            for (int e = 0; e < P; ++e) {
+                float v = wp[co * 32 + (h * HALF + j) * P + e];
+                if (dtype == 0) ((float*)dst)[e] = v; else ((uint16_t*)dst)[e] = host_f32_to_bf16(v);
+            }
+        }
+}
+
+template <typename T> struct S0Mma;
+template <> struct S0Mma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w),
+                                                      __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
+    }
+};
+template <> struct S0Mma<float> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+    }
+};
+
+template <typename T, int FMT>
+__global__ __launch_bounds__(256) void stem0_kernel(Stem0Params p) {
+    constexpr int P = Elem<T>::PER16;
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int ROWB = 32 * sizeof(T) + 16;
+    constexpr int HALF = 32 * sizeof(T) / 16 / 2;                 // k-steps of the project GEMM per lane half
+    constexpr int NIB = (S0_IPX + 31) / 32;                       // 6
+    __shared__ __attribute__((aligned(16))) char E[S0_IPX * ROWB];
+    __shared__ __attribute__((aligned(16))) T Xs[S0_PH * S0_PROW];
+    __shared__ __attribute__((aligned(16))) float Wd[9 * 32];
+    __shared__ float lut[FMT == CF_IN_U8_HWC_BGR ? 768 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 31, h = lane >> 5;
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const int ox0 = blockIdx.x * S0_TOW, oy0 = blockIdx.y * S0_TOH, b = blockIdx.z;
+
+    if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+        for (int i = tid; i < 768; i += 256) lut[i] = p.lut[i];
+    }
+    for (int i = tid; i < 9 * 32; i += 256) Wd[i] = p.wdw[i];
+    if constexpr (FMT == CF_IN_U8_HWC_BGR) __syncthreads();
+
+    // ---- stage the normalised image patch: patch row r, element e = col*3 + ci
+    const int iy0 = 2 * (oy0 - 1), ix0 = 2 * (ox0 - 1);
+    for (int i = tid; i < S0_PH * (S0_PW * 3); i += 256) {
+        const int r = i / (S0_PW * 3), e = i - r * (S0_PW * 3);
+        const int col = e / 3, ci = e - col * 3;
+        const int iy = iy0 + r, ix = ix0 + col;
+        float v = 0.0f;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+            if constexpr (FMT == CF_IN_U8_HWC_BGR)
+                v = lut[ci * 256 + ((const uint8_t*)p.x)[(((size_t)b * p.H + iy) * p.W + ix) * 3 + ci]];
+            else
+                v = ((const float*)p.x)[(((size_t)b * 3 + ci) * p.H + iy) * p.W + ix];
+        }
+        if constexpr (F32) Xs[r * S0_PROW + e] = v;
+        else Xs[r * S0_PROW + e] = (T)(pack_bf16x2(v, 0.0f) & 0xffffu);
+    }
+    __syncthreads();
+
+    // ---- phase 1: stem conv on MFMA + Swish -> E
+    u32x4 ws[F32 ? 4 : 2];
+#pragma unroll
+    for (int c = 0; c < (F32 ? 4 : 2); ++c) ws[c] = ld16((const char*)p.wstem + ((size_t)c * 64 + lane) * 16);
+    for (int ib = wave; ib < NIB; ib += 4) {
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < S0_IPX ? ip : S0_IPX - 1;
+        const int ty = ipc / S0_IW, tx = ipc - ty * S0_IW;           // tile pixel on the H/2 grid
+        const int y = oy0 - 1 + ty, x = ox0 - 1 + tx;
+        const bool inmap = (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo;
+        const T* xp = Xs + (2 * ty) * S0_PROW + (2 * tx) * 3;
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+        if constexpr (F32) {
+            float v[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int t = 2 * s + h;
+                const int ky = t / 9, rr = t - 9 * ky;
+                v[s] = t < 27 ? xp[ky * S0_PROW + rr] : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                u32x4 xc; xc.x = __float_as_uint(v[4 * c]); xc.y = __float_as_uint(v[4 * c + 1]);
+                xc.z = __float_as_uint(v[4 * c + 2]); xc.w = __float_as_uint(v[4 * c + 3]);
+                S0Mma<T>::run(a, ws[c], xc);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                uint32_t w4[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const int t0 = c * 16 + h * 8 + 2 * e2, t1 = t0 + 1;
+                    const int ky0 = t0 / 9, r0 = t0 - 9 * ky0, ky1 = t1 / 9, r1 = t1 - 9 * ky1;
+                    const uint32_t lo = t0 < 27 ? (uint32_t)xp[ky0 * S0_PROW + r0] : 0u;
+                    const uint32_t hi = t1 < 27 ? (uint32_t)xp[ky1 * S0_PROW + r1] : 0u;
+                    w4[e2] = lo | (hi << 16);
+                }
+                u32x4 xc; xc.x = w4[0]; xc.y = w4[1]; xc.z = w4[2]; xc.w = w4[3];
+                S0Mma<T>::run(a, ws[c], xc);
+            }
+        }
+        if (ip < S0_IPX) {
+            char* erow = E + ip * ROWB + h * 16 * (int)sizeof(T);
+#pragma unroll
+            for (int g = 0; g < 16 / P; ++g) {
+                float v[P];
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] = inmap ? swish_f(a[g * P + e]) : 0.0f;
+                st16(erow + g * 16, pack16<T>(v));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2 + 3: depthwise 3x3 + Swish -> project 32->16
+    const int o = wave * 32 + pl;
+    const int oy = o / S0_TOW, ox = o % S0_TOW;
+    const char* eb0 = E + (oy * S0_IW + ox) * ROWB;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) {
+        const int c = h * HALF + j;
+        float d[P];
+#pragma unroll
+        for (int e = 0; e < P; ++e) d[e] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float ev[P], wv[P];
+                unpack16<T>(ld16(eb0 + (ky * S0_IW + kx) * ROWB + c * 16), ev);
+                const char* wt = (const char*)Wd + ((ky * 3 + kx) * 32 + c * P) * 4;
+                unpack16<float>(ld16(wt), wv);
+                if constexpr (P == 8) unpack16<float>(ld16(wt + 16), wv + 4);
+#pragma unroll
+                for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
+            }
+#pragma unroll
+        for (int e = 0; e < P; ++e) d[e] = swish_f(d[e]);
+        S0Mma<T>::run(acc, ld16((const char*)p.wproj + ((size_t)j * 64 + lane) * 16), pack16<T>(d));
+    }
+    const int gy = oy0 + oy, gx = ox0 + ox;
+    if (h != 0 || gy >= Ho || gx >= Wo) return;                  // channels 0..15 live in the h == 0 lanes
+    T* out = (T*)p.y + (((size_t)b * Ho + gy) * Wo + gx) * 16;
+#pragma unroll
+    for (int g = 0; g < 16 / P; ++g) {
+        float v[P];
+#pragma unroll
+        for (int e = 0; e < P; ++e) v[e] = acc[g * P + e];
+        st16(out + g * P, pack16<T>(v));
+    }
+}
+
+hipError_t launch_stem0(hipStream_t s, int dtype, const Stem0Params& p) {
+    if (p.B <= 0) return hipSuccess;
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    dim3 grid((Wo + S0_TOW - 1) / S0_TOW, (Ho + S0_TOH - 1) / S0_TOH, p.B), blk(256);
+    set_kernel_tag("void cf::stem0_kernel<%s, %d>(cf::Stem0Params)", dtype == 0 ? "float" : "unsigned short", p.in_format);
+    if (dtype == 0) {
+        if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem0_kernel<float, CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((stem0_kernel<float, CF_IN_F32_NCHW>), grid, blk, 0, s, p);
+    } else {
+        if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem0_kernel<bf16_t, CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((stem0_kernel<bf16_t, CF_IN_F32_NCHW>), grid, blk, 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace cf
