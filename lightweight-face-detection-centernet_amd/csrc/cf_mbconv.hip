@@ -34,6 +34,7 @@ static inline int slot_channel(int nb, int i) {
 }
 
 constexpr int MB_TOH = 8, MB_TOW = 16;
+bool mb_supported(int dtype, int k, int s, int jx, int hc, int nbo, int res);
 
 template <typename T> struct MbMma;
 template <> struct MbMma<bf16_t> {
@@ -73,6 +74,7 @@ MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
     g.wexp_bytes = (size_t)g.nq * g.NBE * g.JX * 64 * 16;
     g.wdw_floats = (size_t)g.nq * k * k * g.HC;
     g.wproj_bytes = (size_t)g.NBO * g.nq * g.HALF * 64 * 16;
+    g.ok = mb_supported(dtype, k, s, g.JX, g.HC, g.NBO, (Cin == Cout && s == 1) ? 1 : 0);
     return g;
 }
 
@@ -118,32 +120,36 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
 // NW waves per workgroup (4 or 8).  With 8 waves the tile still has 4 pixel blocks: waves w and w+4
 // share pixel block w&3 and split the k-steps of every hidden chunk between them; their partial
 // project sums are combined once, through LDS, in the epilogue.  Twice the waves per LDS byte.
-template <typename T, int KS, int S, int NBO, bool RESID, int NW>
+// The block geometry (JX = 16-byte chunks of a Cin row per lane half, HC = hidden chunk) is a
+// template parameter: the expand / depthwise / project loops are straight-line code that the
+// compiler can interleave (MFMA next to VALU next to LDS) -- with run-time trip counts every k-step
+// became its own basic block and nothing overlapped.
+template <typename T, int KS, int S, int NBO, bool RESID, int NW, int JX, int HC>
 __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
     constexpr int P = Elem<T>::PER16;
     constexpr int IH = (MB_TOH - 1) * S + KS, IW = (MB_TOW - 1) * S + KS, IPX = IH * IW;
     constexpr int NIB = (IPX + 31) / 32;
-    constexpr int MAXJX = sizeof(T) == 4 ? 12 : 6;               // Cin <= 96
+    constexpr int MAXJX = JX;
     constexpr int NT = NW * 64;
+    constexpr int NBE = (HC + 31) / 32, HALF = HC * (int)sizeof(T) / 16 / 2;
+    constexpr int ROWB = HC * (int)sizeof(T) + 16;
+    constexpr int WXB = NBE * JX * 1024;                         // expand fragments per chunk (bytes)
+    constexpr int WSTAGE = WXB + KS * KS * HC * 4;               // + depthwise taps (fp32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ROWB = p.rowb;
     char* E = smem;
-    const int WXB = p.NBE * p.JX * 1024;                         // expand fragments per chunk (bytes)
-    const int WSTAGE = WXB + KS * KS * p.HC * 4;                 // + depthwise taps (fp32)
     char* Wst = smem + ((IPX * ROWB + 15) / 16 * 16);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
     const int ox0 = blockIdx.x * MB_TOW, oy0 = blockIdx.y * MB_TOH, b = blockIdx.z;
-    const int JX = p.JX, HC = p.HC, NBE = p.NBE, HALF = p.HALF, nq = p.nq;
+    const int nq = p.nq;
 
     // this lane's output pixel (phase 2/3 and epilogue) and its share of the k-steps
     const int pbk = wave & 3, jg = wave >> 2;
     const int o = pbk * 32 + pl;
     const int oy = o / MB_TOW, ox = o % MB_TOW;
     const unsigned e_pix = (unsigned)((oy * S) * IW + ox * S) * (unsigned)ROWB;
-    const int jsplit = NW == 8 ? (HALF + 1) / 2 : HALF;
-    const int j0 = jg ? jsplit : 0, j1 = jg ? HALF : jsplit;
+    constexpr int JSPLIT = NW == 8 ? (HALF + 1) / 2 : HALF;
 
     f32x16 acc[NBO];
 #pragma unroll
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
         const unsigned off = ((unsigned)gy * (unsigned)p.Win + (unsigned)gx) * rowbytes + (unsigned)(h * JX * 16);
         if (valid) {
 #pragma unroll
-            for (int j = 0; j < MAXJX; ++j) if (j < JX) xf[j] = ld16(xbase + off + j * 16);
+            for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
         } else {
 #pragma unroll
             for (int j = 0; j < MAXJX; ++j) xf[j] = zero16();
@@ -184,16 +190,14 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
         const bool ipok = ip < IPX;
         char* erow = E + (unsigned)(ipok ? ip : 0) * (unsigned)ROWB;
 #pragma unroll
-        for (int nbl = 0; nbl < 3; ++nbl) {
-            if (nbl < NBE) {
+        for (int nbl = 0; nbl < NBE; ++nbl) {
+            {
                 f32x16 a;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[r] = 0.0f;
                 const char* wb = wx + (nbl * JX * 64 + lane) * 16;
-                MbMma<T>::run(a, ld16(wb), xf[0]);
 #pragma unroll
-                for (int j = 1; j < MAXJX; ++j)
-                    if (j < JX) MbMma<T>::run(a, ld16(wb + j * 1024), xf[j]);
+                for (int j = 0; j < JX; ++j) MbMma<T>::run(a, ld16(wb + j * 1024), xf[j]);
                 const int ch0 = nbl * 32 + h * 16;
 #pragma unroll
                 for (int g = 0; g < 16 / P; ++g) {
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
                     for (int e = 0; e < P; ++e) v[e] = swish_f(a[g * P + e]);
                     const u32x4 pk = pack16<T>(v);
                     const int ch = ch0 + g * P;
-                    if (ipok && ch < HC) st16(erow + ch * (int)sizeof(T), pk);
+                    if (ch < HC) { if (ipok) st16(erow + ch * (int)sizeof(T), pk); }
                 }
             }
         }
@@ -233,25 +237,16 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
         if (q + 1 < nq) stage_weights(q + 1);       // streams in under this chunk's depthwise
 
         // ---- phase 2 + 3: depthwise + Swish in registers, straight into the project MFMA
-        u32x4 wpn[NBO];
-        if (j0 < j1) {
 #pragma unroll
-            for (int i = 0; i < NBO; ++i)
-                wpn[i] = ld16((const char*)p.wproj + ((((size_t)i * nq + q) * HALF + j0) * 64 + lane) * 16);
-        }
-        for (int j = j0; j < j1; ++j) {
+        for (int j = 0; j < HALF; ++j) {
+            // NW == 8: wave group jg owns k-steps [0, JSPLIT) or [JSPLIT, HALF) -- wave-uniform
+            if (NW == 8 && ((j < JSPLIT) != (jg == 0))) continue;
             u32x4 wpc[NBO];
 #pragma unroll
-            for (int i = 0; i < NBO; ++i) wpc[i] = wpn[i];
-            if (j + 1 < j1) {
-#pragma unroll
-                for (int i = 0; i < NBO; ++i)
-                    wpn[i] = ld16((const char*)p.wproj + ((((size_t)i * nq + q) * HALF + j + 1) * 64 + lane) * 16);
-            }
+            for (int i = 0; i < NBO; ++i)
+                wpc[i] = ld16((const char*)p.wproj + ((((size_t)i * nq + q) * HALF + j) * 64 + lane) * 16);
             const int c = h * HALF + j;                               // 16-byte chunk within HC
             float d[P];
-#pragma unroll
-            for (int e = 0; e < P; ++e) d[e] = 0.0f;
             const char* eb = E + e_pix + c * 16;
             const char* wdb = wdq + c * (P * 4);
 #pragma unroll
@@ -264,8 +259,13 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
                     float wv[P];
                     unpack16<float>(ld16(wt), wv);
                     if constexpr (P == 8) unpack16<float>(ld16(wt + 16), wv + 4);
+                    if (ky == 0 && kx == 0) {
 #pragma unroll
-                    for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
+                        for (int e = 0; e < P; ++e) d[e] = ev[e] * wv[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
+                    }
                 }
 #pragma unroll
             for (int e = 0; e < P; ++e) d[e] = swish_f(d[e]);
@@ -328,9 +328,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
     }
 }
 
-template <typename T, int KS, int S, int NBO, bool RESID, int NW>
+template <typename T, int KS, int S, int NBO, bool RESID, int NW, int JX, int HC>
 static hipError_t mb_launch_nw(hipStream_t s, const MbParams& p) {
-    auto kfn = mbconv_kernel<T, KS, S, NBO, RESID, NW>;
+    auto kfn = mbconv_kernel<T, KS, S, NBO, RESID, NW, JX, HC>;
     static thread_local size_t configured = 0;
     if (p.lds_bytes > 64 * 1024 && configured < p.lds_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
@@ -338,53 +338,62 @@ static hipError_t mb_launch_nw(hipStream_t s, const MbParams& p) {
         configured = p.lds_bytes;
     }
     dim3 grid((p.Wout + MB_TOW - 1) / MB_TOW, (p.Hout + MB_TOH - 1) / MB_TOH, p.B), blk(NW * 64);
-    set_kernel_tag("void cf::mbconv_kernel<%s, %d, %d, %d, %s, %d>(cf::MbParams)", type_tag<T>(), KS, S, NBO, RESID ? "true" : "false", NW);
+    set_kernel_tag("void cf::mbconv_kernel<%s, %d, %d, %d, %s, %d, %d, %d>(cf::MbParams)", type_tag<T>(), KS, S, NBO,
+                   RESID ? "true" : "false", NW, JX, HC);
     hipLaunchKernelGGL(kfn, grid, blk, p.lds_bytes, s, p);
     return hipGetLastError();
 }
 
-template <typename T, int KS, int S, int NBO, bool RESID>
+template <typename T, int KS, int S, int NBO, bool RESID, int JX, int HC>
 static hipError_t mb_launch(hipStream_t s, const MbParams& p) {
     // 8 waves need >= 2 k-steps per hidden chunk and room in the E region for the 4 partial-sum slabs
-    const size_t red_bytes = (size_t)4 * 64 * NBO * 16 * 4;
     constexpr int IPX = ((MB_TOH - 1) * S + KS) * ((MB_TOW - 1) * S + KS);
+    constexpr int HALF = HC * (int)sizeof(T) / 16 / 2;
+    constexpr bool can8 = HALF >= 2 && (size_t)4 * 64 * NBO * 16 * 4 <= (size_t)IPX * (HC * sizeof(T) + 16);
     const bool want8 = p.nw == 8 || (p.nw == 0 && KS == 5);
-    const bool can8 = want8 && p.HALF >= 2 && red_bytes <= (size_t)IPX * p.rowb;
-    return can8 ? mb_launch_nw<T, KS, S, NBO, RESID, 8>(s, p) : mb_launch_nw<T, KS, S, NBO, RESID, 4>(s, p);
+    if constexpr (can8) { if (want8) return mb_launch_nw<T, KS, S, NBO, RESID, 8, JX, HC>(s, p); }
+    return mb_launch_nw<T, KS, S, NBO, RESID, 4, JX, HC>(s, p);
 }
 
-template <typename T, int KS, int S>
-static hipError_t mb_by_out(hipStream_t s, const MbParams& p) {
-    const int nbo = (p.Cout + 31) / 32;
-    if (p.residual) {
-        if (S != 1) return hipErrorInvalidValue;
-        switch (nbo) {
-            case 1: return mb_launch<T, KS, 1, 1, true>(s, p);
-            case 2: return mb_launch<T, KS, 1, 2, true>(s, p);
-            case 3: return mb_launch<T, KS, 1, 3, true>(s, p);
-        }
-    } else {
-        switch (nbo) {
-            case 1: return mb_launch<T, KS, S, 1, false>(s, p);
-            case 2: return mb_launch<T, KS, S, 2, false>(s, p);
-            case 3: return mb_launch<T, KS, S, 3, false>(s, p);
-        }
-    }
-    return hipErrorInvalidValue;
+// The block shapes of the CenterFace backbone (model/centernet.py:211-219), layer1.0 .. layer4.1:
+//   X(dtype-independent: KS, S, Cin, hid-chunk rule, NBO, residual)
+struct MbEntry { int dtype, k, s, jx, hc, nbo, res; hipError_t (*fn)(hipStream_t, const MbParams&); };
+#define MB_ENTRY(T, DT, KS, S, JX, HC, NBO, RES) {DT, KS, S, JX, HC, NBO, RES, &mb_launch<T, KS, S, NBO, (RES != 0), JX, HC>}
+static const MbEntry kMbTable[] = {
+    // bf16 storage                           layer
+    MB_ENTRY(bf16_t, 1, 3, 2, 1, 32, 1, 0),   // 1.0  16 ->  96 -> 24
+    MB_ENTRY(bf16_t, 1, 3, 1, 2, 48, 1, 1),   // 1.1  24 -> 144 -> 24 (+res)
+    MB_ENTRY(bf16_t, 1, 5, 2, 2, 48, 1, 0),   // 2.0  24 -> 144 -> 32
+    MB_ENTRY(bf16_t, 1, 5, 1, 2, 96, 1, 1),   // 2.1  32 -> 192 -> 32 (+res)
+    MB_ENTRY(bf16_t, 1, 3, 2, 2, 32, 2, 0),   // 3.0  32 -> 192 -> 64
+    MB_ENTRY(bf16_t, 1, 3, 1, 4, 96, 2, 1),   // 3.1  64 -> 384 -> 64 (+res)
+    MB_ENTRY(bf16_t, 1, 5, 1, 4, 96, 3, 0),   // 4.0  64 -> 384 -> 96
+    MB_ENTRY(bf16_t, 1, 5, 1, 6, 96, 3, 1),   // 4.1  96 -> 576 -> 96 (+res)
+    // fp32 storage (parity mode)
+    MB_ENTRY(float, 0, 3, 2, 2, 32, 1, 0),
+    MB_ENTRY(float, 0, 3, 1, 3, 48, 1, 1),
+    MB_ENTRY(float, 0, 5, 2, 3, 48, 1, 0),
+    MB_ENTRY(float, 0, 5, 1, 4, 32, 1, 1),
+    MB_ENTRY(float, 0, 3, 2, 4, 32, 2, 0),
+    MB_ENTRY(float, 0, 3, 1, 8, 32, 2, 1),
+    MB_ENTRY(float, 0, 5, 1, 8, 32, 3, 0),
+    MB_ENTRY(float, 0, 5, 1, 12, 32, 3, 1),
+};
+#undef MB_ENTRY
+
+static const MbEntry* mb_find(int dtype, int k, int s, int jx, int hc, int nbo, int res) {
+    for (const MbEntry& e : kMbTable)
+        if (e.dtype == dtype && e.k == k && e.s == s && e.jx == jx && e.hc == hc && e.nbo == nbo && e.res == res) return &e;
+    return nullptr;
 }
 
-template <typename T>
-static hipError_t mb_by_shape(hipStream_t s, const MbParams& p) {
-    if (p.k == 3 && p.s == 1) return mb_by_out<T, 3, 1>(s, p);
-    if (p.k == 3 && p.s == 2) return mb_by_out<T, 3, 2>(s, p);
-    if (p.k == 5 && p.s == 1) return mb_by_out<T, 5, 1>(s, p);
-    if (p.k == 5 && p.s == 2) return mb_by_out<T, 5, 2>(s, p);
-    return hipErrorInvalidValue;
-}
+bool mb_supported(int dtype, int k, int s, int jx, int hc, int nbo, int res) { return mb_find(dtype, k, s, jx, hc, nbo, res) != nullptr; }
 
 hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p) {
     if (p.B <= 0) return hipSuccess;
-    return dtype == 0 ? mb_by_shape<float>(s, p) : mb_by_shape<bf16_t>(s, p);
+    const MbEntry* e = mb_find(dtype, p.k, p.s, p.JX, p.HC, (p.Cout + 31) / 32, p.residual ? 1 : 0);
+    if (!e) return hipErrorInvalidValue;
+    return e->fn(s, p);
 }
 
 }  // namespace cf
