@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void dw_kernel(DwParams p) {
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) wreg[t][e] = p.w[(size_t)t * p.C + c0 + e];
+        for (int v4 = 0; v4 < VEC / 4; ++v4)           // 16-byte weight loads (c0 is a multiple of 4)
+            unpack16<float>(ld16(p.w + (size_t)t * p.C + c0 + 4 * v4), &wreg[t][4 * v4]);
     float breg[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) breg[e] = BIAS ? p.bias[c0 + e] : 0.0f;

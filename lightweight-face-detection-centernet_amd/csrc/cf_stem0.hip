@@ -106,19 +106,43 @@ __global__ __launch_bounds__(256) void stem0_kernel(Stem0Params p) {
 
     // ---- stage the normalised image patch: patch row r, element e = col*3 + ci
     const int iy0 = 2 * (oy0 - 1), ix0 = 2 * (ox0 - 1);
-    for (int i = tid; i < S0_PH * (S0_PW * 3); i += 256) {
-        const int r = i / (S0_PW * 3), e = i - r * (S0_PW * 3);
-        const int col = e / 3, ci = e - col * 3;
-        const int iy = iy0 + r, ix = ix0 + col;
-        float v = 0.0f;
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-            if constexpr (FMT == CF_IN_U8_HWC_BGR)
-                v = lut[ci * 256 + ((const uint8_t*)p.x)[(((size_t)b * p.H + iy) * p.W + ix) * 3 + ci]];
-            else
-                v = ((const float*)p.x)[(((size_t)b * 3 + ci) * p.H + iy) * p.W + ix];
+    constexpr int NSTAGE = S0_PH * (S0_PW * 3);                   // 21 x 111 = 2331 elements
+    constexpr int NIT = (NSTAGE + 255) / 256;
+    {
+        // all loads of the patch are issued before any is consumed (one memory latency per tile)
+        float v[NIT];
+        int dst[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int r = i / (S0_PW * 3), e = i - r * (S0_PW * 3);
+            const int col = e / 3, ci = e - col * 3;
+            const int iy = iy0 + r, ix = ix0 + col;
+            dst[it] = i < NSTAGE ? r * S0_PROW + e : -1;
+            v[it] = 0.0f;
+            if (i < NSTAGE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+                    const uint32_t u = ((const uint8_t*)p.x)[(((size_t)b * p.H + iy) * p.W + ix) * 3 + ci];
+                    v[it] = __uint_as_float(u | (uint32_t)(ci << 8));      // table index, resolved below
+                } else {
+                    v[it] = ((const float*)p.x)[(((size_t)b * 3 + ci) * p.H + iy) * p.W + ix];
+                }
+            } else if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+                v[it] = __uint_as_float(0xffffffffu);                      // marks "outside the image"
+            }
         }
-        if constexpr (F32) Xs[r * S0_PROW + e] = v;
-        else Xs[r * S0_PROW + e] = (T)(pack_bf16x2(v, 0.0f) & 0xffffu);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            float val = v[it];
+            if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+                const uint32_t idx = __float_as_uint(v[it]);
+                val = idx == 0xffffffffu ? 0.0f : lut[idx];
+            }
+            if (dst[it] >= 0) {
+                if constexpr (F32) Xs[dst[it]] = val;
+                else Xs[dst[it]] = (T)(pack_bf16x2(val, 0.0f) & 0xffffu);
+            }
+        }
     }
     __syncthreads();
 
