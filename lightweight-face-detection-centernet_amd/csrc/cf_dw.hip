@@ -17,6 +17,8 @@
 //    writes its output once.
 #include "cf_common.h"
 #include "cf_kernels.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace cf {
 
@@ -133,6 +135,147 @@ static hipError_t dw_dispatch(hipStream_t s, const DwParams& p) {
     return hipGetLastError();
 }
 
+// ================================================================== LDS-staged variant
+// The input tile (halo included) of one channel chunk is copied HBM -> LDS by the DMA path
+// (global_load_lds_dwordx4: no VGPR round trip, a wave keeps 1 KiB per instruction in flight with
+// almost no registers), out-of-image chunks are sourced from a 16-byte zero constant (= ZeroPad2d),
+// then every thread computes output vectors from LDS: k*k ds_read_b128 of the tile + the tap weights
+// (fp32, staged once per workgroup).  Consecutive lanes own consecutive 16-byte channel groups of a
+// pixel, so LDS reads are conflict-free and global stores are whole pixels' worth of contiguous bytes.
+__device__ __attribute__((aligned(16))) const uint32_t g_dw_zero16[4] = {0u, 0u, 0u, 0u};
+
+struct DwLdsGeom { int Cc, nchunk, cpp, rc, nch, magic_rc, magic_cpp, nt; size_t lds_bytes; };
+
+template <typename T, int KS, int S, int TH, int TW, int ACT, bool BIAS>
+__global__ __launch_bounds__(256) void dw_lds_kernel(DwParams p, DwLdsGeom g) {
+    constexpr int P = Elem<T>::PER16;
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tile = smem;                                            // [IH][IW][Cc] T, linear 16-byte chunks
+    float* wl = reinterpret_cast<float*>(smem + (((size_t)g.nch * 16 + 1023) / 1024) * 1024);   // [k*k][Cc]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int b = blockIdx.z / g.nchunk, c0 = (blockIdx.z - b * g.nchunk) * g.Cc;
+    const int iy0 = y0 * S - p.pad_lo, ix0 = x0 * S - p.pad_lo;
+    const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.C + c0) * sizeof(T);
+
+    // ---- DMA the tile: chunk q -> (row, pixel, part); LDS address = q * 16 (lane-linear per wave)
+    const int ngroups = (g.nch + 63) >> 6;
+    for (int grp = wave; grp < ngroups; grp += 4) {
+        const int q = grp * 64 + lane;
+        const int row = __umulhi((unsigned)q, (unsigned)g.magic_rc);
+        const int rem = q - row * g.rc;
+        const int px = __umulhi((unsigned)rem, (unsigned)g.magic_cpp);
+        const int part = rem - px * g.cpp;
+        const int gy = iy0 + row, gx = ix0 + px;
+        const bool ok = q < g.nch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const char* src = ok ? xb + ((size_t)gy * p.W + gx) * p.C * sizeof(T) + part * 16
+                             : reinterpret_cast<const char*>(g_dw_zero16);
+        if (g.nt & 1)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tile + grp * 1024), 16, 0, 2);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tile + grp * 1024), 16, 0, 0);
+    }
+    for (int i = tid; i < KS * KS * (g.Cc / 4); i += 256) {       // tap weights of this channel chunk
+        const int t = i / (g.Cc / 4), c4 = i - t * (g.Cc / 4);
+        st16(wl + t * g.Cc + c4 * 4, ld16(p.w + (size_t)t * p.C + c0 + c4 * 4));
+    }
+    __syncthreads();                                              // waits for the DMA (vmcnt) too
+
+    // ---- compute: output vector v -> (pixel, channel group)
+    const int nvec = TH * TW * g.cpp;
+    for (int v = tid; v < nvec; v += 256) {
+        const int opx = __umulhi((unsigned)v, (unsigned)g.magic_cpp);
+        const int cg = v - opx * g.cpp;
+        const int oy = opx / TW, ox = opx % TW;
+        const int gy = y0 + oy, gx = x0 + ox;
+        if (gy >= p.Ho || gx >= p.Wo) continue;
+        const char* tb = tile + ((size_t)((oy * S) * IW + ox * S) * g.cpp + cg) * 16;
+        const float* wb = wl + cg * P;
+        float d[P];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                float ev[P], wv[P];
+                unpack16<T>(ld16(tb + (size_t)(ky * IW + kx) * g.cpp * 16), ev);
+                const float* wt = wb + (ky * KS + kx) * g.Cc;
+                unpack16<float>(ld16(wt), wv);
+                if constexpr (P == 8) unpack16<float>(ld16(wt + 4), wv + 4);
+                if (ky == 0 && kx == 0) {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) d[e] = ev[e] * wv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
+                }
+            }
+        const int ch = c0 + cg * P;
+#pragma unroll
+        for (int e = 0; e < P; ++e) d[e] = act_f<ACT>(d[e] + (BIAS ? p.bias[ch + e] : 0.0f));
+        u32x4* dstp = reinterpret_cast<u32x4*>((char*)p.y + ((((size_t)b * p.Ho + gy) * p.Wo + gx) * p.C + ch) * sizeof(T));
+        if (g.nt & 2) __builtin_nontemporal_store(pack16<T>(d), dstp);
+        else *dstp = pack16<T>(d);
+    }
+}
+
+static int magic_div(int d) { return (int)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }   // exact for n < 2^16
+
+template <typename T, int KS, int S, int TH, int TW>
+static hipError_t dw_lds_dispatch(hipStream_t s, const DwParams& p) {
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int P = 16 / (int)sizeof(T);
+    // channel chunk: largest divisor of C (multiple of one 16-byte group) whose tile fits 48 KiB (tile + tap weights stay under the 64 KiB default dynamic-LDS limit)
+    int Cc = 0;
+    for (int c = p.C; c >= P; c -= P)
+        if (p.C % c == 0 && (size_t)IH * IW * c * sizeof(T) <= 48 * 1024) { Cc = c; break; }
+    if (!Cc) return hipErrorInvalidValue;
+    DwLdsGeom g;
+    g.Cc = Cc; g.nchunk = p.C / Cc; g.cpp = Cc / P; g.rc = IW * g.cpp; g.nch = IH * g.rc;
+    if (g.nch >= 65536) return hipErrorInvalidValue;
+    g.magic_rc = magic_div(g.rc); g.magic_cpp = magic_div(g.cpp);
+    { static const int nt_env = getenv("CF_DW_NT") ? atoi(getenv("CF_DW_NT")) : 0; g.nt = nt_env; }
+    g.lds_bytes = (((size_t)g.nch * 16 + 1023) / 1024) * 1024 + (size_t)KS * KS * Cc * 4;
+    dim3 grid((p.Wo + TW - 1) / TW, (p.Ho + TH - 1) / TH, p.B * g.nchunk), blk(256);
+    const bool bias = p.bias != nullptr;
+    set_kernel_tag("void cf::dw_lds_kernel<%s, %d, %d, %d, %d, %d, %s>(cf::DwParams, cf::DwLdsGeom)", type_tag<T>(), KS, S, TH, TW,
+                   p.act, bias ? "true" : "false");
+#define CF_DW_LAUNCH(ACT, BIAS) \
+    hipLaunchKernelGGL((dw_lds_kernel<T, KS, S, TH, TW, ACT, BIAS>), grid, blk, g.lds_bytes, s, p, g); return hipGetLastError();
+    if (p.act == 1 && !bias) { CF_DW_LAUNCH(1, false) }
+    if (p.act == 0 && bias) { CF_DW_LAUNCH(0, true) }
+    if (p.act == 0 && !bias) { CF_DW_LAUNCH(0, false) }
+    CF_DW_LAUNCH(1, true)
+#undef CF_DW_LAUNCH
+}
+
+template <typename T>
+static hipError_t dw_lds_by_shape(hipStream_t s, const DwParams& p) {
+    static const int tv = getenv("CF_DW_TILE") ? atoi(getenv("CF_DW_TILE")) : 0;     // A/B of tile shapes
+    if (tv == 1) {
+        if (p.k == 3 && p.s == 1) return dw_lds_dispatch<T, 3, 1, 16, 16>(s, p);
+        if (p.k == 3 && p.s == 2) return dw_lds_dispatch<T, 3, 2, 8, 16>(s, p);
+        if (p.k == 5 && p.s == 1) return dw_lds_dispatch<T, 5, 1, 16, 16>(s, p);
+        if (p.k == 5 && p.s == 2) return dw_lds_dispatch<T, 5, 2, 8, 16>(s, p);
+    }
+    if (tv == 2) {
+        if (p.k == 3 && p.s == 1) return dw_lds_dispatch<T, 3, 1, 8, 32>(s, p);
+        if (p.k == 3 && p.s == 2) return dw_lds_dispatch<T, 3, 2, 4, 32>(s, p);
+        if (p.k == 5 && p.s == 1) return dw_lds_dispatch<T, 5, 1, 8, 32>(s, p);
+        if (p.k == 5 && p.s == 2) return dw_lds_dispatch<T, 5, 2, 4, 32>(s, p);
+    }
+    // measured on MI355X, B=64 (profiles/r01_dw_variants.md): wide tiles for the big early maps
+    // (less halo per byte), smaller ones where the channel chunk would otherwise drop below a pixel
+    if (p.k == 3 && p.s == 1) return p.C <= 32 ? dw_lds_dispatch<T, 3, 1, 16, 16>(s, p) : dw_lds_dispatch<T, 3, 1, 8, 16>(s, p);
+    if (p.k == 3 && p.s == 2) return p.Wo >= 64 ? dw_lds_dispatch<T, 3, 2, 4, 32>(s, p) : dw_lds_dispatch<T, 3, 2, 4, 16>(s, p);
+    if (p.k == 5 && p.s == 1) return p.Wo >= 32 ? dw_lds_dispatch<T, 5, 1, 16, 16>(s, p) : dw_lds_dispatch<T, 5, 1, 8, 32>(s, p);
+    if (p.k == 5 && p.s == 2) return p.Wo >= 64 ? dw_lds_dispatch<T, 5, 2, 4, 16>(s, p) : dw_lds_dispatch<T, 5, 2, 4, 32>(s, p);
+    return hipErrorInvalidValue;
+}
+
 template <typename T, int VEC3, int VEC5>
 static hipError_t dw_by_shape(hipStream_t s, const DwParams& p) {
     if (p.k == 3 && p.s == 1) return dw_dispatch<T, 3, 1, VEC3, 8>(s, p);
@@ -145,8 +288,13 @@ static hipError_t dw_by_shape(hipStream_t s, const DwParams& p) {
 hipError_t launch_dw(hipStream_t s, int dtype, const DwParams& p) {
     if (p.B <= 0) return hipSuccess;
     if (p.C % 8) return hipErrorInvalidValue;
-    if (dtype == 0) return dw_by_shape<float, 4, 4>(s, p);
-    return dw_by_shape<bf16_t, 8, 4>(s, p);
+    // CF_DW_VARIANT=march selects the register-marching kernel (A/B against the LDS-staged one)
+    static const bool march = getenv("CF_DW_VARIANT") && !strcmp(getenv("CF_DW_VARIANT"), "march");
+    if (march) {
+        if (dtype == 0) return dw_by_shape<float, 4, 4>(s, p);
+        return dw_by_shape<bf16_t, 8, 4>(s, p);
+    }
+    return dtype == 0 ? dw_lds_by_shape<float>(s, p) : dw_lds_by_shape<bf16_t>(s, p);
 }
 
 }  // namespace cf

@@ -23,11 +23,12 @@ def main():
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--collapse", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="three-kernel MBConv path (CF_FLAG_NO_FUSE)")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
     rng = np.random.default_rng(0)
     img = rng.integers(0, 256, (a.batch, a.size, a.size, 3), dtype=np.uint8)
-    eng = cfa.Engine(a.size, a.size, max_batch=a.batch, dtype=a.dtype, collapse_heads=a.collapse)
+    eng = cfa.Engine(a.size, a.size, max_batch=a.batch, dtype=a.dtype, collapse_heads=True if a.collapse else None, fuse=not a.no_fuse)
     d_in = eng.device_alloc(img.nbytes)
     eng.memcpy_h2d(d_in, img)
     fmt = cfa._lib.CF_IN_U8_HWC_BGR
