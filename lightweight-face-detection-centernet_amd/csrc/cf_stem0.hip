@@ -30,9 +30,10 @@ static inline int slot_channel(int nb, int i) {
     return nb * 32 + h * 16 + r;
 }
 
-constexpr int S0_TOH = 8, S0_TOW = 16;
-constexpr int S0_IH = S0_TOH + 2, S0_IW = S0_TOW + 2, S0_IPX = S0_IH * S0_IW;     // 10 x 18 = 180
-constexpr int S0_PH = 2 * S0_IH + 1, S0_PW = 2 * S0_IW + 1;                         // 21 x 37 image patch
+constexpr int S0_TOH = 16, S0_TOW = 16;                 // 8 waves: one 32-pixel block (2 rows) each
+constexpr int S0_NT = (S0_TOH * S0_TOW / 32) * 64;      // 512 threads
+constexpr int S0_IH = S0_TOH + 2, S0_IW = S0_TOW + 2, S0_IPX = S0_IH * S0_IW;     // 18 x 18 = 324
+constexpr int S0_PH = 2 * S0_IH + 1, S0_PW = 2 * S0_IW + 1;                         // 37 x 37 image patch
 constexpr int S0_PROW = S0_PW * 3 + 1;                                              // 112 elements per patch row
 
 void stem0_lut(float* lut /*[3][256]*/) {
@@ -82,12 +83,13 @@ template <> struct S0Mma<float> {
 };
 
 template <typename T, int FMT>
-__global__ __launch_bounds__(256) void stem0_kernel(Stem0Params p) {
+__global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
     constexpr int P = Elem<T>::PER16;
     constexpr bool F32 = sizeof(T) == 4;
     constexpr int ROWB = 32 * sizeof(T) + 16;
     constexpr int HALF = 32 * sizeof(T) / 16 / 2;                 // k-steps of the project GEMM per lane half
-    constexpr int NIB = (S0_IPX + 31) / 32;                       // 6
+    constexpr int NIB = (S0_IPX + 31) / 32;                       // 11
+    constexpr int NW = S0_NT / 64;
     __shared__ __attribute__((aligned(16))) char E[S0_IPX * ROWB];
     __shared__ __attribute__((aligned(16))) T Xs[S0_PH * S0_PROW];
     __shared__ __attribute__((aligned(16))) float Wd[9 * 32];
@@ -98,23 +100,23 @@ __global__ __launch_bounds__(256) void stem0_kernel(Stem0Params p) {
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const int ox0 = blockIdx.x * S0_TOW, oy0 = blockIdx.y * S0_TOH, b = blockIdx.z;
 
+    // table + tap weights -> LDS; their latency overlaps the patch loads issued right below
     if constexpr (FMT == CF_IN_U8_HWC_BGR) {
-        for (int i = tid; i < 768; i += 256) lut[i] = p.lut[i];
+        for (int i = tid; i < 768; i += S0_NT) lut[i] = p.lut[i];
     }
-    for (int i = tid; i < 9 * 32; i += 256) Wd[i] = p.wdw[i];
-    if constexpr (FMT == CF_IN_U8_HWC_BGR) __syncthreads();
+    for (int i = tid; i < 9 * 32; i += S0_NT) Wd[i] = p.wdw[i];
 
     // ---- stage the normalised image patch: patch row r, element e = col*3 + ci
     const int iy0 = 2 * (oy0 - 1), ix0 = 2 * (ox0 - 1);
-    constexpr int NSTAGE = S0_PH * (S0_PW * 3);                   // 21 x 111 = 2331 elements
-    constexpr int NIT = (NSTAGE + 255) / 256;
+    constexpr int NSTAGE = S0_PH * (S0_PW * 3);                   // 37 x 111 = 4107 elements
+    constexpr int NIT = (NSTAGE + S0_NT - 1) / S0_NT;
     {
         // all loads of the patch are issued before any is consumed (one memory latency per tile)
         float v[NIT];
         int dst[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
+            const int i = tid + it * S0_NT;
             const int r = i / (S0_PW * 3), e = i - r * (S0_PW * 3);
             const int col = e / 3, ci = e - col * 3;
             const int iy = iy0 + r, ix = ix0 + col;
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void stem0_kernel(Stem0Params p) {
                 v[it] = __uint_as_float(0xffffffffu);                      // marks "outside the image"
             }
         }
+        if constexpr (FMT == CF_IN_U8_HWC_BGR) __syncthreads();      // table is in LDS
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             float val = v[it];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void stem0_kernel(Stem0Params p) {
     u32x4 ws[F32 ? 4 : 2];
 #pragma unroll
     for (int c = 0; c < (F32 ? 4 : 2); ++c) ws[c] = ld16((const char*)p.wstem + ((size_t)c * 64 + lane) * 16);
-    for (int ib = wave; ib < NIB; ib += 4) {
+    for (int ib = wave; ib < NIB; ib += NW) {
         const int ip = ib * 32 + pl;
         const int ipc = ip < S0_IPX ? ip : S0_IPX - 1;
         const int ty = ipc / S0_IW, tx = ipc - ty * S0_IW;           // tile pixel on the H/2 grid
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256) void stem0_kernel(Stem0Params p) {
 hipError_t launch_stem0(hipStream_t s, int dtype, const Stem0Params& p) {
     if (p.B <= 0) return hipSuccess;
     const int Ho = p.H / 2, Wo = p.W / 2;
-    dim3 grid((Wo + S0_TOW - 1) / S0_TOW, (Ho + S0_TOH - 1) / S0_TOH, p.B), blk(256);
+    dim3 grid((Wo + S0_TOW - 1) / S0_TOW, (Ho + S0_TOH - 1) / S0_TOH, p.B), blk(S0_NT);
     set_kernel_tag("void cf::stem0_kernel<%s, %d>(cf::Stem0Params)", dtype == 0 ? "float" : "unsigned short", p.in_format);
     if (dtype == 0) {
         if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem0_kernel<float, CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
