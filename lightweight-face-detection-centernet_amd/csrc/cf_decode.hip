@@ -35,7 +35,7 @@ __device__ __forceinline__ float from_orderable(uint32_t k) {
 // suffix-inclusive scan over NBINS LDS counters by wave 0; finds digit d with
 // sum(hist[d+1..]) < kth <= sum(hist[d..]); returns d and the count above it via LDS result slots.
 template <int NBINS>
-__device__ __forceinline__ void find_digit(const uint32_t* hist, uint32_t kth, uint32_t* res /*[2]*/) {
+__device__ __forceinline__ void find_digit(const uint32_t* hist, uint32_t kth, uint32_t* res /*[3]: digit, count above, count in bin*/) {
     // called by all threads; wave 0 does the work
     if (threadIdx.x < 64) {
         constexpr int PER = NBINS / 64;
@@ -57,7 +57,7 @@ __device__ __forceinline__ void find_digit(const uint32_t* hist, uint32_t kth, u
             uint32_t above = excl;
             for (int i = PER - 1; i >= 0; --i) {
                 uint32_t c = hist[base + i];
-                if (above + c >= kth) { res[0] = (uint32_t)(base + i); res[1] = above; break; }
+                if (above + c >= kth) { res[0] = (uint32_t)(base + i); res[1] = above; res[2] = c; break; }
                 above += c;
             }
         }
@@ -66,20 +66,24 @@ __device__ __forceinline__ void find_digit(const uint32_t* hist, uint32_t kth, u
 
 __global__ __launch_bounds__(1024) void peak_topk_kernel(TopkParams p) {
     __shared__ uint32_t hist[2048];
-    __shared__ uint32_t res[2];
+    __shared__ uint32_t res[3];
     __shared__ uint32_t nsel;
     __shared__ u64 sel[1024];
 
     const int b = blockIdx.x;
     const int HW = p.h * p.w;
     const int tid = threadIdx.x;
-    const float* hm = p.heads + (size_t)b * HW * 16;          // channel 0 of each 16-float record
+    // dense heat-map plane when the head kernel provided one (coalesced), else channel 0 of the records
+    const float* hm = p.hm_plane ? p.hm_plane + (size_t)b * HW : p.heads + (size_t)b * HW * 16;
+    const int hs = p.hm_plane ? 1 : 16;
     u64* keys = p.scratch + (size_t)b * HW;
 
-    // ---- pass 0: peak test (_nms) and composite keys
+    // ---- pass 0: peak test (_nms), composite keys, and the histogram of the top 11 score bits
+    for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+    __syncthreads();
     for (int i = tid; i < HW; i += 1024) {
         const int y = i / p.w, x = i - y * p.w;
-        const float v = hm[(size_t)i * 16];
+        const float v = hm[(size_t)i * hs];
         float mx = v;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
@@ -87,11 +91,13 @@ __global__ __launch_bounds__(1024) void peak_topk_kernel(TopkParams p) {
             for (int dx = -1; dx <= 1; ++dx) {
                 const int yy = y + dy, xx = x + dx;
                 if ((unsigned)yy < (unsigned)p.h && (unsigned)xx < (unsigned)p.w)
-                    mx = fmaxf(mx, hm[((size_t)yy * p.w + xx) * 16]);
+                    mx = fmaxf(mx, hm[((size_t)yy * p.w + xx) * hs]);
             }
         // heat * keep  (keep = 1.0 where hmax == heat else 0.0); "+ 0.0f" canonicalises -0 to +0
         const float kept = (mx == v) ? v : (v * 0.0f + 0.0f);
-        keys[i] = ((u64)orderable(kept) << 32) | (u64)(0xffffffffu - (uint32_t)i);
+        const uint32_t ok = orderable(kept);
+        keys[i] = ((u64)ok << 32) | (u64)(0xffffffffu - (uint32_t)i);
+        atomicAdd(&hist[ok >> 21], 1u);
     }
     __syncthreads();
 
@@ -106,19 +112,24 @@ __global__ __launch_bounds__(1024) void peak_topk_kernel(TopkParams p) {
     for (int pass = 0; pass < 5; ++pass) {
         if (pass == 3) { prefix |= 0xfffe0000ull; mask |= 0xfffe0000ull; }
         const int sh = shifts[pass], wd = widths[pass];
-        for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < HW; i += 1024) {
-            const u64 k = keys[i];
-            if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> sh) & ((1u << wd) - 1u)], 1u);
+        if (pass > 0) {                                  // pass 0's histogram was built with the keys
+            for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < HW; i += 1024) {
+                const u64 k = keys[i];
+                if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> sh) & ((1u << wd) - 1u)], 1u);
+            }
+            __syncthreads();
         }
-        __syncthreads();
         find_digit<2048>(hist, kth, res);
         __syncthreads();
         prefix |= (u64)res[0] << sh;
         mask |= (u64)((1u << wd) - 1u) << sh;
         kth -= res[1];
+        const uint32_t in_bin = res[2];
         __syncthreads();
+        // all 32 score bits fixed and every key with that score is needed: no tie to break by index
+        if (pass == 2 && kth == in_bin) break;
     }
     const u64 thresh = prefix;          // exact K-th largest composite key (keys are distinct)
 

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
     sg = fminf(fmaxf(sg, 1e-4f), 1.0f - 1e-4f);
     out[0] = sg;
     out[15] = raw;
+    if (p.hm_plane) p.hm_plane[m] = sg;
     float* dst = p.heads + (size_t)m * 16;
 #pragma unroll
     for (int g = 0; g < 4; ++g) st16(dst + g * 4, pack16<float>(&out[g * 4]));

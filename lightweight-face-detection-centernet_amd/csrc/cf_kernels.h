@@ -108,6 +108,7 @@ struct HeadParams {
     const float* w1d;     // [96][16] dense second-stage table (two-stage only)
     const float* b1;      // [16]
     float* heads;         // [B][h][w][16] fp32: hm_sigmoid, wh0, wh1, lm0..9, reg0, reg1, hm_raw
+    float* hm_plane;      // optional dense [B][h][w] copy of hm_sigmoid for the peak test (coalesced reads)
     int B, h, w;
     int collapsed;
 };
@@ -122,6 +123,7 @@ hipError_t launch_heads(hipStream_t s, int dtype, const HeadParams& p);
 // D3: 3x3 peak test + top-K (radix select + bitonic sort) + gather, one workgroup per image.
 struct TopkParams {
     const float* heads;   // [B][h*w][16]
+    const float* hm_plane; // optional dense [B][h*w] heat map (else channel 0 of the records is used)
     unsigned long long* scratch;   // [B][h*w] composite keys
     int B, h, w, K, use_reg;
     float* dets;          // [B][K][6]

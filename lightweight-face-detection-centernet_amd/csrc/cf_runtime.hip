@@ -70,7 +70,7 @@ struct cf_ctx {
     std::string err;
     hipEvent_t events[64] = {};
     // decode workspaces (lazy)
-    unsigned long long* keys = nullptr;
+    unsigned long long* keys = nullptr; float* hm_plane = nullptr;
     float* d_dets = nullptr; float* d_lms = nullptr; long long* d_inds = nullptr; int decK = 0;
     float* t_cand = nullptr; int* t_count = nullptr; int* t_order = nullptr; unsigned long long* t_mask = nullptr;
     float* t_dets = nullptr; float* t_lms = nullptr; int* t_counts = nullptr; int* t_overflow = nullptr;
@@ -313,6 +313,8 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
         // zero-initialised incl. the slack: kernels may over-read (never write) one 16-byte chunk
         if ((e = hipMemset(b.p, 0, bytes)) != hipSuccess) return bail(CF_EHIP, "hipMemset(activations)", e);
     }
+    if ((e = hipMalloc((void**)&c->hm_plane, (size_t)max_batch * (H / 4) * (W / 4) * sizeof(float))) != hipSuccess)
+        return bail(CF_EHIP, "hipMalloc(hm_plane)", e);
     *out = c;
     return CF_OK;
 }
@@ -323,7 +325,7 @@ int cf_destroy(cf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& b : c->bufs) if (b.p) hipFree(b.p);
     for (void* p : c->owned) hipFree(p);
-    for (void* p : {(void*)c->keys, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
+    for (void* p : {(void*)c->hm_plane, (void*)c->keys, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
                     (void*)c->t_order, (void*)c->t_mask, (void*)c->t_dets, (void*)c->t_lms, (void*)c->t_counts, (void*)c->t_overflow})
         if (p) hipFree(p);
     for (auto& ev : c->events) if (ev) hipEventDestroy(ev);
@@ -507,7 +509,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
         }
         case OP_HEAD: {
             HeadParams p{}; p.x = bp(op.in); p.w0p = op.wp; p.b0 = op.bias; p.w1d = op.w1d; p.b1 = op.b1;
-            p.heads = (float*)bp(op.out); p.B = B; p.h = op.Hout; p.w = op.Wout;
+            p.heads = (float*)bp(op.out); p.hm_plane = c->hm_plane; p.B = B; p.h = op.Hout; p.w = op.Wout;
             p.collapsed = (c->flags & CF_FLAG_COLLAPSE_HEADS) ? 1 : 0;
             return launch_heads(c->stream, c->dtype, p);
         }
@@ -558,7 +560,7 @@ int ensure_topk_ws(cf_ctx* c, int K) {
 
 int enqueue_topk(cf_ctx* c, int B, int K, int use_reg, float* dets, float* lms, long long* inds) {
     TopkParams p{};
-    p.heads = (const float*)c->bufs[c->buf_heads].p; p.scratch = c->keys;
+    p.heads = (const float*)c->bufs[c->buf_heads].p; p.hm_plane = c->hm_plane; p.scratch = c->keys;
     p.B = B; p.h = c->H / 4; p.w = c->W / 4; p.K = K; p.use_reg = use_reg;
     p.dets = dets; p.lms = lms; p.inds = inds;
     HIPCHK(c, launch_peak_topk(c->stream, p));

@@ -100,11 +100,6 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const int ox0 = blockIdx.x * S0_TOW, oy0 = blockIdx.y * S0_TOH, b = blockIdx.z;
 
-    // table + tap weights -> LDS; their latency overlaps the patch loads issued right below
-    if constexpr (FMT == CF_IN_U8_HWC_BGR) {
-        for (int i = tid; i < 768; i += S0_NT) lut[i] = p.lut[i];
-    }
-    for (int i = tid; i < 9 * 32; i += S0_NT) Wd[i] = p.wdw[i];
 
     // ---- stage the normalised image patch: patch row r, element e = col*3 + ci
     const int iy0 = 2 * (oy0 - 1), ix0 = 2 * (ox0 - 1);
@@ -121,18 +116,24 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
             const int col = e / 3, ci = e - col * 3;
             const int iy = iy0 + r, ix = ix0 + col;
             dst[it] = i < NSTAGE ? r * S0_PROW + e : -1;
-            v[it] = 0.0f;
-            if (i < NSTAGE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-                if constexpr (FMT == CF_IN_U8_HWC_BGR) {
-                    const uint32_t u = ((const uint8_t*)p.x)[(((size_t)b * p.H + iy) * p.W + ix) * 3 + ci];
-                    v[it] = __uint_as_float(u | (uint32_t)(ci << 8));      // table index, resolved below
-                } else {
-                    v[it] = ((const float*)p.x)[(((size_t)b * 3 + ci) * p.H + iy) * p.W + ix];
-                }
-            } else if constexpr (FMT == CF_IN_U8_HWC_BGR) {
-                v[it] = __uint_as_float(0xffffffffu);                      // marks "outside the image"
+            // branch-free: the load is always issued from a clamped (valid) address and the result is
+            // discarded when the element lies outside the image -- predicated loads would each sit in
+            // their own exec-masked block with a full vmcnt(0) wait (9 serialised HBM round trips)
+            const bool ok = i < NSTAGE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+            if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+                const uint32_t u = ((const uint8_t*)p.x)[(((size_t)b * p.H + cy) * p.W + cx) * 3 + ci];
+                v[it] = __uint_as_float(ok ? (u | (uint32_t)(ci << 8)) : 0xffffffffu);   // table index | "outside"
+            } else {
+                const float f = ((const float*)p.x)[(((size_t)b * 3 + ci) * p.H + cy) * p.W + cx];
+                v[it] = ok ? f : 0.0f;
             }
         }
+        // table + tap weights -> LDS while the patch loads are in flight
+        if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+            for (int i = tid; i < 768; i += S0_NT) lut[i] = p.lut[i];
+        }
+        for (int i = tid; i < 9 * 32; i += S0_NT) Wd[i] = p.wdw[i];
         if constexpr (FMT == CF_IN_U8_HWC_BGR) __syncthreads();      // table is in LDS
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
