@@ -19,6 +19,7 @@
 //    cache line instead of striding across rows.
 #include "cf_common.h"
 #include "cf_kernels.h"
+#include <cstdlib>
 
 namespace cf {
 
@@ -160,6 +161,98 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
     }
 }
 
+// ------------------------------------------------------------------ weight-in-LDS variant
+// For the GEMM-heavy late layers (K, N up to 960 on 20x20 / 40x40 maps) the plain kernel is bound
+// by the L1 path that feeds one 1 KiB weight fragment per MFMA (64 B/clk/CU).  Here the four waves
+// of a workgroup share every weight fragment: KT k-steps x NBW n-blocks of fragments are DMA'd
+// HBM/L2 -> LDS (global_load_lds_dwordx4, lane-linear = fragment order, conflict-free) once per
+// workgroup and read back at 256 B/clk/CU.  Activations still stream straight into registers.
+template <typename T, int NBW, int ACT, int RES>
+__global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
+    constexpr int P = Elem<T>::PER16;
+    constexpr int KT = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [NBW][KT][1 KiB]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int pl = lane & 31, h = lane >> 5;
+    const long long pb = (long long)blockIdx.x * 4 + wave;
+    const long long m = pb * 32 + pl;
+    const bool mvalid = m < p.M;
+    const long long mr = mvalid ? m : p.M - 1;
+    const int NC = (int)((size_t)p.K * sizeof(T) / 16), NCh = (NC + 1) >> 1;
+    const int NB = (p.N + 31) >> 5;
+    const int nb0 = blockIdx.y * NBW;
+    const char* xrow = (const char*)p.x + (size_t)mr * p.K * sizeof(T) + (size_t)h * NCh * 16;
+    const int jmax = (h == 0) ? NCh : NC - NCh;
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    for (int j0 = 0; j0 < NCh; j0 += KT) {
+        const int kt = NCh - j0 < KT ? NCh - j0 : KT;
+        for (int c = wave; c < NBW * kt; c += 4) {
+            const int i = c / kt, jj = c - i * kt;
+            if (nb0 + i < NB) {
+                const char* src = (const char*)p.wp + ((((size_t)(nb0 + i) * NCh + j0 + jj) * 64) + lane) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + (i * KT + jj) * 1024), 16, 0, 0);
+            }
+        }
+        u32x4 xc[KT];
+#pragma unroll
+        for (int jj = 0; jj < KT; ++jj) xc[jj] = (j0 + jj < jmax) ? ld16(xrow + (size_t)(j0 + jj) * 16) : zero16();
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < KT; ++jj) {
+            if (jj < kt) {
+#pragma unroll
+                for (int i = 0; i < NBW; ++i)
+                    if (nb0 + i < NB) Mma<T>::run(acc[i], ld16(smem + (i * KT + jj) * 1024 + lane * 16), xc[jj]);
+            }
+        }
+        __syncthreads();
+    }
+    if (!mvalid) return;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        if (nb0 + i >= NB) break;
+        const int cb = (nb0 + i) * 32 + h * 16;
+#pragma unroll
+        for (int g = 0; g < 16 / P; ++g) {
+            const int ch = cb + g * P;
+            if (ch >= p.N) break;
+            float v[P];
+#pragma unroll
+            for (int e = 0; e < P; ++e) v[e] = act_f<ACT>(acc[i][g * P + e]);
+            if constexpr (RES == 1) {
+                float r[P];
+                unpack16<T>(ld16((const char*)p.res + ((size_t)m * p.N + ch) * sizeof(T)), r);
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] += r[e];
+            }
+            st16((char*)p.y + ((size_t)m * p.N + ch) * sizeof(T), pack16<T>(v));
+        }
+    }
+}
+
+template <typename T, int NBW>
+static hipError_t dispatch_wlds(hipStream_t s, const PwParams& p, dim3 grid) {
+    dim3 blk(256);
+    const size_t lds = (size_t)NBW * 4 * 1024;
+    const int res = p.res ? 1 : 0;
+#define CF_PWL_LAUNCH(ACT, RES) \
+    set_kernel_tag("void cf::pw_wlds_kernel<%s, %d, %d, %d>(cf::PwParams)", type_tag<T>(), NBW, ACT, RES); \
+    hipLaunchKernelGGL((pw_wlds_kernel<T, NBW, ACT, RES>), grid, blk, lds, s, p); return hipGetLastError();
+    if (p.act == 1 && res == 0) { CF_PWL_LAUNCH(1, 0) }
+    if (p.act == 0 && res == 0) { CF_PWL_LAUNCH(0, 0) }
+    if (p.act == 0 && res == 1) { CF_PWL_LAUNCH(0, 1) }
+#undef CF_PWL_LAUNCH
+    return hipErrorInvalidValue;
+}
+
 template <typename T, int NBW>
 static hipError_t dispatch_epi(hipStream_t s, const PwParams& p, dim3 grid) {
     dim3 blk(256);
@@ -183,6 +276,19 @@ template <typename T>
 static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
     const int NB = (p.N + 31) / 32;
     const long long gx = (p.M + 127) / 128;
+    // GEMM-heavy layers (no bias / IDAUp epilogue): share weight fragments through LDS
+    static const int wl_env = getenv("CF_PW_WLDS") ? atoi(getenv("CF_PW_WLDS")) : -1;     // A/B: 0 off, N = force NBW
+    if (wl_env != 0 && !p.bias && !p.low && p.K >= 64 && NB >= 4 && (p.act == 1 || p.act == 0)) {
+        int nbw = wl_env > 0 ? wl_env : 4;     // measured best of {4,5,6,8} on every late layer
+        dim3 grid((unsigned)gx, (unsigned)((NB + nbw - 1) / nbw));
+        switch (nbw) {
+            case 4: return dispatch_wlds<T, 4>(s, p, grid);
+            case 5: return dispatch_wlds<T, 5>(s, p, grid);
+            case 6: return dispatch_wlds<T, 6>(s, p, grid);
+            case 8: return dispatch_wlds<T, 8>(s, p, grid);
+            default: return dispatch_wlds<T, 5>(s, p, grid);
+        }
+    }
     // n-blocks per wave: as many as fit 64..128 accumulator VGPRs, fewer when the grid would be
     // too small to fill 256 CUs x 8 waves.
     int nbw = NB >= 4 ? 4 : NB;
