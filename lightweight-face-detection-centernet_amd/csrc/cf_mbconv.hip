@@ -160,31 +160,46 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
     const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * sizeof(T);
     const unsigned rowbytes = (unsigned)p.Cin * sizeof(T);
 
+    // weights of hidden chunk q -> stage (q & 1) by DMA (global_load_lds): nothing waits here, the
+    // copy lands under the following phase and is fenced by the next __syncthreads()
     auto stage_weights = [&](int q) {
         char* dst = Wst + (q & 1) * WSTAGE;
         const char* srcx = (const char*)p.wexp + (size_t)q * WXB;
-        for (int i = tid * 16; i < WXB; i += NT * 16) st16(dst + i, ld16(srcx + i));
+        for (int c = wave; c < WXB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+        constexpr int WDB = KS * KS * HC * 4;                         // multiple of 16, not of 1024
         const char* srcd = (const char*)(p.wdw + (size_t)q * KS * KS * HC);
-        for (int i = tid * 16; i < KS * KS * HC * 4; i += NT * 16) st16(dst + WXB + i, ld16(srcd + i));
+        for (int c = wave; c < (WDB + 1023) / 1024; c += NW)
+            if (c * 1024 + lane * 16 < WDB)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcd + c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(dst + WXB + c * 1024), 16, 0, 0);
     };
-    // input-tile pixel block ib -> this lane's X fragments; zero outside the image (= ZeroPad2d).
-    // A row whose 16-byte chunk count is odd is over-read by one chunk on the h=1 half: the matching
-    // weight fragment is zero and activation buffers are zero-initialised with slack, so it is inert.
-    auto load_x = [&](int ib, u32x4* xf) {
+    // This wave's input-tile pixel blocks (ib = wave + NW * t) -> X fragments, loaded ONCE: the input
+    // tile is the same for every hidden chunk.  Branch-free: always load from a clamped (valid)
+    // address, then zero what lies outside the image (= ZeroPad2d) -- predicated loads would each
+    // end in a full vmcnt(0) wait.  A row whose 16-byte chunk count is odd is over-read by one chunk
+    // on the h = 1 half: the matching weight fragment is zero and activation buffers are
+    // zero-initialised with slack, so it is inert.
+    constexpr int MAXI = (NIB + NW - 1) / NW;
+    u32x4 xf[MAXI][JX];
+#pragma unroll
+    for (int t = 0; t < MAXI; ++t) {
+        const int ib = wave + NW * t;
         const int ip = ib * 32 + pl;
         const int ipc = ip < IPX ? ip : IPX - 1;
         const int iy = ipc / IW, ix = ipc - iy * IW;
         const int gy = oy0 * S - p.pad_lo + iy, gx = ox0 * S - p.pad_lo + ix;
-        const bool valid = ib < NIB && ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
-        const unsigned off = ((unsigned)gy * (unsigned)p.Win + (unsigned)gx) * rowbytes + (unsigned)(h * JX * 16);
-        if (valid) {
+        const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+        const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
 #pragma unroll
-            for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
-        } else {
-#pragma unroll
-            for (int j = 0; j < MAXJX; ++j) xf[j] = zero16();
+        for (int j = 0; j < JX; ++j) {
+            const u32x4 v = ld16(xbase + off + j * 16);
+            xf[t][j].x = valid ? v.x : 0u; xf[t][j].y = valid ? v.y : 0u;
+            xf[t][j].z = valid ? v.z : 0u; xf[t][j].w = valid ? v.w : 0u;
         }
-    };
+    }
     auto expand_block = [&](int ib, const u32x4* xf, const char* wx) {
         const int ip = ib * 32 + pl;
         const bool ipok = ip < IPX;
@@ -218,20 +233,11 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
         const char* wdq = wx + WXB;
         __syncthreads();      // previous chunk's phase 2 done with E; this stage's weights landed
 
-        // ---- phase 1: expand + Swish -> E ; X fragments prefetched one pixel block ahead
-        {
-            u32x4 xa[MAXJX], xb[MAXJX];
-            int ib = wave;
-            load_x(ib, xa);
-            while (ib < NIB) {
-                load_x(ib + NW, xb);
-                expand_block(ib, xa, wx);
-                ib += NW;
-                if (ib >= NIB) break;
-                load_x(ib + NW, xa);
-                expand_block(ib, xb, wx);
-                ib += NW;
-            }
+        // ---- phase 1: expand + Swish -> E (X fragments are register-resident)
+#pragma unroll
+        for (int t = 0; t < MAXI; ++t) {
+            const int ib = wave + NW * t;
+            if (ib < NIB) expand_block(ib, xf[t], wx);
         }
         __syncthreads();
         if (q + 1 < nq) stage_weights(q + 1);       // streams in under this chunk's depthwise
