@@ -22,6 +22,7 @@
 // The same two free permutations as cf_pw.hip are used (output channel <-> MFMA row, k <-> slot).
 #include "cf_common.h"
 #include "cf_kernels.h"
+#include <type_traits>
 
 namespace cf {
 
@@ -33,8 +34,7 @@ static inline int slot_channel(int nb, int i) {
     return nb * 32 + h * 16 + r;
 }
 
-constexpr int MB_TOH = 8, MB_TOW = 16;
-bool mb_supported(int dtype, int k, int s, int jx, int hc, int nbo, int res);
+
 
 template <typename T> struct MbMma;
 template <> struct MbMma<bf16_t> {
@@ -52,32 +52,7 @@ template <> struct MbMma<float> {
     }
 };
 
-// ---------------------------------------------------------------- host: geometry + packing
-MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
-    MbGeom g{};
-    const int sz = (int)elem_size(dtype);
-    g.ok = (Cin % 8 == 0) && (hid % 48 == 0) && (Cout % 8 == 0) && Cout <= 96 && Cin <= 96 && (k == 3 || k == 5) && (s == 1 || s == 2);
-    if (!g.ok) return g;
-    // hidden chunk: whole 32-channel MFMA blocks where hid allows; smaller chunks for the stride-2
-    // tiles (4.6x more input pixels per output pixel in LDS) and for fp32 storage
-    if (dtype == 0) g.HC = (hid % 32 == 0) ? 32 : 48;
-    else if (s == 2) g.HC = (hid % 32 == 0) ? 32 : 48;
-    else g.HC = (hid % 96 == 0) ? 96 : 48;
-    g.nq = hid / g.HC;
-    g.NBE = (g.HC + 31) / 32;
-    g.JX = (Cin * sz / 16 + 1) / 2;
-    g.HALF = g.HC * sz / 16 / 2;
-    g.NBO = (Cout + 31) / 32;
-    const int IH = (MB_TOH - 1) * s + k, IW = (MB_TOW - 1) * s + k;
-    g.rowb = g.HC * sz + 16;
-    g.lds_bytes = (size_t)((IH * IW * g.rowb + 15) / 16 * 16) + 2 * ((size_t)g.NBE * g.JX * 1024 + (size_t)k * k * g.HC * 4);
-    g.wexp_bytes = (size_t)g.nq * g.NBE * g.JX * 64 * 16;
-    g.wdw_floats = (size_t)g.nq * k * k * g.HC;
-    g.wproj_bytes = (size_t)g.NBO * g.nq * g.HALF * 64 * 16;
-    g.ok = mb_supported(dtype, k, s, g.JX, g.HC, g.NBO, (Cin == Cout && s == 1) ? 1 : 0);
-    return g;
-}
-
+// ---------------------------------------------------------------- host: packing (geometry: mb_geometry below the kernel table)
 // we [hid][Cin], wd [hid][k*k], wp [Cout][hid]
 void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we,
                      const float* wd, const float* wp, void* wexp_host, float* wdw_host, void* wproj_host) {
@@ -117,39 +92,42 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
 }
 
 // ---------------------------------------------------------------- device
-// NW waves per workgroup (4 or 8).  With 8 waves the tile still has 4 pixel blocks: waves w and w+4
-// share pixel block w&3 and split the k-steps of every hidden chunk between them; their partial
-// project sums are combined once, through LDS, in the epilogue.  Twice the waves per LDS byte.
-// The block geometry (JX = 16-byte chunks of a Cin row per lane half, HC = hidden chunk) is a
-// template parameter: the expand / depthwise / project loops are straight-line code that the
-// compiler can interleave (MFMA next to VALU next to LDS) -- with run-time trip counts every k-step
-// became its own basic block and nothing overlapped.
-template <typename T, int KS, int S, int NBO, bool RESID, int NW, int JX, int HC>
+// Template geometry: TOH x TOW output tile (NPB = TOH*TOW/32 pixel blocks), NW waves = NPB x KG
+// (KG = 1 or 2 k-groups: with KG = 2, waves w and w + NPB share pixel block w % NPB and split the
+// k-steps of every hidden chunk; their partial project sums are combined once, through LDS, in the
+// epilogue -- twice the waves per LDS byte).  JX = 16-byte chunks of a Cin row per lane half, HC =
+// hidden chunk, EF = keep the expanded tile in LDS as fp32 (no bf16 unpack in the depthwise inner
+// loop: half the VALU work per tap, at 2x the LDS bytes per channel -> smaller HC).  Everything is
+// compile-time so the expand / depthwise / project loops are straight-line code.
+template <typename T, int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW, bool EF>
 __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
-    constexpr int P = Elem<T>::PER16;
-    constexpr int IH = (MB_TOH - 1) * S + KS, IW = (MB_TOW - 1) * S + KS, IPX = IH * IW;
+    typedef typename std::conditional<EF, float, T>::type ET;     // element type of E in LDS
+    constexpr int P = Elem<T>::PER16;                             // channels per project k-chunk
+    constexpr int EP = 16 / (int)sizeof(ET);                      // E elements per 16 bytes
+    constexpr int IH = (TOH - 1) * S + KS, IW = (TOW - 1) * S + KS, IPX = IH * IW;
     constexpr int NIB = (IPX + 31) / 32;
-    constexpr int MAXJX = JX;
-    constexpr int NT = NW * 64;
+    constexpr int NPB = TOH * TOW / 32, KG = NW / NPB;
+    static_assert(NPB * 32 == TOH * TOW && KG * NPB == NW && (KG == 1 || KG == 2), "tile / wave geometry");
     constexpr int NBE = (HC + 31) / 32, HALF = HC * (int)sizeof(T) / 16 / 2;
-    constexpr int ROWB = HC * (int)sizeof(T) + 16;
+    constexpr int ROWB = HC * (int)sizeof(ET) + 16;
     constexpr int WXB = NBE * JX * 1024;                         // expand fragments per chunk (bytes)
-    constexpr int WSTAGE = WXB + KS * KS * HC * 4;               // + depthwise taps (fp32)
+    constexpr int WDB = KS * KS * HC * 4;                        // depthwise taps (fp32)
+    constexpr int WSTAGE = WXB + WDB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* E = smem;
     char* Wst = smem + ((IPX * ROWB + 15) / 16 * 16);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
-    const int ox0 = blockIdx.x * MB_TOW, oy0 = blockIdx.y * MB_TOH, b = blockIdx.z;
+    const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH, b = blockIdx.z;
     const int nq = p.nq;
 
     // this lane's output pixel (phase 2/3 and epilogue) and its share of the k-steps
-    const int pbk = wave & 3, jg = wave >> 2;
+    const int pbk = wave % NPB, jg = wave / NPB;
     const int o = pbk * 32 + pl;
-    const int oy = o / MB_TOW, ox = o % MB_TOW;
+    const int oy = o / TOW, ox = o % TOW;
     const unsigned e_pix = (unsigned)((oy * S) * IW + ox * S) * (unsigned)ROWB;
-    constexpr int JSPLIT = NW == 8 ? (HALF + 1) / 2 : HALF;
+    constexpr int JSPLIT = KG == 2 ? (HALF + 1) / 2 : HALF;
 
     f32x16 acc[NBO];
 #pragma unroll
@@ -168,13 +146,13 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
         for (int c = wave; c < WXB / 1024; c += NW)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
-        constexpr int WDB = KS * KS * HC * 4;                         // multiple of 16, not of 1024
         const char* srcd = (const char*)(p.wdw + (size_t)q * KS * KS * HC);
         for (int c = wave; c < (WDB + 1023) / 1024; c += NW)
             if (c * 1024 + lane * 16 < WDB)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcd + c * 1024 + lane * 16),
                                                  (__attribute__((address_space(3))) void*)(dst + WXB + c * 1024), 16, 0, 0);
     };
+
     // This wave's input-tile pixel blocks (ib = wave + NW * t) -> X fragments, loaded ONCE: the input
     // tile is the same for every hidden chunk.  Branch-free: always load from a clamped (valid)
     // address, then zero what lies outside the image (= ZeroPad2d) -- predicated loads would each
@@ -200,29 +178,28 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
             xf[t][j].z = valid ? v.z : 0u; xf[t][j].w = valid ? v.w : 0u;
         }
     }
-    auto expand_block = [&](int ib, const u32x4* xf, const char* wx) {
+
+    auto expand_block = [&](int ib, const u32x4* xfr, const char* wx) {
         const int ip = ib * 32 + pl;
         const bool ipok = ip < IPX;
         char* erow = E + (unsigned)(ipok ? ip : 0) * (unsigned)ROWB;
 #pragma unroll
         for (int nbl = 0; nbl < NBE; ++nbl) {
-            {
-                f32x16 a;
+            f32x16 a;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] = 0.0f;
-                const char* wb = wx + (nbl * JX * 64 + lane) * 16;
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+            const char* wb = wx + (nbl * JX * 64 + lane) * 16;
 #pragma unroll
-                for (int j = 0; j < JX; ++j) MbMma<T>::run(a, ld16(wb + j * 1024), xf[j]);
-                const int ch0 = nbl * 32 + h * 16;
+            for (int j = 0; j < JX; ++j) MbMma<T>::run(a, ld16(wb + j * 1024), xfr[j]);
+            const int ch0 = nbl * 32 + h * 16;
 #pragma unroll
-                for (int g = 0; g < 16 / P; ++g) {
-                    float v[P];
+            for (int g = 0; g < 16 / EP; ++g) {
+                float v[EP];
 #pragma unroll
-                    for (int e = 0; e < P; ++e) v[e] = swish_f(a[g * P + e]);
-                    const u32x4 pk = pack16<T>(v);
-                    const int ch = ch0 + g * P;
-                    if (ch < HC) { if (ipok) st16(erow + ch * (int)sizeof(T), pk); }
-                }
+                for (int e = 0; e < EP; ++e) v[e] = swish_f(a[g * EP + e]);
+                const u32x4 pk = pack16<ET>(v);
+                const int ch = ch0 + g * EP;
+                if (ch < HC) { if (ipok) st16(erow + ch * (int)sizeof(ET), pk); }
             }
         }
     };
@@ -245,26 +222,27 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
         // ---- phase 2 + 3: depthwise + Swish in registers, straight into the project MFMA
 #pragma unroll
         for (int j = 0; j < HALF; ++j) {
-            // NW == 8: wave group jg owns k-steps [0, JSPLIT) or [JSPLIT, HALF) -- wave-uniform
-            if (NW == 8 && ((j < JSPLIT) != (jg == 0))) continue;
+            // KG == 2: wave group jg owns k-steps [0, JSPLIT) or [JSPLIT, HALF) -- wave-uniform
+            if (KG == 2 && ((j < JSPLIT) != (jg == 0))) continue;
             u32x4 wpc[NBO];
 #pragma unroll
             for (int i = 0; i < NBO; ++i)
                 wpc[i] = ld16((const char*)p.wproj + ((((size_t)i * nq + q) * HALF + j) * 64 + lane) * 16);
-            const int c = h * HALF + j;                               // 16-byte chunk within HC
+            const int c = h * HALF + j;                               // project k-chunk: P hidden channels
             float d[P];
-            const char* eb = E + e_pix + c * 16;
+            const char* eb = E + e_pix + c * (P * (int)sizeof(ET));
             const char* wdb = wdq + c * (P * 4);
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
-                    float ev[P];
-                    unpack16<T>(ld16(eb + (ky * IW + kx) * ROWB), ev);
+                    float ev[P], wv[P];
+                    const char* et = eb + (ky * IW + kx) * ROWB;
+#pragma unroll
+                    for (int g = 0; g < P / EP; ++g) unpack16<ET>(ld16(et + g * 16), ev + g * EP);
                     const char* wt = wdb + (ky * KS + kx) * HC * 4;
-                    float wv[P];
-                    unpack16<float>(ld16(wt), wv);
-                    if constexpr (P == 8) unpack16<float>(ld16(wt + 16), wv + 4);
+#pragma unroll
+                    for (int g = 0; g < P / 4; ++g) unpack16<float>(ld16(wt + g * 16), wv + g * 4);
                     if (ky == 0 && kx == 0) {
 #pragma unroll
                         for (int e = 0; e < P; ++e) d[e] = ev[e] * wv[e];
@@ -281,9 +259,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
         }
     }
 
-    // ---- combine the two k-halves (NW == 8): waves 4..7 hand their partial sums over through LDS
-    if constexpr (NW == 8) {
-        __syncthreads();                                  // everyone is done with E
+    // ---- combine the two k-groups: the upper group hands its partial sums over through LDS
+    if constexpr (KG == 2) {
+        __syncthreads();                                  // everyone is done with E and the stages
         float* red = reinterpret_cast<float*>(smem) + (size_t)(pbk * 64 + lane) * (NBO * 16);
         if (jg == 1) {
 #pragma unroll
@@ -334,71 +312,94 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
     }
 }
 
-template <typename T, int KS, int S, int NBO, bool RESID, int NW, int JX, int HC>
-static hipError_t mb_launch_nw(hipStream_t s, const MbParams& p) {
-    auto kfn = mbconv_kernel<T, KS, S, NBO, RESID, NW, JX, HC>;
+// One table row = one kernel instantiation = one block shape of the CenterFace backbone
+// (model/centernet.py:211-219, layer1.0 .. layer4.1) in one storage type.
+struct MbEntry {
+    int dtype, k, s, jx, hc, nbo, res;
+    int toh, tow, ef, nw, lds_bytes;
+    hipError_t (*fn)(hipStream_t, const MbParams&);
+};
+
+template <typename T, int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW, bool EF>
+static hipError_t mb_launch(hipStream_t s, const MbParams& p) {
+    auto kfn = mbconv_kernel<T, KS, S, NBO, RESID, NW, JX, HC, TOH, TOW, EF>;
     static thread_local size_t configured = 0;
     if (p.lds_bytes > 64 * 1024 && configured < p.lds_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
         configured = p.lds_bytes;
     }
-    dim3 grid((p.Wout + MB_TOW - 1) / MB_TOW, (p.Hout + MB_TOH - 1) / MB_TOH, p.B), blk(NW * 64);
-    set_kernel_tag("void cf::mbconv_kernel<%s, %d, %d, %d, %s, %d, %d, %d>(cf::MbParams)", type_tag<T>(), KS, S, NBO,
-                   RESID ? "true" : "false", NW, JX, HC);
+    dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
+    set_kernel_tag("void cf::mbconv_kernel<%s, %d, %d, %d, %s, %d, %d, %d, %d, %d, %s>(cf::MbParams)", type_tag<T>(), KS, S, NBO,
+                   RESID ? "true" : "false", NW, JX, HC, TOH, TOW, EF ? "true" : "false");
     hipLaunchKernelGGL(kfn, grid, blk, p.lds_bytes, s, p);
     return hipGetLastError();
 }
 
-template <typename T, int KS, int S, int NBO, bool RESID, int JX, int HC>
-static hipError_t mb_launch(hipStream_t s, const MbParams& p) {
-    // 8 waves need >= 2 k-steps per hidden chunk and room in the E region for the 4 partial-sum slabs
-    constexpr int IPX = ((MB_TOH - 1) * S + KS) * ((MB_TOW - 1) * S + KS);
-    constexpr int HALF = HC * (int)sizeof(T) / 16 / 2;
-    constexpr bool can8 = HALF >= 2 && (size_t)4 * 64 * NBO * 16 * 4 <= (size_t)IPX * (HC * sizeof(T) + 16);
-    const bool want8 = p.nw == 8 || (p.nw == 0 && KS == 5);
-    if constexpr (can8) { if (want8) return mb_launch_nw<T, KS, S, NBO, RESID, 8, JX, HC>(s, p); }
-    return mb_launch_nw<T, KS, S, NBO, RESID, 4, JX, HC>(s, p);
+template <typename T, int KS, int S, int JX, int HC, int TOH, int TOW, bool EF>
+constexpr int mb_lds_bytes() {
+    constexpr int ES = EF ? 4 : (int)sizeof(T);
+    constexpr int IPX = ((TOH - 1) * S + KS) * ((TOW - 1) * S + KS);
+    constexpr int NBE = (HC + 31) / 32;
+    return (IPX * (HC * ES + 16) + 15) / 16 * 16 + 2 * (NBE * JX * 1024 + KS * KS * HC * 4);
 }
 
-// The block shapes of the CenterFace backbone (model/centernet.py:211-219), layer1.0 .. layer4.1:
-//   X(dtype-independent: KS, S, Cin, hid-chunk rule, NBO, residual)
-struct MbEntry { int dtype, k, s, jx, hc, nbo, res; hipError_t (*fn)(hipStream_t, const MbParams&); };
-#define MB_ENTRY(T, DT, KS, S, JX, HC, NBO, RES) {DT, KS, S, JX, HC, NBO, RES, &mb_launch<T, KS, S, NBO, (RES != 0), JX, HC>}
+#define MB_ENTRY(T, DT, KS, S, JX, HC, NBO, RES, TOH, TOW, EF, NW) \
+    {DT, KS, S, JX, HC, NBO, RES, TOH, TOW, EF, NW, mb_lds_bytes<T, KS, S, JX, HC, TOH, TOW, (EF != 0)>(), \
+     &mb_launch<T, KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, (EF != 0)>}
 static const MbEntry kMbTable[] = {
-    // bf16 storage                           layer
-    MB_ENTRY(bf16_t, 1, 3, 2, 1, 32, 1, 0),   // 1.0  16 ->  96 -> 24
-    MB_ENTRY(bf16_t, 1, 3, 1, 2, 48, 1, 1),   // 1.1  24 -> 144 -> 24 (+res)
-    MB_ENTRY(bf16_t, 1, 5, 2, 2, 48, 1, 0),   // 2.0  24 -> 144 -> 32
-    MB_ENTRY(bf16_t, 1, 5, 1, 2, 96, 1, 1),   // 2.1  32 -> 192 -> 32 (+res)
-    MB_ENTRY(bf16_t, 1, 3, 2, 2, 32, 2, 0),   // 3.0  32 -> 192 -> 64
-    MB_ENTRY(bf16_t, 1, 3, 1, 4, 96, 2, 1),   // 3.1  64 -> 384 -> 64 (+res)
-    MB_ENTRY(bf16_t, 1, 5, 1, 4, 96, 3, 0),   // 4.0  64 -> 384 -> 96
-    MB_ENTRY(bf16_t, 1, 5, 1, 6, 96, 3, 1),   // 4.1  96 -> 576 -> 96 (+res)
+    // bf16 storage: KS S JX HC NBO res | tile  E-fp32 waves        layer   (per-layer best of the
+    // measured variants: E as bf16 vs fp32, tile 8x16 vs 4x16, 4 vs 8 waves -- profiles/r01_mbconv_variants.md)
+    MB_ENTRY(bf16_t, 1, 3, 2, 1, 32, 1, 0, 8, 16, 0, 4),   // 1.0  16 ->  96 -> 24
+    MB_ENTRY(bf16_t, 1, 3, 1, 2, 48, 1, 1, 8, 16, 0, 4),   // 1.1  24 -> 144 -> 24 (+res)
+    MB_ENTRY(bf16_t, 1, 5, 2, 2, 48, 1, 0, 8, 16, 0, 8),   // 2.0  24 -> 144 -> 32
+    MB_ENTRY(bf16_t, 1, 5, 1, 2, 96, 1, 1, 8, 16, 0, 8),   // 2.1  32 -> 192 -> 32 (+res)
+    MB_ENTRY(bf16_t, 1, 3, 2, 2, 32, 2, 0, 8, 16, 0, 4),   // 3.0  32 -> 192 -> 64
+    MB_ENTRY(bf16_t, 1, 3, 1, 4, 32, 2, 1, 8, 16, 1, 4),   // 3.1  64 -> 384 -> 64 (+res)
+    MB_ENTRY(bf16_t, 1, 5, 1, 4, 32, 3, 0, 8, 16, 1, 8),   // 4.0  64 -> 384 -> 96
+    MB_ENTRY(bf16_t, 1, 5, 1, 6, 32, 3, 1, 8, 16, 1, 8),   // 4.1  96 -> 576 -> 96 (+res)
     // fp32 storage (parity mode)
-    MB_ENTRY(float, 0, 3, 2, 2, 32, 1, 0),
-    MB_ENTRY(float, 0, 3, 1, 3, 48, 1, 1),
-    MB_ENTRY(float, 0, 5, 2, 3, 48, 1, 0),
-    MB_ENTRY(float, 0, 5, 1, 4, 32, 1, 1),
-    MB_ENTRY(float, 0, 3, 2, 4, 32, 2, 0),
-    MB_ENTRY(float, 0, 3, 1, 8, 32, 2, 1),
-    MB_ENTRY(float, 0, 5, 1, 8, 32, 3, 0),
-    MB_ENTRY(float, 0, 5, 1, 12, 32, 3, 1),
+    MB_ENTRY(float, 0, 3, 2, 2, 32, 1, 0, 8, 16, 1, 4),
+    MB_ENTRY(float, 0, 3, 1, 3, 48, 1, 1, 8, 16, 1, 4),
+    MB_ENTRY(float, 0, 5, 2, 3, 48, 1, 0, 8, 16, 1, 8),
+    MB_ENTRY(float, 0, 5, 1, 4, 32, 1, 1, 8, 16, 1, 8),
+    MB_ENTRY(float, 0, 3, 2, 4, 32, 2, 0, 8, 16, 1, 4),
+    MB_ENTRY(float, 0, 3, 1, 8, 32, 2, 1, 8, 16, 1, 4),
+    MB_ENTRY(float, 0, 5, 1, 8, 32, 3, 0, 8, 16, 1, 8),
+    MB_ENTRY(float, 0, 5, 1, 12, 32, 3, 1, 8, 16, 1, 8),
 };
 #undef MB_ENTRY
 
-static const MbEntry* mb_find(int dtype, int k, int s, int jx, int hc, int nbo, int res) {
+static const MbEntry* mb_find(int dtype, int k, int s, int jx, int nbo, int res) {
     for (const MbEntry& e : kMbTable)
-        if (e.dtype == dtype && e.k == k && e.s == s && e.jx == jx && e.hc == hc && e.nbo == nbo && e.res == res) return &e;
+        if (e.dtype == dtype && e.k == k && e.s == s && e.jx == jx && e.nbo == nbo && e.res == res) return &e;
     return nullptr;
 }
 
-bool mb_supported(int dtype, int k, int s, int jx, int hc, int nbo, int res) { return mb_find(dtype, k, s, jx, hc, nbo, res) != nullptr; }
+MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
+    MbGeom g{};
+    const int sz = (int)elem_size(dtype);
+    if ((Cin % 8) || (Cout % 8) || Cout > 96 || Cin > 96 || hid == Cin) return g;
+    g.JX = (Cin * sz / 16 + 1) / 2;
+    g.NBO = (Cout + 31) / 32;
+    const MbEntry* e = mb_find(dtype, k, s, g.JX, g.NBO, (Cin == Cout && s == 1) ? 1 : 0);
+    if (!e || hid % e->hc) return g;
+    g.ok = true;
+    g.HC = e->hc; g.nq = hid / g.HC;
+    g.NBE = (g.HC + 31) / 32;
+    g.HALF = g.HC * sz / 16 / 2;
+    g.rowb = g.HC * (e->ef ? 4 : sz) + 16;
+    g.lds_bytes = (size_t)e->lds_bytes;
+    g.wexp_bytes = (size_t)g.nq * g.NBE * g.JX * 64 * 16;
+    g.wdw_floats = (size_t)g.nq * k * k * g.HC;
+    g.wproj_bytes = (size_t)g.NBO * g.nq * g.HALF * 64 * 16;
+    return g;
+}
 
 hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p) {
     if (p.B <= 0) return hipSuccess;
-    const MbEntry* e = mb_find(dtype, p.k, p.s, p.JX, p.HC, (p.Cout + 31) / 32, p.residual ? 1 : 0);
-    if (!e) return hipErrorInvalidValue;
+    const MbEntry* e = mb_find(dtype, p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
+    if (!e || e->hc != p.HC) return hipErrorInvalidValue;
     return e->fn(s, p);
 }
 
