@@ -123,6 +123,8 @@ def main():
 
     def step():
         eng.forward_enqueue(d_in.data_ptr(), on_device=True, B=B, in_format=cfa._lib.CF_IN_U8_HWC_BGR)
+        if world > 1:
+            torch.cuda.current_stream().synchronize()   # last step's pack/gather has consumed d_dets / d_lms
         eng.decode_topk_device(K, d_dets.data_ptr(), d_lms.data_ptr(), d_inds.data_ptr())
         if world > 1:
             eng.synchronize()                      # hand-off ctx stream -> torch stream for RCCL

@@ -96,6 +96,17 @@ int cf_get_heads(cf_ctx* ctx, float* hm, float* wh, float* lm, float* reg, float
 int cf_decode_topk(cf_ctx* ctx, int K, int use_reg, float* dets, float* lms, int64_t* inds,
                    int out_on_device);
 
+/* Same, followed by ctdet_post_process (utils/post_process.py:83-100): both box corners are mapped
+ * from heat-map coordinates back to source-image coordinates with the inverse affine of
+ * get_affine_transform(center, scale, rot=0, (out_w, out_h), inv=1) (utils/image.py:19-66), fused into
+ * the decode kernel's epilogue.  centers [B,2] (c[i]), scales [B,2] (s[i]; [0] is used, as the
+ * reference does), out_w/out_h = heat-map size.  cv2.getAffineTransform is replaced by a float64
+ * 3-point solve. */
+int cf_decode_topk_post(cf_ctx* ctx, int K, int use_reg, const float* centers, const float* scales,
+                        int out_w, int out_h, float* dets, float* lms, int64_t* inds, int out_on_device);
+/* the 2x3 float64 matrix used above (row-major), for callers that want transform_preds themselves */
+int cf_affine_from_center_scale(float cx, float cy, float scale_w, int out_w, int out_h, double* trans6);
+
 /* ---- decode D1: replaces CenterFace.decode + nms (centerface.py:73-151) -------------------- */
 /* For each image: cells with hm > score_thresh in row-major order, boxes/landmarks with the
  * reference's arithmetic (offsets ignored, x2 = min(x1c + w, W)), greedy IoU >= nms_thresh
@@ -104,6 +115,12 @@ int cf_decode_topk(cf_ctx* ctx, int K, int use_reg, float* dets, float* lms, int
  * The reference ignores its `threshold` argument and uses 0.3 (centerface.py:77); pass 0.3f. */
 int cf_decode_threshold(cf_ctx* ctx, float score_thresh, float nms_thresh, int max_out,
                         float* dets, float* lms, int32_t* counts);
+
+/* mode 0 = the above (D1); mode 1 = D2, eval_widerface.decode (eval_widerface.py:92-110): the threshold
+ * argument is honoured and the offsets are added -- reg channel 1 to x and channel 0 to y plus the
+ * 0.5, exactly as that file does (:102-104) -- no landmarks; same greedy NMS (:112-152). */
+int cf_decode_threshold_ex(cf_ctx* ctx, int mode, float score_thresh, float nms_thresh, int max_out,
+                           float* dets, float* lms, int32_t* counts);
 
 /* ---- fused convenience: forward + D3 decode in one enqueue (eval_widerface.py:76-90 shape) -- */
 int cf_detect_topk(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int K,
@@ -173,6 +190,12 @@ int cf_op_ctdet_decode(int device, const float* heat, const float* wh, const flo
 int cf_op_decode_threshold(int device, const float* hm, const float* wh, const float* lm,
                            int B, int h, int w, int img_h, int img_w, float score_thresh,
                            float nms_thresh, int max_out, float* dets, float* lms, int32_t* counts);
+int cf_op_decode_threshold_ex(int device, int mode, const float* hm, const float* wh, const float* reg,
+                              const float* lm, int B, int h, int w, int img_h, int img_w, float score_thresh,
+                              float nms_thresh, int max_out, float* dets, float* lms, int32_t* counts);
+/* ctdet_post_process's coordinate part on explicit detections dets [B,K,dim] (in place, host array) */
+int cf_op_ctdet_post_process(int device, float* dets, const float* centers, const float* scales, int B, int K,
+                             int dim, int out_w, int out_h);
 /* CenterFace.nms alone (centerface.py:111-151): keep[] receives kept indices in keep order. */
 int cf_op_nms(int device, const float* boxes, const float* scores, int n, float nms_thresh,
               int32_t* keep, int32_t* n_keep);

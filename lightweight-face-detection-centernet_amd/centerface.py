@@ -126,14 +126,23 @@ class Engine(object):
         return self.heads()
 
     # -- decode -----------------------------------------------------------------------------
-    def decode_topk(self, K=100, use_reg=True, landmarks=True):
-        """ctdet_decode on the last forward's heads: (dets [B,K,6], lms [B,K,10] | None, inds [B,K])."""
+    def decode_topk(self, K=100, use_reg=True, landmarks=True, post=None):
+        """ctdet_decode on the last forward's heads: (dets [B,K,6], lms [B,K,10] | None, inds [B,K]).
+        ``post=(c, s)`` (centers [B,2], scales [B] or [B,2]) additionally applies ctdet_post_process's
+        coordinate mapping (utils/post_process.py:83-90) inside the decode kernel."""
         B = self.last_B
         dets = np.empty((B, K, 6), np.float32)
         lms = np.empty((B, K, 10), np.float32) if landmarks else None
         inds = np.empty((B, K), np.int64)
-        self._chk(self._L.cf_decode_topk(self._h, int(K), 1 if use_reg else 0, _lib.ptr(dets), _lib.ptr(lms),
-                                         _lib.ptr(inds), 0))
+        if post is None:
+            self._chk(self._L.cf_decode_topk(self._h, int(K), 1 if use_reg else 0, _lib.ptr(dets), _lib.ptr(lms),
+                                             _lib.ptr(inds), 0))
+        else:
+            c = np.ascontiguousarray(np.asarray(post[0], np.float32).reshape(B, 2))
+            s = np.asarray(post[1], np.float32)
+            s = np.ascontiguousarray(np.repeat(s.reshape(B, 1), 2, axis=1) if s.size == B else s.reshape(B, 2))
+            self._chk(self._L.cf_decode_topk_post(self._h, int(K), 1 if use_reg else 0, _lib.ptr(c), _lib.ptr(s),
+                                                  self.w, self.h, _lib.ptr(dets), _lib.ptr(lms), _lib.ptr(inds), 0))
         return dets, lms, inds
 
     def decode_topk_device(self, K, dets_ptr, lms_ptr=None, inds_ptr=None, use_reg=True):
@@ -142,14 +151,15 @@ class Engine(object):
                                          C.c_void_p(int(lms_ptr)) if lms_ptr else None,
                                          C.c_void_p(int(inds_ptr)) if inds_ptr else None, 1))
 
-    def decode_threshold(self, score_thresh=0.3, nms_thresh=0.3, max_out=1024):
-        """CenterFace.decode + nms on the last forward: list of (boxes [n,5], lms [n,10]) per image."""
+    def decode_threshold(self, score_thresh=0.3, nms_thresh=0.3, max_out=1024, mode="d1"):
+        """CenterFace.decode + nms on the last forward: list of (boxes [n,5], lms [n,10]) per image.
+        mode "d2" = eval_widerface.decode (eval_widerface.py:92-110): threshold honoured, offsets used."""
         B = self.last_B
         dets = np.empty((B, max_out, 5), np.float32)
         lms = np.empty((B, max_out, 10), np.float32)
         counts = np.empty((B,), np.int32)
-        self._chk(self._L.cf_decode_threshold(self._h, float(score_thresh), float(nms_thresh), int(max_out),
-                                              _lib.ptr(dets), _lib.ptr(lms), _lib.ptr(counts)))
+        self._chk(self._L.cf_decode_threshold_ex(self._h, {"d1": 0, "d2": 1}[mode], float(score_thresh), float(nms_thresh),
+                                                 int(max_out), _lib.ptr(dets), _lib.ptr(lms), _lib.ptr(counts)))
         return [(dets[b, :counts[b]].copy(), lms[b, :counts[b]].copy()) for b in range(B)]
 
     # -- timing -----------------------------------------------------------------------------

@@ -175,7 +175,16 @@ __global__ __launch_bounds__(1024) void peak_topk_kernel(TopkParams p) {
         else { xs = xs + 0.5f; ys = ys + 0.5f; }
         const float hw0 = rec[1] / 2.0f, hw1 = rec[2] / 2.0f;
         float* d = p.dets + ((size_t)b * p.K + tid) * 6;
-        d[0] = xs - hw0; d[1] = ys - hw1; d[2] = xs + hw0; d[3] = ys + hw1; d[4] = score; d[5] = 0.0f;
+        float bx1 = xs - hw0, by1 = ys - hw1, bx2 = xs + hw0, by2 = ys + hw1;
+        if (p.trans) {
+            // ctdet_post_process (utils/post_process.py:83-90): transform_preds on both corners with the
+            // inverse affine of get_affine_transform (utils/image.py:19-66); float64 like np.dot(t, pt)
+            const double* t = p.trans + (size_t)b * 6;
+            const double ax1 = t[0] * (double)bx1 + t[1] * (double)by1 + t[2], ay1 = t[3] * (double)bx1 + t[4] * (double)by1 + t[5];
+            const double ax2 = t[0] * (double)bx2 + t[1] * (double)by2 + t[2], ay2 = t[3] * (double)bx2 + t[4] * (double)by2 + t[5];
+            bx1 = (float)ax1; by1 = (float)ay1; bx2 = (float)ax2; by2 = (float)ay2;
+        }
+        d[0] = bx1; d[1] = by1; d[2] = bx2; d[3] = by2; d[4] = score; d[5] = 0.0f;
         if (p.lms) {
             float* l = p.lms + ((size_t)b * p.K + tid) * 10;
 #pragma unroll
@@ -225,8 +234,11 @@ __global__ __launch_bounds__(1024) void thresh_collect_kernel(ThreshParams p) {
                 const int cy = i / p.w, cx = i - cy * p.w;
                 // centerface.py:84-91 -- float32 sizes, float64 centre arithmetic, cast at the end
                 const float s0 = rec[1] * 4.0f, s1 = rec[2] * 4.0f;
-                double x1 = fmax(0.0, ((double)cx + 0.5) * 4.0 - (double)(s0 / 2.0f));
-                double y1 = fmax(0.0, ((double)cy + 0.5) * 4.0 - (double)(s1 / 2.0f));
+                // D2 (eval_widerface.py:102-104) adds the offsets -- channel 1 to x, channel 0 to y, as the
+                // reference does -- in float64 (int64 + float32 promotes to float64 in numpy)
+                const double ox = p.mode == 1 ? (double)rec[14] : 0.0, oy = p.mode == 1 ? (double)rec[13] : 0.0;
+                double x1 = fmax(0.0, ((double)cx + ox + 0.5) * 4.0 - (double)(s0 / 2.0f));
+                double y1 = fmax(0.0, ((double)cy + oy + 0.5) * 4.0 - (double)(s1 / 2.0f));
                 x1 = fmin(x1, (double)p.img_w); y1 = fmin(y1, (double)p.img_h);
                 const double x2 = fmin(x1 + (double)s0, (double)p.img_w);
                 const double y2 = fmin(y1 + (double)s1, (double)p.img_h);
@@ -327,6 +339,21 @@ __global__ __launch_bounds__(64) void thresh_sweep_kernel(ThreshParams p) {
         __syncthreads();
     }
     if (lane == 0) p.counts[b] = kept < p.max_out ? kept : p.max_out;
+}
+
+__global__ void affine_boxes_kernel(float* dets, const double* trans, int B, int K, int stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const double* t = trans + (size_t)(i / K) * 6;
+    float* d = dets + (size_t)i * stride;
+    const double x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3];
+    d[0] = (float)(t[0] * x1 + t[1] * y1 + t[2]); d[1] = (float)(t[3] * x1 + t[4] * y1 + t[5]);
+    d[2] = (float)(t[0] * x2 + t[1] * y2 + t[2]); d[3] = (float)(t[3] * x2 + t[4] * y2 + t[5]);
+}
+hipError_t launch_affine_boxes(hipStream_t s, float* dets, const double* trans, int B, int K, int stride) {
+    if (B * K <= 0) return hipSuccess;
+    hipLaunchKernelGGL(affine_boxes_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, dets, trans, B, K, stride);
+    return hipGetLastError();
 }
 
 hipError_t launch_nms_stages(hipStream_t s, const ThreshParams& p) {

@@ -129,6 +129,7 @@ struct TopkParams {
     float* dets;          // [B][K][6]
     float* lms;           // [B][K][10] or nullptr
     long long* inds;      // [B][K] or nullptr
+    const double* trans;  // optional [B][6]: row-major 2x3 affine (heat-map -> source image) applied to both box corners
 };
 hipError_t launch_peak_topk(hipStream_t s, const TopkParams& p);
 
@@ -138,6 +139,7 @@ struct ThreshParams {
     int B, h, w, img_h, img_w;
     float score_thresh, nms_thresh;
     int cap;              // candidate capacity per image
+    int mode;             // 0 = D1 CenterFace.decode (centerface.py:73-109), 1 = D2 eval_widerface.decode (:92-110)
     // workspace (device)
     float* cand;          // [B][cap][16]: x1,y1,x2,y2,score, lm[10], pad
     int* cand_count;      // [B]
@@ -151,6 +153,8 @@ struct ThreshParams {
     int* overflow;        // [1] set to 1 when some image exceeded cap
 };
 hipError_t launch_decode_threshold(hipStream_t s, const ThreshParams& p);
+// apply per-image 2x3 affines to the (x1,y1),(x2,y2) corners of dets [B][K][stride] in place (utils/post_process.py:83-90)
+hipError_t launch_affine_boxes(hipStream_t s, float* dets, const double* trans, int B, int K, int stride);
 // rank + suppression matrix + greedy sweep only (candidates already collected)
 hipError_t launch_nms_stages(hipStream_t s, const ThreshParams& p);
 

@@ -252,13 +252,13 @@ int cf_op_ctdet_decode(int device, const float* heat, const float* wh, const flo
     return sc.result("cf_op_ctdet_decode");
 }
 
-static int run_threshold(Scope& sc, const float* d_heads, int B, int h, int w, int img_h, int img_w,
+static int run_threshold(Scope& sc, int mode, const float* d_heads, int B, int h, int w, int img_h, int img_w,
                          float score_thresh, float nms_thresh, int cap, int max_out,
                          float* dets, float* lms, int32_t* counts, int* overflow_out) {
     const size_t words = (cap + 63) / 64;
     ThreshParams p{};
     p.heads = d_heads; p.B = B; p.h = h; p.w = w; p.img_h = img_h; p.img_w = img_w;
-    p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = cap;
+    p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = cap; p.mode = mode;
     p.cand = (float*)sc.alloc((size_t)B * cap * 16 * 4);
     p.cand_count = (int*)sc.alloc((size_t)B * 4);
     p.order = (int*)sc.alloc((size_t)B * cap * 4);
@@ -279,17 +279,37 @@ static int run_threshold(Scope& sc, const float* d_heads, int B, int h, int w, i
 int cf_op_decode_threshold(int device, const float* hm, const float* wh, const float* lm,
                            int B, int h, int w, int img_h, int img_w, float score_thresh,
                            float nms_thresh, int max_out, float* dets, float* lms, int32_t* counts) {
-    if (!hm || !wh || !dets || !counts || B < 1 || max_out < 1) return CF_EINVAL;
+    return cf_op_decode_threshold_ex(device, 0, hm, wh, nullptr, lm, B, h, w, img_h, img_w, score_thresh, nms_thresh,
+                                     max_out, dets, lms, counts);
+}
+
+int cf_op_decode_threshold_ex(int device, int mode, const float* hm, const float* wh, const float* reg, const float* lm,
+                              int B, int h, int w, int img_h, int img_w, float score_thresh,
+                              float nms_thresh, int max_out, float* dets, float* lms, int32_t* counts) {
+    if (!hm || !wh || !dets || !counts || B < 1 || max_out < 1 || (mode != 0 && mode != 1) || (mode == 1 && !reg)) return CF_EINVAL;
     Scope sc(device);
-    std::vector<float> rec = make_records(hm, wh, nullptr, lm, B, h, w);
+    std::vector<float> rec = make_records(hm, wh, reg, lm, B, h, w);
     const float* d_heads = sc.upv(rec);
     const int HW = h * w;
     const int cap = HW < 4096 ? (HW + 63) / 64 * 64 : 4096;
     int overflow = 0;
-    int r = run_threshold(sc, d_heads, B, h, w, img_h, img_w, score_thresh, nms_thresh, cap, max_out, dets, lms, counts, &overflow);
+    int r = run_threshold(sc, mode, d_heads, B, h, w, img_h, img_w, score_thresh, nms_thresh, cap, max_out, dets, lms, counts, &overflow);
     if (r) return r;
     if (overflow) { g_op_error = "candidate capacity exceeded"; return CF_EOVERFLOW; }
     return CF_OK;
+}
+
+int cf_op_ctdet_post_process(int device, float* dets, const float* centers, const float* scales, int B, int K, int dim,
+                             int out_w, int out_h) {
+    if (!dets || !centers || !scales || B < 1 || K < 1 || dim < 4) return CF_EINVAL;
+    Scope sc(device);
+    std::vector<double> t((size_t)B * 6);
+    for (int b = 0; b < B; ++b) cf_affine_from_center_scale(centers[2 * b], centers[2 * b + 1], scales[2 * b], out_w, out_h, &t[(size_t)b * 6]);
+    float* d = (float*)sc.up(dets, (size_t)B * K * dim * 4);
+    double* dt = sc.upv(t);
+    if (sc.err == hipSuccess) sc.chk(launch_affine_boxes(sc.s, d, dt, B, K, dim));
+    if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(dets, d, (size_t)B * K * dim * 4, hipMemcpyDeviceToHost, sc.s));
+    return sc.result("cf_op_ctdet_post_process");
 }
 
 int cf_op_nms(int device, const float* boxes, const float* scores, int n, float nms_thresh, int32_t* keep, int32_t* n_keep) {

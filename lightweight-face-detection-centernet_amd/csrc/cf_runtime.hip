@@ -70,7 +70,7 @@ struct cf_ctx {
     std::string err;
     hipEvent_t events[64] = {};
     // decode workspaces (lazy)
-    unsigned long long* keys = nullptr; float* hm_plane = nullptr;
+    unsigned long long* keys = nullptr; float* hm_plane = nullptr; double* d_trans = nullptr;
     float* d_dets = nullptr; float* d_lms = nullptr; long long* d_inds = nullptr; int decK = 0;
     float* t_cand = nullptr; int* t_count = nullptr; int* t_order = nullptr; unsigned long long* t_mask = nullptr;
     float* t_dets = nullptr; float* t_lms = nullptr; int* t_counts = nullptr; int* t_overflow = nullptr;
@@ -325,7 +325,7 @@ int cf_destroy(cf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& b : c->bufs) if (b.p) hipFree(b.p);
     for (void* p : c->owned) hipFree(p);
-    for (void* p : {(void*)c->hm_plane, (void*)c->keys, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
+    for (void* p : {(void*)c->d_trans, (void*)c->hm_plane, (void*)c->keys, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
                     (void*)c->t_order, (void*)c->t_mask, (void*)c->t_dets, (void*)c->t_lms, (void*)c->t_counts, (void*)c->t_overflow})
         if (p) hipFree(p);
     for (auto& ev : c->events) if (ev) hipEventDestroy(ev);
@@ -544,6 +544,31 @@ int stage_input(cf_ctx* c, const void* in, int in_format, int in_on_device, int 
     return CF_OK;
 }
 
+// get_affine_transform(center, scale, rot=0, output_size=(out_w, out_h), inv=1) (utils/image.py:27-60):
+// the three point pairs are built in float32 exactly as the numpy code does, then the 2x3 map
+// dst -> src is solved in float64 (Cramer) where the reference calls cv2.getAffineTransform.
+void inverse_affine(float cx, float cy, float sw, int out_w, int out_h, double t[6]) {
+    const float dw = (float)out_w, dh = (float)out_h;
+    // dst triangle (heat-map side)
+    const float d0x = dw * 0.5f, d0y = dh * 0.5f;
+    const float d1x = d0x + 0.0f, d1y = d0y + dw * -0.5f;
+    const float d2x = d1x - (d0y - d1y), d2y = d1y + (d0x - d1x);
+    // src triangle (image side)
+    const float s0x = cx, s0y = cy;
+    const float s1x = (float)((double)cx + 0.0), s1y = (float)((double)cy + (double)(sw * -0.5f));
+    const float s2x = s1x - (s0y - s1y), s2y = s1y + (s0x - s1x);
+    // solve [dx dy 1] * [a b c]^T = sx (and sy) for the three points
+    const double x0 = d0x, y0 = d0y, x1 = d1x, y1 = d1y, x2 = d2x, y2 = d2y;
+    const double det = x0 * (y1 - y2) - y0 * (x1 - x2) + (x1 * y2 - x2 * y1);
+    auto solve = [&](double u0, double u1, double u2, double* o) {
+        o[0] = (u0 * (y1 - y2) - y0 * (u1 - u2) + (u1 * y2 - u2 * y1)) / det;
+        o[1] = (x0 * (u1 - u2) - u0 * (x1 - x2) + (x1 * u2 - x2 * u1)) / det;
+        o[2] = (x0 * (y1 * u2 - y2 * u1) - y0 * (x1 * u2 - x2 * u1) + u0 * (x1 * y2 - x2 * y1)) / det;
+    };
+    solve(s0x, s1x, s2x, t);
+    solve(s0y, s1y, s2y, t + 3);
+}
+
 int ensure_topk_ws(cf_ctx* c, int K) {
     const size_t HW = (size_t)(c->H / 4) * (c->W / 4);
     if (!c->keys) HIPCHK(c, hipMalloc((void**)&c->keys, HW * c->max_batch * sizeof(unsigned long long)));
@@ -558,8 +583,9 @@ int ensure_topk_ws(cf_ctx* c, int K) {
     return CF_OK;
 }
 
-int enqueue_topk(cf_ctx* c, int B, int K, int use_reg, float* dets, float* lms, long long* inds) {
+int enqueue_topk(cf_ctx* c, int B, int K, int use_reg, float* dets, float* lms, long long* inds, const double* trans = nullptr) {
     TopkParams p{};
+    p.trans = trans;
     p.heads = (const float*)c->bufs[c->buf_heads].p; p.hm_plane = c->hm_plane; p.scratch = c->keys;
     p.B = B; p.h = c->H / 4; p.w = c->W / 4; p.K = K; p.use_reg = use_reg;
     p.dets = dets; p.lms = lms; p.inds = inds;
@@ -624,6 +650,35 @@ int cf_decode_topk(cf_ctx* c, int K, int use_reg, float* dets, float* lms, int64
     return CF_OK;
 }
 
+int cf_decode_topk_post(cf_ctx* c, int K, int use_reg, const float* centers, const float* scales, int out_w, int out_h,
+                        float* dets, float* lms, int64_t* inds, int out_on_device) {
+    if (!c || !dets || !centers || !scales) return CF_EINVAL;
+    if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_decode_topk_post before cf_forward");
+    const int B = c->last_B, HW = (c->H / 4) * (c->W / 4);
+    if (K < 1 || K > 1024 || K > HW) return c->fail(CF_EINVAL, "K=%d must be in [1, min(1024, %d)]", K, HW);
+    HIPCHK(c, hipSetDevice(c->device));
+    int r = ensure_topk_ws(c, K); if (r) return r;
+    if (!c->d_trans) HIPCHK(c, hipMalloc((void**)&c->d_trans, (size_t)c->max_batch * 6 * sizeof(double)));
+    std::vector<double> t((size_t)B * 6);
+    for (int b = 0; b < B; ++b) inverse_affine(centers[2 * b], centers[2 * b + 1], scales[2 * b], out_w, out_h, &t[(size_t)b * 6]);
+    HIPCHK(c, hipMemcpyAsync(c->d_trans, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // t is a stack-lifetime host buffer
+    if (out_on_device) return enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds, c->d_trans);
+    r = enqueue_topk(c, B, K, use_reg, c->d_dets, lms ? c->d_lms : nullptr, inds ? c->d_inds : nullptr, c->d_trans);
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(dets, c->d_dets, (size_t)B * K * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (lms) HIPCHK(c, hipMemcpyAsync(lms, c->d_lms, (size_t)B * K * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (inds) HIPCHK(c, hipMemcpyAsync(inds, c->d_inds, (size_t)B * K * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CF_OK;
+}
+
+int cf_affine_from_center_scale(float cx, float cy, float scale_w, int out_w, int out_h, double* trans6) {
+    if (!trans6 || out_w < 1 || out_h < 1) return CF_EINVAL;
+    inverse_affine(cx, cy, scale_w, out_w, out_h, trans6);
+    return CF_OK;
+}
+
 int cf_detect_topk(cf_ctx* c, const void* in, int in_format, int in_on_device, int B, int K,
                    float* dets, float* lms, int64_t* inds, int out_on_device) {
     int r = cf_forward(c, in, in_format, in_on_device, B);
@@ -657,14 +712,19 @@ static int ensure_thresh_ws(cf_ctx* c, int max_out) {
 
 int cf_decode_threshold(cf_ctx* c, float score_thresh, float nms_thresh, int max_out,
                         float* dets, float* lms, int32_t* counts) {
-    if (!c || !dets || !counts || max_out < 1) return CF_EINVAL;
+    return cf_decode_threshold_ex(c, 0, score_thresh, nms_thresh, max_out, dets, lms, counts);
+}
+
+int cf_decode_threshold_ex(cf_ctx* c, int mode, float score_thresh, float nms_thresh, int max_out,
+                           float* dets, float* lms, int32_t* counts) {
+    if (!c || !dets || !counts || max_out < 1 || (mode != 0 && mode != 1)) return CF_EINVAL;
     if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_decode_threshold before cf_forward");
     HIPCHK(c, hipSetDevice(c->device));
     int r = ensure_thresh_ws(c, max_out); if (r) return r;
     const int B = c->last_B;
     ThreshParams p{};
     p.heads = (const float*)c->bufs[c->buf_heads].p; p.B = B; p.h = c->H / 4; p.w = c->W / 4;
-    p.img_h = c->H; p.img_w = c->W; p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = c->t_cap;
+    p.img_h = c->H; p.img_w = c->W; p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = c->t_cap; p.mode = mode;
     p.cand = c->t_cand; p.cand_count = c->t_count; p.order = c->t_order; p.mask = c->t_mask;
     p.max_out = max_out; p.dets = c->t_dets; p.lms = c->t_lms; p.counts = c->t_counts; p.overflow = c->t_overflow;
     HIPCHK(c, hipMemsetAsync(c->t_overflow, 0, sizeof(int), c->stream));

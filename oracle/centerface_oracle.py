@@ -225,6 +225,74 @@ def ctdet_decode(heat, wh, reg=None, K=100, lm=None):
     return det, lms, inds
 
 
+# ----------------------------------------------------------------------------- post-process -----
+def _get_3rd_point(a, b):
+    """utils/image.py:69-71."""
+    direct = a - b
+    return b + np.array([-direct[1], direct[0]], dtype=np.float32)
+
+
+def _get_dir(src_point, rot_rad):
+    """utils/image.py:74-81."""
+    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
+    return [src_point[0] * cs - src_point[1] * sn, src_point[0] * sn + src_point[1] * cs]
+
+
+def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0], dtype=np.float32), inv=0):
+    """utils/image.py:27-60 with cv2.getAffineTransform replaced by a float64 solve of the same
+    3-point system (cv2 is not installable here: parity at that call is pinned analytically)."""
+    if not isinstance(scale, np.ndarray) and not isinstance(scale, list):
+        scale = np.array([scale, scale], dtype=np.float32)
+    scale_tmp = scale
+    src_w = scale_tmp[0]
+    dst_w, dst_h = output_size[0], output_size[1]
+    rot_rad = np.pi * rot / 180
+    src_dir = _get_dir([0, src_w * -0.5], rot_rad)
+    dst_dir = np.array([0, dst_w * -0.5], np.float32)
+    src = np.zeros((3, 2), dtype=np.float32)
+    dst = np.zeros((3, 2), dtype=np.float32)
+    src[0, :] = center + scale_tmp * shift
+    src[1, :] = center + src_dir + scale_tmp * shift
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + dst_dir
+    src[2:, :] = _get_3rd_point(src[0, :], src[1, :])
+    dst[2:, :] = _get_3rd_point(dst[0, :], dst[1, :])
+    a, b = (dst, src) if inv else (src, dst)
+    A = np.concatenate([a.astype(np.float64), np.ones((3, 1))], axis=1)
+    return np.linalg.solve(A, b.astype(np.float64)).T          # 2x3: b_i = M . [a_i, 1]
+
+
+def affine_transform(pt, t):
+    """utils/image.py:63-66."""
+    new_pt = np.array([pt[0], pt[1], 1.], dtype=np.float32).T
+    return np.dot(t, new_pt)[:2]
+
+
+def transform_preds(coords, center, scale, output_size):
+    """utils/image.py:19-24."""
+    target_coords = np.zeros(coords.shape)
+    trans = get_affine_transform(center, scale, 0, output_size, inv=1)
+    for p in range(coords.shape[0]):
+        target_coords[p, 0:2] = affine_transform(coords[p, 0:2], trans)
+    return target_coords
+
+
+def ctdet_post_process(dets, c, s, h, w, num_classes):
+    """utils/post_process.py:83-100 (dets modified in place, returns list of {cls+1: rows})."""
+    ret = []
+    for i in range(dets.shape[0]):
+        top_preds = {}
+        dets[i, :, :2] = transform_preds(dets[i, :, 0:2], c[i], s[i], (w, h))
+        dets[i, :, 2:4] = transform_preds(dets[i, :, 2:4], c[i], s[i], (w, h))
+        classes = dets[i, :, -1]
+        for j in range(num_classes):
+            inds = (classes == j)
+            top_preds[j + 1] = np.concatenate([dets[i, inds, :4].astype(np.float32),
+                                               dets[i, inds, 4:5].astype(np.float32)], axis=1).tolist()
+        ret.append(top_preds)
+    return ret
+
+
 # ----------------------------------------------------------------------------- decoder D1 ------
 def nms_greedy(boxes, scores, nms_thresh):
     """CenterFace.nms: centerface.py:111-151 (float32 arithmetic, +1 areas, ovr >= thresh).
@@ -287,6 +355,30 @@ def decode_d1(heatmap, scale, offset, landmark, size, threshold=0.1, nms_thresh=
     lms = np.asarray(lms, dtype=np.float32)
     keep = nms_greedy(boxes[:, :4], boxes[:, 4], nms_thresh)
     return boxes[keep, :], lms[keep, :]
+
+
+def decode_d2(heatmap, scale, offset, size, threshold=0.1, nms_thresh=0.3):
+    """eval_widerface.decode: eval_widerface.py:92-110.  heatmap [1,h,w], scale/offset [2,h,w].  The
+    threshold IS honoured; offsets are applied with channels swapped (o1 on x, o0 on y) and an extra
+    +0.5 (:102-104); int64 + float32 promotes to float64.  Returns boxes [n,5] f32 or []."""
+    hm = np.squeeze(heatmap)
+    s0m, s1m = scale[0], scale[1]
+    o0m, o1m = offset[0], offset[1]
+    c0, c1 = np.where(hm > threshold)
+    if len(c0) == 0:
+        return []
+    boxes = []
+    for y, x in zip(c0, c1):
+        s0 = np.float32(s0m[y, x]) * np.float32(4)
+        s1 = np.float32(s1m[y, x]) * np.float32(4)
+        o0, o1 = float(o0m[y, x]), float(o1m[y, x])
+        x1 = max(0.0, (float(x) + o1 + 0.5) * 4 - float(s0) / 2)
+        y1 = max(0.0, (float(y) + o0 + 0.5) * 4 - float(s1) / 2)
+        x1, y1 = min(x1, float(size[1])), min(y1, float(size[0]))
+        boxes.append([x1, y1, min(x1 + float(s0), float(size[1])), min(y1 + float(s1), float(size[0])), float(hm[y, x])])
+    boxes = np.asarray(boxes, dtype=np.float32)
+    keep = nms_greedy(boxes[:, :4], boxes[:, 4], nms_thresh)
+    return boxes[keep, :]
 
 
 def rescale(dets, lms, scale_h, scale_w):

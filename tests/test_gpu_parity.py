@@ -293,6 +293,40 @@ def test_ctdet_decode_large_crowd_map():
     assert (np.diff(d[..., 4], axis=1) <= 0).all()
 
 
+def test_ctdet_post_process_vs_oracle():
+    """utils/post_process.py:83-100 on the GPU: standalone on explicit dets and fused into the top-K
+    decode epilogue, against the oracle restatement (float64 matrices agree to rounding)."""
+    rng = np.random.default_rng(8)
+    B, K = 3, 50
+    dets = np.zeros((B, K, 6), np.float32)
+    dets[:, :, :4] = rng.uniform(-5, 170, (B, K, 4)); dets[:, :, 4] = rng.uniform(0, 1, (B, K))
+    c = np.array([[320, 320], [360, 239], [100.5, 77.25]], np.float32)
+    s = np.array([640.0, 736.0, 512.0], np.float32)
+    ref_in = dets.copy()
+    ref = O.ctdet_post_process(ref_in, c, s, 160, 160, 1)
+    got_in = dets.copy()
+    got = cfa.post_process.ctdet_post_process(got_in, c, s, 160, 160, 1)
+    np.testing.assert_allclose(got_in, ref_in, rtol=1e-6, atol=1e-4)
+    assert [sorted(g) for g in got] == [sorted(r) for r in ref] and len(got[0][1]) == K
+    np.testing.assert_allclose(np.asarray(got[2][1]), np.asarray(ref[2][1]), rtol=1e-6, atol=1e-4)
+    t = cfa.post_process.get_affine_transform(c[1], s[1], 0, (160, 160), inv=1)
+    np.testing.assert_allclose(t, O.get_affine_transform(c[1], s[1], 0, (160, 160), inv=1), rtol=1e-9, atol=1e-9)
+    pts = rng.uniform(0, 160, (7, 2)).astype(np.float32)
+    np.testing.assert_allclose(cfa.post_process.transform_preds(pts, c[2], s[2], (160, 160)),
+                               O.transform_preds(pts, c[2], s[2], (160, 160)), rtol=1e-6, atol=1e-4)
+    # fused into the decode kernel
+    eng = cfa.Engine(64, 96, max_batch=2, dtype="fp32")
+    eng.forward_enqueue(rng.integers(0, 256, (2, 64, 96, 3), dtype=np.uint8))
+    plain, _, inds = eng.decode_topk(K=20)
+    c2, s2 = np.array([[48, 32], [50, 30]], np.float32), np.array([96.0, 120.0], np.float32)
+    fused, _, inds2 = eng.decode_topk(K=20, post=(c2, s2))
+    assert np.array_equal(inds, inds2)
+    want = plain.copy()
+    O.ctdet_post_process(want, c2, s2, eng.h, eng.w, 1)
+    np.testing.assert_allclose(fused, want, rtol=1e-6, atol=1e-4)
+    eng.close()
+
+
 # ------------------------------------------------------------------------------- decode D1 + API
 def test_decode_d1_and_nms_bit_exact_vs_reference(golden):
     g = golden("decode_d1")
@@ -310,6 +344,32 @@ def test_decode_d1_and_nms_bit_exact_vs_reference(golden):
         assert keep == [int(v) for v in g["nms_keep_%d" % int(thr * 10)]]
     for (h, w), ref in zip(g["tf_in"], g["tf_out"]):
         assert np.array_equal(np.asarray(face.transform(int(h), int(w)), np.float64), ref)
+
+
+def test_decode_d2_and_get_detections(golden):
+    """eval_widerface.decode / get_detections (eval_widerface.py:76-152) on the GPU path: D2 decode
+    bit-exact against the reference goldens, batched get_detections against the oracle."""
+    from centerface_amd import eval_widerface as ew
+    g = golden("decode_d2")
+    for tag in "abc":
+        h, w = g[tag + "_hm"].shape[1:]
+        b = ew.decode(g[tag + "_hm"], g[tag + "_wh"], g[tag + "_off"], None, (h * 4, w * 4), threshold=float(g[tag + "_thr"]))
+        assert np.array_equal(np.asarray(b, np.float32).reshape(-1, 5), g[tag + "_boxes"].reshape(-1, 5)), tag
+    assert ew.decode(np.full((1, 4, 4), 0.1, np.float32), np.ones((2, 4, 4), np.float32), np.zeros((2, 4, 4), np.float32),
+                     None, (16, 16), threshold=0.5) == []
+    assert ew.nms(g["a_boxes"][:, :4], g["a_boxes"][:, 4], 0.3) == O.nms_greedy(g["a_boxes"][:, :4], g["a_boxes"][:, 4], 0.3)
+    # batched harness: forward on the GPU, then D2 of OUR heads must equal the oracle's D2 of the same heads
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((3, 3, 64, 96)).astype(np.float32)
+    eng = cfa.Engine(64, 96, max_batch=2, dtype="fp32")
+    dets = ew.get_detections({"input": x}, eng, threshold=0.2)
+    assert len(dets) == 3
+    for i in range(3):
+        eng.forward_enqueue(x[i:i + 1])
+        hd = eng.heads(sigmoid_hm=True)
+        ref = O.decode_d2(hd["hm_sigmoid"][0], hd["wh"][0], hd["reg"][0], (64, 96), threshold=0.2)
+        assert np.array_equal(np.asarray(dets[i], np.float32).reshape(-1, 5), np.asarray(ref, np.float32).reshape(-1, 5))
+    eng.close()
 
 
 def test_centerface_call_matches_oracle():

@@ -127,3 +127,36 @@ def test_transform_and_rescale(golden):
     assert np.array_equal(dets, g["f_dets"]) and np.array_equal(lms, g["f_lms"])
     d, l = O.rescale([], [], 1.0, 1.0)
     assert d.shape == (0, 5) and l.shape == (0, 10) and d.dtype == np.float32
+
+
+def test_post_process_affine_analytic():
+    """ctdet_post_process / transform_preds (utils/post_process.py:83-100, utils/image.py:19-66): cv2 is
+    not installable here, so the restatement is pinned analytically -- for rot = 0 the inverse map is
+    x_src = cx + (x - w/2) * (s/w), y_src = cy + (y - h/2) * (s/w)."""
+    rng = np.random.default_rng(4)
+    for (cx, cy, sc, w, h) in ((320.0, 240.0, 640.0, 160, 120), (100.5, 77.25, 512.0, 128, 128), (360.0, 239.0, 736.0, 184, 120)):
+        pts = rng.uniform(0, w, (20, 2)).astype(np.float32)
+        out = O.transform_preds(pts, np.array([cx, cy], np.float32), sc, (w, h))
+        r = sc / w
+        np.testing.assert_allclose(out[:, 0], cx + (pts[:, 0].astype(np.float64) - w / 2) * r, rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(out[:, 1], cy + (pts[:, 1].astype(np.float64) - h / 2) * r, rtol=1e-6, atol=1e-4)
+        fwd = O.get_affine_transform(np.array([cx, cy], np.float32), sc, 0, (w, h))
+        inv = O.get_affine_transform(np.array([cx, cy], np.float32), sc, 0, (w, h), inv=1)
+        eye = np.vstack([fwd, [0, 0, 1]]) @ np.vstack([inv, [0, 0, 1]])
+        np.testing.assert_allclose(eye, np.eye(3), atol=1e-9)
+    dets = np.zeros((2, 3, 6), np.float32)
+    dets[:, :, :4] = rng.uniform(0, 100, (2, 3, 4)); dets[:, :, 4] = [[0.9, 0.8, 0.7]] * 2
+    ret = O.ctdet_post_process(dets.copy(), np.array([[50, 50], [60, 40]], np.float32), np.array([200.0, 100.0], np.float32), 100, 100, 1)
+    assert len(ret) == 2 and list(ret[0]) == [1] and len(ret[0][1]) == 3 and len(ret[0][1][0]) == 5
+
+
+def test_decode_d2_vs_reference(golden):
+    """eval_widerface.decode (eval_widerface.py:92-152): threshold honoured, offsets swapped + 0.5."""
+    g = golden("decode_d2")
+    for tag in "abc":
+        h, w = g[tag + "_hm"].shape[1:]
+        b = O.decode_d2(g[tag + "_hm"], g[tag + "_wh"], g[tag + "_off"], (h * 4, w * 4), threshold=float(g[tag + "_thr"]))
+        assert np.array_equal(np.asarray(b, np.float32).reshape(-1, 5), g[tag + "_boxes"].reshape(-1, 5)), tag
+    assert len(g["a_boxes"]) > 10 and bool(g["empty_is_list"])
+    assert O.decode_d2(np.full((1, 4, 4), 0.1, np.float32), np.ones((2, 4, 4), np.float32),
+                       np.zeros((2, 4, 4), np.float32), (16, 16), threshold=0.5) == []

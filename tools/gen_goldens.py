@@ -11,7 +11,7 @@ per-op weights that produced them).  The whole-network cases use
 ``efficientnet_b0()``; only its fingerprint is stored, the weights are a pure function of the seed.
 
 Stubs: mlconfig.register (decorator, model/centernet.py:178,298),
-torchsummary.summary (:303), empty cv2 / torchvision / numba, np.bool (centerface.py:119), and
+torchsummary.summary (:303), empty cv2 / torchvision / numba, and
 model.centernet.ghost_net so that centerface_ext.py:4 resolves.
 """
 import os
@@ -36,7 +36,7 @@ def install_stubs():
     sys.modules["torchsummary"].summary = lambda *a, **k: None
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
     sys.modules["numba"].jit = lambda *a, **k: (lambda f: f)
-    np.bool = bool
+    # np.bool exists again in numpy >= 2.0 (alias of np.bool_), so centerface.py:119 needs no stub here
     sys.path.insert(0, REF)
 
 
@@ -264,6 +264,26 @@ def main():
     d1["f_scale"] = np.array([sh, sw])
     d1["f_dets"], d1["f_lms"] = dets, lms_
     np.savez_compressed(os.path.join(OUT, "decode_d1.npz"), **d1)
+
+    # ------------------------------------------------------------------ decoder D2 (eval_widerface.py:92-152)
+    import eval_widerface as ew
+    rng = np.random.default_rng(17)
+    d2 = {}
+    for tag, (H, W, thr) in (("a", (24, 40, 0.6)), ("b", (160, 160, 0.97)), ("c", (20, 12, 0.05))):
+        # strictly distinct scores: np.argsort(scores)[::-1] (an unstable sort) leaves the order of equal
+        # scores implementation-defined, and the greedy NMS result depends on it
+        vals = np.linspace(2e-4, 0.999, H * W, dtype=np.float64).astype(np.float32)
+        assert len(np.unique(vals)) == H * W
+        hm = vals[rng.permutation(H * W)].reshape(1, H, W)
+        wh = rng.uniform(0.5, 8, (2, H, W)).astype(np.float32)
+        off = rng.uniform(-0.5, 1.0, (2, H, W)).astype(np.float32)
+        boxes = ew.decode(hm, wh, off, None, (H * 4, W * 4), threshold=thr)
+        d2[tag + "_hm"], d2[tag + "_wh"], d2[tag + "_off"] = hm, wh, off
+        d2[tag + "_thr"] = np.array(thr)
+        d2[tag + "_boxes"] = np.asarray(boxes, np.float32)
+    d2["empty_is_list"] = np.array(isinstance(ew.decode(np.full((1, 4, 4), 0.1, np.float32), np.ones((2, 4, 4), np.float32),
+                                                         np.zeros((2, 4, 4), np.float32), None, (16, 16), threshold=0.5), list))
+    np.savez_compressed(os.path.join(OUT, "decode_d2.npz"), **d2)
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
