@@ -80,6 +80,12 @@ int cf_load_weights(cf_ctx* ctx, const cf_tensor_desc* tensors, int n);
 /* `in` is a host pointer (in_on_device = 0; copied H2D on the ctx stream) or a device pointer on
  * ctx's GPU (in_on_device = 1).  Asynchronous: returns after enqueueing. */
 int cf_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B);
+/* cv2.resize + forward in one enqueue (centerface.py:30-41): imgs uint8 [B,h,w,3] BGR of ANY size are
+ * stretch-resized on the device to the ctx's (H, W) (bilinear, half-pixel centres, float32, round to
+ * nearest) and fed to the network.  Bit parity with cv2's fixed-point INTER_LINEAR is unpinned. */
+int cf_forward_resized(cf_ctx* ctx, const void* imgs_u8, int in_on_device, int B, int h, int w);
+/* the resized uint8 [B,H,W,3] batch of the last cf_forward_resized (tests) */
+int cf_get_resized_input(cf_ctx* ctx, void* out_u8, int B);
 /* copies the four head maps of the last forward to host as NCHW float32: hm [B,1,h,w] raw logits
  * (what net() returns), wh [B,2,h,w], lm [B,10,h,w], reg [B,2,h,w]; h=H/4, w=W/4 (model/centernet.py
  * :277-280).  Any pointer may be NULL.  hm_sigmoid (optional) receives clamp(sigmoid(hm),1e-4,1-1e-4)

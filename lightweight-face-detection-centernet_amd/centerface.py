@@ -105,6 +105,22 @@ class Engine(object):
         self._chk(self._L.cf_forward(self._h, p, int(in_format), 1 if on_device else 0, int(B)))
         self.last_B = int(B)
 
+    def forward_resized_enqueue(self, imgs_u8):
+        """cv2.resize + forward (centerface.py:30-41): uint8 [B,h,w,3] BGR images of any (common) size are
+        stretch-resized on the device to (H, W) and fed to the network."""
+        x = np.ascontiguousarray(imgs_u8, dtype=np.uint8)
+        if x.ndim != 4 or x.shape[3] != 3:
+            raise ValueError("images must be uint8 [B,h,w,3], got %s" % (x.shape,))
+        self._keep_in = x
+        self._chk(self._L.cf_forward_resized(self._h, _lib.ptr(x), 0, x.shape[0], x.shape[1], x.shape[2]))
+        self.last_B = x.shape[0]
+
+    def resized_input(self):
+        """The resized uint8 [B,H,W,3] batch of the last forward_resized_enqueue (for tests)."""
+        out = np.empty((self.last_B, self.H, self.W, 3), np.uint8)
+        self._chk(self._L.cf_get_resized_input(self._h, _lib.ptr(out), self.last_B))
+        return out
+
     def synchronize(self):
         self._chk(self._L.cf_synchronize(self._h))
 
@@ -201,26 +217,6 @@ class Engine(object):
         self._chk(self._L.cf_memcpy_h2d(self._h, C.c_void_p(int(dptr)), _lib.ptr(arr), arr.nbytes))
 
 
-def _resize_bilinear_u8(img, new_h, new_w):
-    """Stand-in for cv2.resize(img, (w, h)) (centerface.py:30) -- bilinear with half-pixel centres.
-    cv2 is not installed where this was built, so parity with cv2's fixed-point INTER_LINEAR is
-    UNPINNED; for inputs whose sides are already multiples of 32 the resize is the identity."""
-    h, w = img.shape[:2]
-    if (h, w) == (new_h, new_w):
-        return img
-    ys = (np.arange(new_h, dtype=np.float64) + 0.5) * (h / new_h) - 0.5
-    xs = (np.arange(new_w, dtype=np.float64) + 0.5) * (w / new_w) - 0.5
-    y0 = np.clip(np.floor(ys).astype(np.int64), 0, h - 1); y1 = np.clip(y0 + 1, 0, h - 1)
-    x0 = np.clip(np.floor(xs).astype(np.int64), 0, w - 1); x1 = np.clip(x0 + 1, 0, w - 1)
-    fy = np.clip(ys - np.floor(ys), 0, 1)[:, None, None]
-    fx = np.clip(xs - np.floor(xs), 0, 1)[None, :, None]
-    fy = np.where(ys[:, None, None] < 0, 0.0, fy); fx = np.where(xs[None, :, None] < 0, 0.0, fx)
-    im = img.astype(np.float64)
-    top = im[y0][:, x0] * (1 - fx) + im[y0][:, x1] * fx
-    bot = im[y1][:, x0] * (1 - fx) + im[y1][:, x1] * fx
-    return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8)
-
-
 class CenterFace(object):
     """Same construction and call surface as the reference class (centerface.py:11-66)."""
     mean = np.array([0.408, 0.447, 0.470], dtype=np.float32).reshape(1, 1, 3)   # centerface.py:12-13
@@ -262,11 +258,15 @@ class CenterFace(object):
         """Batched ``__call__`` (the shape of eval_widerface.get_detections, :76-90).  The reference's
         decode ignores ``threshold`` and uses 0.3 (centerface.py:77); so does this."""
         del threshold
-        batch = np.stack([_resize_bilinear_u8(np.asarray(im, dtype=np.uint8), self.img_h_new, self.img_w_new)
-                          for im in imgs])
+        batch = np.stack([np.asarray(im, dtype=np.uint8) for im in imgs])    # one common (h, w) per instance
+        identity = batch.shape[1:3] == (self.img_h_new, self.img_w_new)
         out = []
         for i in range(0, len(batch), self.engine.max_batch):
-            self.engine.forward_enqueue(batch[i:i + self.engine.max_batch])
+            chunk = batch[i:i + self.engine.max_batch]
+            if identity:
+                self.engine.forward_enqueue(chunk)
+            else:
+                self.engine.forward_resized_enqueue(chunk)           # cv2.resize stand-in, on the device
             for dets, lms in self.engine.decode_threshold(0.3, self.nms_thresh, self.max_dets):
                 out.append(self._postprocess(dets, lms))
         return out

@@ -158,6 +158,9 @@ hipError_t launch_affine_boxes(hipStream_t s, float* dets, const double* trans, 
 // rank + suppression matrix + greedy sweep only (candidates already collected)
 hipError_t launch_nms_stages(hipStream_t s, const ThreshParams& p);
 
+// bilinear stretch-resize of uint8 HWC images (cv2.resize(img, (W, H)) at centerface.py:30; half-pixel centres)
+hipError_t launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int B, int h, int w, int H, int W);
+
 // layout converters used by cf_get_heads and the per-op test entry points
 hipError_t launch_nchw_to_nhwc(hipStream_t s, int dtype, const float* src /*f32 NCHW*/, void* dst /*T NHWC*/,
                                int B, int C, int H, int W);

@@ -70,7 +70,7 @@ struct cf_ctx {
     std::string err;
     hipEvent_t events[64] = {};
     // decode workspaces (lazy)
-    unsigned long long* keys = nullptr; float* hm_plane = nullptr; double* d_trans = nullptr;
+    unsigned long long* keys = nullptr; float* hm_plane = nullptr; double* d_trans = nullptr; uint8_t* src_stage = nullptr; size_t src_stage_bytes = 0;
     float* d_dets = nullptr; float* d_lms = nullptr; long long* d_inds = nullptr; int decK = 0;
     float* t_cand = nullptr; int* t_count = nullptr; int* t_order = nullptr; unsigned long long* t_mask = nullptr;
     float* t_dets = nullptr; float* t_lms = nullptr; int* t_counts = nullptr; int* t_overflow = nullptr;
@@ -325,7 +325,7 @@ int cf_destroy(cf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& b : c->bufs) if (b.p) hipFree(b.p);
     for (void* p : c->owned) hipFree(p);
-    for (void* p : {(void*)c->d_trans, (void*)c->hm_plane, (void*)c->keys, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
+    for (void* p : {(void*)c->src_stage, (void*)c->d_trans, (void*)c->hm_plane, (void*)c->keys, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
                     (void*)c->t_order, (void*)c->t_mask, (void*)c->t_dets, (void*)c->t_lms, (void*)c->t_counts, (void*)c->t_overflow})
         if (p) hipFree(p);
     for (auto& ev : c->events) if (ev) hipEventDestroy(ev);
@@ -604,6 +604,37 @@ int cf_forward(cf_ctx* c, const void* in, int in_format, int in_on_device, int B
     if (r) return r;
     for (auto& op : c->ops) HIPCHK(c, launch_op(c, op, net_in, in_format, B));
     c->last_B = B;
+    return CF_OK;
+}
+
+int cf_forward_resized(cf_ctx* c, const void* imgs, int in_on_device, int B, int h, int w) {
+    if (!c || !imgs || h < 1 || w < 1) return CF_EINVAL;
+    if (!c->weights_loaded) return c->fail(CF_ESTATE, "cf_forward_resized before cf_load_weights");
+    if (B < 1 || B > c->max_batch) return c->fail(CF_EINVAL, "cf_forward_resized: B=%d outside [1, %d]", B, c->max_batch);
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint8_t* src = (const uint8_t*)imgs;
+    if (!in_on_device) {
+        const size_t bytes = (size_t)B * h * w * 3;
+        if (c->src_stage_bytes < bytes) {
+            if (c->src_stage) HIPCHK(c, hipFree(c->src_stage));
+            c->src_stage = nullptr; c->src_stage_bytes = 0;
+            HIPCHK(c, hipMalloc((void**)&c->src_stage, bytes));
+            c->src_stage_bytes = bytes;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->src_stage, imgs, bytes, hipMemcpyHostToDevice, c->stream));
+        src = c->src_stage;
+    }
+    uint8_t* dst = (uint8_t*)c->bufs[c->buf_in].p;
+    HIPCHK(c, launch_resize_u8(c->stream, src, dst, B, h, w, c->H, c->W));
+    for (auto& op : c->ops) HIPCHK(c, launch_op(c, op, dst, CF_IN_U8_HWC_BGR, B));
+    c->last_B = B;
+    return CF_OK;
+}
+
+int cf_get_resized_input(cf_ctx* c, void* out_u8, int B) {
+    if (!c || !out_u8 || B < 1 || B > c->max_batch) return CF_EINVAL;
+    HIPCHK(c, hipMemcpyAsync(out_u8, c->bufs[c->buf_in].p, (size_t)B * c->H * c->W * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return CF_OK;
 }
 

@@ -156,6 +156,23 @@ def transform(h, w):
     return h_new, w_new, h_new / h, w_new / w
 
 
+def resize_bilinear_u8(img, new_h, new_w):
+    """Stand-in for cv2.resize(img, (w, h)) (centerface.py:30): bilinear, half-pixel centres, clamped,
+    float32 arithmetic, round-to-nearest-even -- the formula the device kernel implements.  cv2 is not
+    installable here, so parity with cv2's fixed-point INTER_LINEAR is UNPINNED."""
+    h, w = img.shape[:2]
+    f = np.float32
+    fy = np.clip((np.arange(new_h, dtype=f) + f(0.5)) * (f(h) / f(new_h)) - f(0.5), f(0), f(h - 1)).astype(f)
+    fx = np.clip((np.arange(new_w, dtype=f) + f(0.5)) * (f(w) / f(new_w)) - f(0.5), f(0), f(w - 1)).astype(f)
+    y0 = np.floor(fy).astype(np.int64); x0 = np.floor(fx).astype(np.int64)
+    y1 = np.minimum(y0 + 1, h - 1); x1 = np.minimum(x0 + 1, w - 1)
+    wy = (fy - y0.astype(f))[:, None, None]; wx = (fx - x0.astype(f))[None, :, None]
+    im = img.astype(f)
+    top = im[y0][:, x0] * (f(1) - wx) + im[y0][:, x1] * wx
+    bot = im[y1][:, x0] * (f(1) - wx) + im[y1][:, x1] * wx
+    return np.clip(np.rint(top * (f(1) - wy) + bot * wy), 0, 255).astype(np.uint8)
+
+
 def preprocess(img_bgr_u8):
     """centerface.py:32-37 for the identity-resize case (cv2.resize at :30 is unpinned):
     /255, (x-mean)/std in BGR order, HWC->CHW, add batch dim.  Returns float32 [1,3,H,W]."""
@@ -396,7 +413,8 @@ def detect(sd, img_bgr_u8, threshold=0.2):
     """CenterFace.__call__ (centerface.py:29-66) for images whose H, W are multiples of 32."""
     h, w = img_bgr_u8.shape[:2]
     h_new, w_new, sh, sw = transform(h, w)
-    assert (h_new, w_new) == (h, w), "cv2.resize is unpinned; oracle covers identity resize only"
+    if (h_new, w_new) != (h, w):                     # cv2.resize stand-in (parity with cv2 unpinned)
+        img_bgr_u8 = resize_bilinear_u8(img_bgr_u8, h_new, w_new)
     out = forward(sd, torch.from_numpy(preprocess(img_bgr_u8)))
     hm = sigmoid_clamp(out["hm"]).numpy()
     dets, lms = decode_d1(hm, out["wh"].numpy(), out["reg"].numpy(), out["lm"].numpy(),

@@ -84,3 +84,12 @@ def test_transform_table(golden):
     face = object.__new__(cfa.CenterFace)
     for (h, w), ref in zip(g["tf_in"], g["tf_out"]):
         assert np.array_equal(np.asarray(cfa.CenterFace.transform(face, int(h), int(w)), np.float64), ref)
+
+
+def test_wider_result_format(tmp_path):
+    """demo.py:81-87: path line, count line, then 'x y w h score' with w = x2 - x1 + 1."""
+    dets = np.array([[10.0, 20.0, 29.0, 59.0, 0.98765], [0.0, 0.0, 5.5, 7.25, 0.05]], np.float32)
+    txt = cfa.demo.format_wider_result("0--Parade/0_Parade_marchingband_1_465.jpg", dets)
+    assert txt == "0--Parade/0_Parade_marchingband_1_465.jpg\n2\n10.0 20.0 20.0 40.0 0.988\n0.0 0.0 6.5 8.2 0.050\n"
+    p = cfa.demo.write_wider_result(str(tmp_path), "0--Parade", "img_1", np.empty((0, 5), np.float32))
+    assert open(p).read() == "0--Parade/img_1.jpg\n0\n" and p.endswith("0--Parade/img_1.txt")

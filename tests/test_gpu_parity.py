@@ -372,6 +372,28 @@ def test_decode_d2_and_get_detections(golden):
     eng.close()
 
 
+def test_device_resize_and_non32_sizes():
+    """centerface.py:30 on the device: bilinear stretch to the next multiple of 32, against the numpy
+    restatement of the same formula (cv2 parity is unpinned), then the full __call__ on a 478x720 image
+    (imgs/1.jpg's size, BASELINE config 1 geometry)."""
+    rng = np.random.default_rng(12)
+    sd = cfa.weights.synthetic_state_dict(0)
+    for (h, w) in ((50, 70), (478, 720)):
+        img = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        face = cfa.CenterFace(h, w, weights=sd, max_batch=2)
+        assert (face.img_h_new, face.img_w_new) == (O.transform(h, w)[:2])
+        face.engine.forward_resized_enqueue(img)
+        got = face.engine.resized_input()
+        want = np.stack([O.resize_bilinear_u8(im, face.img_h_new, face.img_w_new) for im in img])
+        diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    res = face.detect_batch(list(img))
+    assert len(res) == 2
+    rd, rl = O.detect(O.to_torch_sd(sd), img[0])
+    dets, lms = res[0]
+    assert dets.shape[1] == 5 and lms.shape[1] == 10 and abs(len(dets) - len(rd)) <= max(2, len(rd) // 50)
+
+
 def test_centerface_call_matches_oracle():
     """CenterFace.__call__ end to end (identity-resize sizes) vs the oracle's restatement of it."""
     rng = np.random.default_rng(21)
