@@ -69,7 +69,14 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
             for (int j = 0; j < g.JX; ++j)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int i = lane & 31, h = lane >> 5;
-                    const int cl = slot_channel(nbl, i);           // channel within the hidden chunk
+                    int cl = slot_channel(nbl, i);                 // channel within the hidden chunk
+                    if (nbl == g.NBE - 1 && g.HC % 32 == 16) {
+                        // half-filled last block: 8 channels on EACH half of the MFMA rows (registers
+                        // 0..7 of both lane halves) instead of 16 on one half -- the Swish epilogue
+                        // then works on 8 live registers in every lane, none on dead ones
+                        const int hh = (i >> 2) & 1, rr = (i & 3) + 4 * (i >> 3);
+                        cl = rr < 8 ? nbl * 32 + hh * 8 + rr : g.HC;
+                    }
                     const int c = h * g.JX + j;                     // 16-byte chunk of the Cin row
                     if (cl >= g.HC || c >= NCx) continue;
                     char* dst = (char*)wexp_host + ((((size_t)q * g.NBE + nbl) * g.JX + j) * 64 + lane) * 16;
@@ -191,15 +198,26 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
             const char* wb = wx + (nbl * JX * 64 + lane) * 16;
 #pragma unroll
             for (int j = 0; j < JX; ++j) MbMma<T>::run(a, ld16(wb + j * 1024), xfr[j]);
-            const int ch0 = nbl * 32 + h * 16;
+            constexpr bool PARTIAL = (HC % 32 == 16);
+            if (PARTIAL && nbl == NBE - 1) {
+                // half-filled last block: channels nbl*32 + h*8 + [0,8) live in registers 0..7
+                const int ch0 = nbl * 32 + h * 8;
 #pragma unroll
-            for (int g = 0; g < 16 / EP; ++g) {
-                float v[EP];
+                for (int g = 0; g < 8 / EP; ++g) {
+                    float v[EP];
 #pragma unroll
-                for (int e = 0; e < EP; ++e) v[e] = swish_f(a[g * EP + e]);
-                const u32x4 pk = pack16<ET>(v);
-                const int ch = ch0 + g * EP;
-                if (ch < HC) { if (ipok) st16(erow + ch * (int)sizeof(ET), pk); }
+                    for (int e = 0; e < EP; ++e) v[e] = swish_f(a[g * EP + e]);
+                    if (ipok) st16(erow + (ch0 + g * EP) * (int)sizeof(ET), pack16<ET>(v));
+                }
+            } else {
+                const int ch0 = nbl * 32 + h * 16;
+#pragma unroll
+                for (int g = 0; g < 16 / EP; ++g) {
+                    float v[EP];
+#pragma unroll
+                    for (int e = 0; e < EP; ++e) v[e] = swish_f(a[g * EP + e]);
+                    if (ipok) st16(erow + (ch0 + g * EP) * (int)sizeof(ET), pack16<ET>(v));
+                }
             }
         }
     };
