@@ -206,7 +206,11 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
                 for (int g = 0; g < 8 / EP; ++g) {
                     float v[EP];
 #pragma unroll
-                    for (int e = 0; e < EP; ++e) v[e] = swish_f(a[g * EP + e]);
+                    for (int e = 0; e < EP; e += 2) {
+                        f32x2 x2; x2.x = a[g * EP + e]; x2.y = a[g * EP + e + 1];
+                        const f32x2 y2 = swish2(x2);
+                        v[e] = y2.x; v[e + 1] = y2.y;
+                    }
                     if (ipok) st16(erow + (ch0 + g * EP) * (int)sizeof(ET), pack16<ET>(v));
                 }
             } else {
@@ -215,7 +219,11 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
                 for (int g = 0; g < 16 / EP; ++g) {
                     float v[EP];
 #pragma unroll
-                    for (int e = 0; e < EP; ++e) v[e] = swish_f(a[g * EP + e]);
+                    for (int e = 0; e < EP; e += 2) {
+                        f32x2 x2; x2.x = a[g * EP + e]; x2.y = a[g * EP + e + 1];
+                        const f32x2 y2 = swish2(x2);
+                        v[e] = y2.x; v[e + 1] = y2.y;
+                    }
                     if (ipok) st16(erow + (ch0 + g * EP) * (int)sizeof(ET), pack16<ET>(v));
                 }
             }
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
             for (int i = 0; i < NBO; ++i)
                 wpc[i] = ld16((const char*)p.wproj + ((((size_t)i * nq + q) * HALF + j) * 64 + lane) * 16);
             const int c = h * HALF + j;                               // project k-chunk: P hidden channels
-            float d[P];
+            f32x2 d2[P / 2];
             const char* eb = E + e_pix + c * (P * (int)sizeof(ET));
             const char* wdb = wdq + c * (P * 4);
 #pragma unroll
@@ -261,16 +269,15 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
                     const char* wt = wdb + (ky * KS + kx) * HC * 4;
 #pragma unroll
                     for (int g = 0; g < P / 4; ++g) unpack16<float>(ld16(wt + g * 16), wv + g * 4);
-                    if (ky == 0 && kx == 0) {
 #pragma unroll
-                        for (int e = 0; e < P; ++e) d[e] = ev[e] * wv[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
+                    for (int e = 0; e < P / 2; ++e) {
+                        f32x2 e2, w2; e2.x = ev[2 * e]; e2.y = ev[2 * e + 1]; w2.x = wv[2 * e]; w2.y = wv[2 * e + 1];
+                        d2[e] = (ky == 0 && kx == 0) ? e2 * w2 : fma2(e2, w2, d2[e]);   // v_pk_mul / v_pk_fma
                     }
                 }
+            float d[P];
 #pragma unroll
-            for (int e = 0; e < P; ++e) d[e] = swish_f(d[e]);
+            for (int e = 0; e < P / 2; ++e) { const f32x2 y2 = swish2(d2[e]); d[2 * e] = y2.x; d[2 * e + 1] = y2.y; }
             const u32x4 xc = pack16<T>(d);
 #pragma unroll
             for (int i = 0; i < NBO; ++i) MbMma<T>::run(acc[i], wpc[i], xc);
