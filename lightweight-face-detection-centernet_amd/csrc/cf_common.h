@@ -44,6 +44,20 @@ __device__ __forceinline__ f32x2 swish2(f32x2 x) {
     return x * r;                                                 // v_pk_mul_f32
 }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// activation over a small register array, two lanes' worth per packed instruction (N even)
+template <int ACT, int N> __device__ __forceinline__ void act_arr(float* v) {
+    if constexpr (ACT == 1) {
+#pragma unroll
+        for (int e = 0; e < N; e += 2) {
+            f32x2 x2; x2.x = v[e]; x2.y = v[e + 1];
+            const f32x2 y2 = swish2(x2);
+            v[e] = y2.x; v[e + 1] = y2.y;
+        }
+    } else if constexpr (ACT == 2) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = relu_f(v[e]);
+    }
+}
 template <int ACT> __device__ __forceinline__ float act_f(float x) {
     if constexpr (ACT == 1) return swish_f(x);
     else if constexpr (ACT == 2) return relu_f(x);

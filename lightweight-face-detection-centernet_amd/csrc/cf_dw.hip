@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void dw_kernel(DwParams p) {
             if (yo < p.Ho) {
                 float o[VEC];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) o[e] = act_f<ACT>(acc[t][e] + breg[e]);
+                for (int e = 0; e < VEC; ++e) o[e] = acc[t][e] + breg[e];
+                act_arr<ACT, VEC>(o);
                 VecIO<T, VEC>::store(yout + (size_t)yo * p.Wo * p.C, o);
             }
         }
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(DwParams p, DwLdsGeom g) {
             }
         const int ch = c0 + cg * P;
 #pragma unroll
-        for (int e = 0; e < P; ++e) d[e] = act_f<ACT>(d[e] + (BIAS ? p.bias[ch + e] : 0.0f));
+        for (int e = 0; e < P; ++e) d[e] = d[e] + (BIAS ? p.bias[ch + e] : 0.0f);
+        act_arr<ACT, P>(d);
         u32x4* dstp = reinterpret_cast<u32x4*>((char*)p.y + ((((size_t)b * p.Ho + gy) * p.Wo + gx) * p.C + ch) * sizeof(T));
         if (g.nt & 2) __builtin_nontemporal_store(pack16<T>(d), dstp);
         else *dstp = pack16<T>(d);

@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
             for (int e = 0; e < P; ++e) {
                 float t = acc[i][g * P + e];
                 if constexpr (BIAS) t += p.bias[ch + e];
-                v[e] = act_f<ACT>(t);
+                v[e] = t;
             }
+            act_arr<ACT, P>(v);
             if constexpr (RES == 1) {
                 float r[P];
                 unpack16<T>(ld16((const char*)p.res + ((size_t)m * p.N + ch) * sizeof(T)), r);
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
             if (ch >= p.N) break;
             float v[P];
 #pragma unroll
-            for (int e = 0; e < P; ++e) v[e] = act_f<ACT>(acc[i][g * P + e]);
+            for (int e = 0; e < P; ++e) v[e] = acc[i][g * P + e];
+            act_arr<ACT, P>(v);
             if constexpr (RES == 1) {
                 float r[P];
                 unpack16<T>(ld16((const char*)p.res + ((size_t)m * p.N + ch) * sizeof(T)), r);

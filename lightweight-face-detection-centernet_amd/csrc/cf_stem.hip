@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p) {
     for (int g = 0; g < 16 / P; ++g) {
         float o[P];
 #pragma unroll
-        for (int e = 0; e < P; ++e) o[e] = swish_f(acc[g * P + e]);
+        for (int e = 0; e < P; ++e) o[e] = acc[g * P + e];
+        act_arr<1, P>(o);
         st16(out + g * P, pack16<T>(o));
     }
 }

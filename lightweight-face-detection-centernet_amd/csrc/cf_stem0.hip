@@ -200,7 +200,8 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
             for (int g = 0; g < 16 / P; ++g) {
                 float v[P];
 #pragma unroll
-                for (int e = 0; e < P; ++e) v[e] = inmap ? swish_f(a[g * P + e]) : 0.0f;
+                for (int e = 0; e < P; ++e) v[e] = inmap ? a[g * P + e] : 0.0f;     // swish(0) = 0
+                act_arr<1, P>(v);
                 st16(erow + g * 16, pack16<T>(v));
             }
         }
@@ -232,8 +233,7 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
             }
-#pragma unroll
-        for (int e = 0; e < P; ++e) d[e] = swish_f(d[e]);
+        act_arr<1, P>(d);
         S0Mma<T>::run(acc, ld16((const char*)p.wproj + ((size_t)j * 64 + lane) * 16), pack16<T>(d));
     }
     const int gy = oy0 + oy, gx = ox0 + ox;
