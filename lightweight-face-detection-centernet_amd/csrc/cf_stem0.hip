@@ -103,24 +103,28 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
 
     // ---- stage the normalised image patch: patch row r, element e = col*3 + ci
     const int iy0 = 2 * (oy0 - 1), ix0 = 2 * (ox0 - 1);
-    constexpr int NSTAGE = S0_PH * (S0_PW * 3);                   // 37 x 111 = 4107 elements
-    constexpr int NIT = (NSTAGE + S0_NT - 1) / S0_NT;
+    // Thread t owns one element column e = col*3 + ci of the patch (fixed for the whole loop) and walks
+    // down the rows with stride RSTEP: every per-element quantity except the row is loop-invariant, so
+    // the loop body is a load, a compare/select, a table read and an LDS store -- no index division.
+    constexpr int ECOLS = S0_PW * 3;                              // 111 elements per patch row
+    constexpr int RSTEP = S0_NT / ECOLS;                          // 4 rows per pass (68 lanes idle)
+    constexpr int NIT = (S0_PH + RSTEP - 1) / RSTEP;              // 10 passes over the 37 rows
     {
-        // all loads of the patch are issued before any is consumed (one memory latency per tile)
+        const int e = tid % ECOLS, r0 = tid / ECOLS;
+        const bool tact = r0 < RSTEP;
+        const int col = e / 3, ci = e - col * 3;
+        const int ix = ix0 + col;
+        const bool xok = tact && (unsigned)ix < (unsigned)p.W;
+        const int cx = min(max(ix, 0), p.W - 1);
+        // all loads of the patch are issued before any is consumed (one memory latency per tile);
+        // branch-free: loads come from a clamped (valid) address and are discarded when outside
         float v[NIT];
-        int dst[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * S0_NT;
-            const int r = i / (S0_PW * 3), e = i - r * (S0_PW * 3);
-            const int col = e / 3, ci = e - col * 3;
-            const int iy = iy0 + r, ix = ix0 + col;
-            dst[it] = i < NSTAGE ? r * S0_PROW + e : -1;
-            // branch-free: the load is always issued from a clamped (valid) address and the result is
-            // discarded when the element lies outside the image -- predicated loads would each sit in
-            // their own exec-masked block with a full vmcnt(0) wait (9 serialised HBM round trips)
-            const bool ok = i < NSTAGE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+            const int r = r0 + it * RSTEP;
+            const int iy = iy0 + r;
+            const bool ok = xok && r < S0_PH && (unsigned)iy < (unsigned)p.H;
+            const int cy = min(max(iy, 0), p.H - 1);
             if constexpr (FMT == CF_IN_U8_HWC_BGR) {
                 const uint32_t u = ((const uint8_t*)p.x)[(((size_t)b * p.H + cy) * p.W + cx) * 3 + ci];
                 v[it] = __uint_as_float(ok ? (u | (uint32_t)(ci << 8)) : 0xffffffffu);   // table index | "outside"
@@ -137,14 +141,15 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
         if constexpr (FMT == CF_IN_U8_HWC_BGR) __syncthreads();      // table is in LDS
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
+            const int r = r0 + it * RSTEP;
             float val = v[it];
             if constexpr (FMT == CF_IN_U8_HWC_BGR) {
                 const uint32_t idx = __float_as_uint(v[it]);
                 val = idx == 0xffffffffu ? 0.0f : lut[idx];
             }
-            if (dst[it] >= 0) {
-                if constexpr (F32) Xs[dst[it]] = val;
-                else Xs[dst[it]] = (T)(pack_bf16x2(val, 0.0f) & 0xffffu);
+            if (tact && r < S0_PH) {
+                if constexpr (F32) Xs[r * S0_PROW + e] = val;
+                else Xs[r * S0_PROW + e] = (T)(pack_bf16x2(val, 0.0f) & 0xffffu);
             }
         }
     }
@@ -218,9 +223,7 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
 #pragma unroll
     for (int j = 0; j < HALF; ++j) {
         const int c = h * HALF + j;
-        float d[P];
-#pragma unroll
-        for (int e = 0; e < P; ++e) d[e] = 0.0f;
+        f32x2 d2[P / 2];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -231,9 +234,14 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
                 unpack16<float>(ld16(wt), wv);
                 if constexpr (P == 8) unpack16<float>(ld16(wt + 16), wv + 4);
 #pragma unroll
-                for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
+                for (int e = 0; e < P / 2; ++e) {
+                    f32x2 e2, w2; e2.x = ev[2 * e]; e2.y = ev[2 * e + 1]; w2.x = wv[2 * e]; w2.y = wv[2 * e + 1];
+                    d2[e] = (ky == 0 && kx == 0) ? e2 * w2 : fma2(e2, w2, d2[e]);
+                }
             }
-        act_arr<1, P>(d);
+        float d[P];
+#pragma unroll
+        for (int e = 0; e < P / 2; ++e) { const f32x2 y2 = swish2(d2[e]); d[2 * e] = y2.x; d[2 * e + 1] = y2.y; }
         S0Mma<T>::run(acc, ld16((const char*)p.wproj + ((size_t)j * 64 + lane) * 16), pack16<T>(d));
     }
     const int gy = oy0 + oy, gx = ox0 + ox;
