@@ -453,6 +453,51 @@ def test_full_size_640_fp32_vs_oracle_topk():
     eng.close()
 
 
+def test_vga_480x640_fp32_vs_oracle():
+    """BASELINE config 4 geometry (VGA, non-square, multiples of 32): heads + D3 decode vs the oracle."""
+    rng = np.random.default_rng(44)
+    img = rng.integers(0, 256, (2, 480, 640, 3), dtype=np.uint8)
+    sd = cfa.weights.synthetic_state_dict(0)
+    eng = cfa.Engine(480, 640, max_batch=2, dtype="fp32", weights=sd)
+    eng.forward_enqueue(img)
+    got = eng.heads(sigmoid_hm=True)
+    ref = O.forward(O.to_torch_sd(sd), torch.from_numpy(np.concatenate([O.preprocess(im) for im in img])))
+    for k in ("hm", "wh", "lm", "reg"):
+        assert got[k].shape == tuple(ref[k].shape) == (2, {"hm": 1, "wh": 2, "lm": 10, "reg": 2}[k], 120, 160)
+        np.testing.assert_allclose(got[k], ref[k].numpy(), rtol=1e-3, atol=1e-3, err_msg=k)
+    dets, lms, inds = eng.decode_topk(K=100)
+    odet, olms, oinds = O.ctdet_decode(got["hm_sigmoid"], got["wh"], got["reg"], 100, got["lm"])
+    assert np.array_equal(inds, oinds) and np.array_equal(dets, odet) and np.array_equal(lms, olms)
+    eng.close()
+
+
+def test_crowd_1280_topk1000():
+    """BASELINE config 5 geometry: 1280x1280, heat map 320x320, K = 1000.  fp32 heads vs the oracle on one
+    image; bf16 batch: decode of our heads bit-exact vs the oracle decode, sorted, deterministic."""
+    rng = np.random.default_rng(45)
+    sd = cfa.weights.synthetic_state_dict(0)
+    img = rng.integers(0, 256, (1, 1280, 1280, 3), dtype=np.uint8)
+    eng = cfa.Engine(1280, 1280, max_batch=1, dtype="fp32", weights=sd)
+    eng.forward_enqueue(img)
+    got = eng.heads(sigmoid_hm=True)
+    ref = O.forward(O.to_torch_sd(sd), torch.from_numpy(O.preprocess(img[0])))
+    for k in ("hm", "wh", "lm", "reg"):
+        np.testing.assert_allclose(got[k], ref[k].numpy(), rtol=1e-3, atol=1e-3, err_msg=k)
+    dets, lms, inds = eng.decode_topk(K=1000)
+    odet, olms, oinds = O.ctdet_decode(got["hm_sigmoid"], got["wh"], got["reg"], 1000, got["lm"])
+    assert np.array_equal(inds, oinds) and np.array_equal(dets, odet) and np.array_equal(lms, olms)
+    eng.close()
+    imgs = rng.integers(0, 256, (4, 1280, 1280, 3), dtype=np.uint8)
+    eng = cfa.Engine(1280, 1280, max_batch=4, dtype="bf16", weights=sd)
+    eng.forward_enqueue(imgs)
+    d1, l1, i1 = eng.decode_topk(K=1000)
+    hd = eng.heads(sigmoid_hm=True)
+    od, ol, oi = O.ctdet_decode(hd["hm_sigmoid"], hd["wh"], hd["reg"], 1000, hd["lm"])
+    assert np.array_equal(i1, oi) and np.array_equal(d1, od)
+    assert (np.diff(d1[..., 4], axis=1) <= 0).all() and i1.max() < 320 * 320
+    eng.close()
+
+
 def test_batch64_bf16_properties():
     """BASELINE config 2 at full size (B=64, 640x640, bf16): size-independent properties --
     batch-slot independence, run-to-run determinism, decode sortedness and index validity."""
