@@ -61,6 +61,9 @@ struct cf_ctx {
     int device = 0, max_batch = 0, H = 0, W = 0, dtype = 0;
     uint32_t flags = 0;
     hipStream_t stream = nullptr;
+    // device-output top-K decode runs on a second stream so that it overlaps the NEXT forward (it
+    // occupies 64 workgroups of a 256-CU chip); the head kernel of that forward waits for it
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fwd = nullptr, ev_dec = nullptr; bool dec_pending = false;
     std::vector<Buf> bufs;
     std::vector<Op> ops;
     std::vector<void*> owned;                 // device allocations to free
@@ -302,6 +305,9 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
         return code;
     };
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_fwd, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_dec, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
     for (auto& ev : c->events) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
     build_plan(c);
     // input staging: the larger of u8 HWC and f32 NCHW
@@ -323,6 +329,9 @@ int cf_destroy(cf_ctx* c) {
     if (!c) return CF_OK;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+    if (c->ev_fwd) hipEventDestroy(c->ev_fwd);
+    if (c->ev_dec) hipEventDestroy(c->ev_dec);
     for (auto& b : c->bufs) if (b.p) hipFree(b.p);
     for (void* p : c->owned) hipFree(p);
     for (void* p : {(void*)c->src_stage, (void*)c->d_trans, (void*)c->hm_plane, (void*)c->keys, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
@@ -583,13 +592,26 @@ int ensure_topk_ws(cf_ctx* c, int K) {
     return CF_OK;
 }
 
-int enqueue_topk(cf_ctx* c, int B, int K, int use_reg, float* dets, float* lms, long long* inds, const double* trans = nullptr) {
+int enqueue_topk(cf_ctx* c, int B, int K, int use_reg, float* dets, float* lms, long long* inds, const double* trans = nullptr,
+                 hipStream_t on = nullptr) {
     TopkParams p{};
     p.trans = trans;
     p.heads = (const float*)c->bufs[c->buf_heads].p; p.hm_plane = c->hm_plane; p.scratch = c->keys;
     p.B = B; p.h = c->H / 4; p.w = c->W / 4; p.K = K; p.use_reg = use_reg;
     p.dets = dets; p.lms = lms; p.inds = inds;
-    HIPCHK(c, launch_peak_topk(c->stream, p));
+    HIPCHK(c, launch_peak_topk(on ? on : c->stream, p));
+    return CF_OK;
+}
+
+int launch_all_ops(cf_ctx* c, const void* net_in, int in_format, int B) {
+    for (auto& op : c->ops) {
+        if (op.kind == OP_HEAD && c->dec_pending) {       // the overlapped decode still reads heads / hm_plane
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dec, 0));
+            c->dec_pending = false;
+        }
+        HIPCHK(c, launch_op(c, op, net_in, in_format, B));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_fwd, c->stream));
     return CF_OK;
 }
 
@@ -602,7 +624,8 @@ int cf_forward(cf_ctx* c, const void* in, int in_format, int in_on_device, int B
     const void* net_in = nullptr;
     int r = stage_input(c, in, in_format, in_on_device, B, &net_in);
     if (r) return r;
-    for (auto& op : c->ops) HIPCHK(c, launch_op(c, op, net_in, in_format, B));
+    r = launch_all_ops(c, net_in, in_format, B);
+    if (r) return r;
     c->last_B = B;
     return CF_OK;
 }
@@ -626,7 +649,8 @@ int cf_forward_resized(cf_ctx* c, const void* imgs, int in_on_device, int B, int
     }
     uint8_t* dst = (uint8_t*)c->bufs[c->buf_in].p;
     HIPCHK(c, launch_resize_u8(c->stream, src, dst, B, h, w, c->H, c->W));
-    for (auto& op : c->ops) HIPCHK(c, launch_op(c, op, dst, CF_IN_U8_HWC_BGR, B));
+    int r = launch_all_ops(c, dst, CF_IN_U8_HWC_BGR, B);
+    if (r) return r;
     c->last_B = B;
     return CF_OK;
 }
@@ -641,6 +665,7 @@ int cf_get_resized_input(cf_ctx* c, void* out_u8, int B) {
 int cf_synchronize(cf_ctx* c) {
     if (!c) return CF_EINVAL;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
     return CF_OK;
 }
 
@@ -671,7 +696,16 @@ int cf_decode_topk(cf_ctx* c, int K, int use_reg, float* dets, float* lms, int64
     if (K < 1 || K > 1024 || K > HW) return c->fail(CF_EINVAL, "K=%d must be in [1, min(1024, %d)]", K, HW);
     HIPCHK(c, hipSetDevice(c->device));
     int r = ensure_topk_ws(c, K); if (r) return r;
-    if (out_on_device) return enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds);
+    if (out_on_device) {
+        static const bool overlap = !(getenv("CF_DECODE_OVERLAP") && atoi(getenv("CF_DECODE_OVERLAP")) == 0);
+        if (!overlap) return enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds);
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
+        r = enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds, nullptr, c->stream2);
+        if (r) return r;
+        HIPCHK(c, hipEventRecord(c->ev_dec, c->stream2));
+        c->dec_pending = true;
+        return CF_OK;
+    }
     r = enqueue_topk(c, B, K, use_reg, c->d_dets, lms ? c->d_lms : nullptr, inds ? c->d_inds : nullptr);
     if (r) return r;
     HIPCHK(c, hipMemcpyAsync(dets, c->d_dets, (size_t)B * K * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -498,6 +498,31 @@ def test_crowd_1280_topk1000():
     eng.close()
 
 
+def test_device_output_decode_overlapped_stream():
+    """cf_decode_topk with device destinations runs on the ctx's second stream (overlapping the next
+    forward); results must equal the synchronous host-output path, run after run."""
+    rng = np.random.default_rng(77)
+    B, K = 4, 50
+    eng = cfa.Engine(128, 160, max_batch=B, dtype="bf16")
+    imgs = [rng.integers(0, 256, (B, 128, 160, 3), dtype=np.uint8) for _ in range(3)]
+    d_dets = eng.device_alloc(B * K * 6 * 4); d_lms = eng.device_alloc(B * K * 10 * 4); d_inds = eng.device_alloc(B * K * 8)
+    import ctypes
+    outs = []
+    for x in imgs + imgs:                      # back-to-back enqueues, no host sync in between
+        eng.forward_enqueue(x)
+        eng.decode_topk_device(K, d_dets, d_lms, d_inds)
+    eng.synchronize()
+    dets = np.empty((B, K, 6), np.float32); inds = np.empty((B, K), np.int64)
+    eng._chk(eng._L.cf_memcpy_d2h(eng._h, cfa._lib.ptr(dets), ctypes.c_void_p(d_dets), dets.nbytes))
+    eng._chk(eng._L.cf_memcpy_d2h(eng._h, cfa._lib.ptr(inds), ctypes.c_void_p(d_inds), inds.nbytes))
+    eng.forward_enqueue(imgs[-1])
+    hd, _, hi = eng.decode_topk(K)
+    assert np.array_equal(inds, hi) and np.array_equal(dets, hd)
+    for p_ in (d_dets, d_lms, d_inds):
+        eng.device_free(p_)
+    eng.close()
+
+
 def test_batch64_bf16_properties():
     """BASELINE config 2 at full size (B=64, 640x640, bf16): size-independent properties --
     batch-slot independence, run-to-run determinism, decode sortedness and index validity."""
