@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--profile-reps", type=int, default=5)
-    ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic_r01.json"),
-                    help="per-kernel HBM bytes from rocprofv3 PMC passes (tools/summarize_pmc.py), optional")
+    ap.add_argument("--traffic-json", default=None,
+                    help="per-kernel HBM bytes from rocprofv3 PMC passes (tools/summarize_prof.py); "
+                         "default: the newest profiles/traffic_*.json")
     return ap.parse_args()
 
 
@@ -171,7 +172,9 @@ def main():
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         try:
-            with open(args.traffic_json) as f:
+            import glob
+            tj = args.traffic_json or sorted(glob.glob(os.path.join(REPO, "profiles", "traffic_*.json")))[-1]
+            with open(tj) as f:
                 traffic = json.load(f).get(dom_name, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None

@@ -269,6 +269,13 @@ static hipError_t dw_lds_by_shape(hipStream_t s, const DwParams& p) {
         if (p.k == 5 && p.s == 1) return dw_lds_dispatch<T, 5, 1, 8, 32>(s, p);
         if (p.k == 5 && p.s == 2) return dw_lds_dispatch<T, 5, 2, 4, 32>(s, p);
     }
+    // small late maps (20x20 at 640x640 input): one tile = the whole map (no spatial padding waste)
+    if (p.Ho <= 20 && p.Wo <= 20 && p.Ho > 8) {
+        if (p.k == 3 && p.s == 1) return dw_lds_dispatch<T, 3, 1, 20, 20>(s, p);
+        if (p.k == 5 && p.s == 1) return dw_lds_dispatch<T, 5, 1, 20, 20>(s, p);
+        if (p.k == 3 && p.s == 2) return dw_lds_dispatch<T, 3, 2, 10, 20>(s, p);
+        // 5x5 stride 2: the 43-wide halo tile forces a 24-channel chunk; 4x32 tiles measured faster
+    }
     // measured on MI355X, B=64 (profiles/r01_dw_variants.md): wide tiles for the big early maps
     // (less halo per byte), smaller ones where the channel chunk would otherwise drop below a pixel
     if (p.k == 3 && p.s == 1) return p.C <= 32 ? dw_lds_dispatch<T, 3, 1, 16, 16>(s, p) : dw_lds_dispatch<T, 3, 1, 8, 16>(s, p);
