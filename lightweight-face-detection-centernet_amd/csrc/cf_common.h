@@ -32,9 +32,10 @@ __device__ __forceinline__ float swish_f(float x) {
 }
 __device__ __forceinline__ float relu_f(float x) { return fmaxf(x, 0.0f); }
 
-// Packed fp32 math: a wave64 VALU instruction costs ~4 cycles on a CDNA4 SIMD whether it carries one
-// or two fp32 lanes' worth of work, so v_pk_mul/add/fma_f32 on register pairs halve the issue cost of
-// the simple ops.  Swish on a pair: 3 packed ops + 2x(v_exp, v_rcp) instead of 2 x 5 scalar ops.
+// Packed fp32 math on register pairs (v_pk_mul/add/fma_f32).  Measured (profiles/r01_valu_microbench.md):
+// v_pk_fma_f32 issues in 5.65 cycles vs 2.88 for v_fma_f32, i.e. the same per-element rate -- what it
+// buys is fewer instructions to fetch/issue (5-12 % on the fused kernels).  The cost that matters in
+// Swish is the two transcendentals (v_exp_f32, v_rcp_f32: 9.45 cycles each).
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ f32x2 swish2(f32x2 x) {
     const f32x2 t = x * -1.44269504088896341f;                    // v_pk_mul_f32: -x * log2(e)
