@@ -1,0 +1,32 @@
+#!/bin/bash
+# One-shot evidence capture on the GPU box:  gpurun --timeout 1500 -- 'bash tools/capture_profile.sh r01d'
+# then, back in the container:                python tools/summarize_prof.py --tag r01d --stats ... (printed below)
+# Counter passes are separate rocprofv3 runs with --kernel-trace only (no sys/hip/hsa tracing).
+set -u
+TAG=${1:-r01x}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd "$ROOT"
+if [ "${SKIP_TESTS:-0}" != 1 ]; then
+    timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
+    tail -3 "$OUT/pytest_gpu.log"
+fi
+timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 600 "$OUT/bench.json"
+timeout 300 python tools/profile_ops.py --json "$OUT/ops.json" > "$OUT/ops.txt" 2>&1
+timeout 300 python tools/profile_ops.py --dtype fp32 --batch 16 > "$OUT/ops_fp32_b16.txt" 2>&1
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k" -o k -- \
+    python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/prof_k.log" 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch" -o f -- \
+    python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_fetch.log" 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/prof_write" -o w -- \
+    python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_write.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM \
+    --kernel-trace --output-format csv -d "$OUT/prof_sq" -o s -- \
+    python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_sq.log" 2>&1
+find "$OUT" -name '*.csv' | head -20
+# keep the merge-back under 64 MiB: drop per-dispatch traces, keep stats + counters
+find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
+du -sh "$OUT"
