@@ -150,6 +150,9 @@ typedef struct cf_op_time {
 } cf_op_time;
 int cf_profile_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int K,
                        cf_op_time* out, int cap, int* n_out);
+/* hipGraph replay state: number of captured forward graphs held by the context, and how many
+ * (input, format, batch) keys could not be captured and run as eager launches instead. */
+int cf_graph_stats(cf_ctx* ctx, int* n_graphs, int* n_uncapturable);
 /* device memory helpers so a host language without a GPU allocator can keep inputs resident */
 int cf_device_alloc(cf_ctx* ctx, uint64_t bytes, void** dptr);
 int cf_device_free(cf_ctx* ctx, void* dptr);

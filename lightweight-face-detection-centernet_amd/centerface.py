@@ -27,7 +27,7 @@ class Engine(object):
     """One cf_ctx: one GPU, one stream, fixed (H, W), batch up to ``max_batch``."""
 
     def __init__(self, height, width, max_batch=1, dtype="fp32", device=0, weights=None,
-                 collapse_heads=None, fuse=True):
+                 collapse_heads=None, fuse=True, graph=True):
         L = _lib.lib()
         if dtype not in _DTYPES:
             raise ValueError("dtype must be one of %s" % sorted(_DTYPES))
@@ -39,7 +39,8 @@ class Engine(object):
             # into one 3x3 24->15 conv is exact algebra; default on in the throughput mode, off in
             # the fp32 parity mode so that mode keeps the reference's operation order
             collapse_heads = (dtype not in ("fp32", "float32", "f32"))
-        flags = (_lib.CF_FLAG_COLLAPSE_HEADS if collapse_heads else 0) | (0 if fuse else _lib.CF_FLAG_NO_FUSE)
+        flags = ((_lib.CF_FLAG_COLLAPSE_HEADS if collapse_heads else 0) | (0 if fuse else _lib.CF_FLAG_NO_FUSE)
+                 | (0 if graph else _lib.CF_FLAG_NO_GRAPH))
         handle = C.c_void_p()
         _lib.check(L.cf_create(self.device, self.max_batch, self.H, self.W, _DTYPES[dtype], flags, C.byref(handle)))
         self._h = handle
@@ -203,6 +204,12 @@ class Engine(object):
         self.last_B = int(B)
         return [dict(name=r.name.decode(), kind=r.kind.decode(), kernel=r.kernel.decode(), ms=r.ms, algo_bytes=r.algo_bytes, flops=r.flops)
                 for r in rec[:n.value]]
+
+    def graph_stats(self):
+        """(captured forward graphs, keys that fell back to eager launches)."""
+        a, b = C.c_int(), C.c_int()
+        self._chk(self._L.cf_graph_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def device_alloc(self, nbytes):
         p = C.c_void_p()

@@ -78,6 +78,11 @@ struct cf_ctx {
     float* t_cand = nullptr; int* t_count = nullptr; int* t_order = nullptr; unsigned long long* t_mask = nullptr;
     float* t_dets = nullptr; float* t_lms = nullptr; int* t_counts = nullptr; int* t_overflow = nullptr;
     int t_cap = 0, t_maxout = 0;
+    // hipGraph replay of the backbone + neck launches, one executable graph per (input pointer,
+    // input format, batch): the second forward with a key captures it, later ones replay it
+    struct FwdGraph { const void* in; int fmt, B; hipGraphExec_t exec; bool broken; unsigned long long used; };
+    std::vector<FwdGraph> graphs;
+    unsigned long long graph_clock = 0;
 
     int fail(int code, const char* fmt, ...) {
         char b[512];
@@ -338,6 +343,7 @@ int cf_destroy(cf_ctx* c) {
                     (void*)c->t_order, (void*)c->t_mask, (void*)c->t_dets, (void*)c->t_lms, (void*)c->t_counts, (void*)c->t_overflow})
         if (p) hipFree(p);
     for (auto& ev : c->events) if (ev) hipEventDestroy(ev);
+    for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return CF_OK;
@@ -603,12 +609,52 @@ int enqueue_topk(cf_ctx* c, int B, int K, int use_reg, float* dets, float* lms, 
     return CF_OK;
 }
 
+// Everything in front of the head kernel as one executable graph (the head kernel stays an eager
+// launch: it may have to wait for an overlapped decode of the previous batch, a dependency on work
+// outside the capture).  Returns nullptr when this key has not been seen twice yet or cannot be captured.
+hipGraphExec_t forward_graph(cf_ctx* c, const void* net_in, int in_format, int B) {
+    constexpr size_t kMaxGraphs = 16;
+    cf_ctx::FwdGraph* g = nullptr;
+    for (auto& e : c->graphs) if (e.in == net_in && e.fmt == in_format && e.B == B) g = &e;
+    if (!g) {
+        if (c->graphs.size() >= kMaxGraphs) {                         // evict the least recently used
+            size_t lru = 0;
+            for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i].used < c->graphs[lru].used) lru = i;
+            if (c->graphs[lru].exec) hipGraphExecDestroy(c->graphs[lru].exec);
+            c->graphs.erase(c->graphs.begin() + lru);
+        }
+        c->graphs.push_back({net_in, in_format, B, nullptr, false, ++c->graph_clock});
+        return nullptr;                                               // first sighting: eager (also does the one-time kernel attribute setup)
+    }
+    g->used = ++c->graph_clock;
+    if (g->exec || g->broken) return g->exec;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g->broken = true; return nullptr; }
+    hipError_t e = hipSuccess;
+    for (auto& op : c->ops) {
+        if (op.kind == OP_HEAD) break;
+        if ((e = launch_op(c, op, net_in, in_format, B)) != hipSuccess) break;
+    }
+    hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+    if (e == hipSuccess && e2 == hipSuccess && graph && hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        hipGraphDestroy(graph);
+        return g->exec;
+    }
+    if (graph) hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    g->exec = nullptr; g->broken = true;
+    return nullptr;
+}
+
 int launch_all_ops(cf_ctx* c, const void* net_in, int in_format, int B) {
+    hipGraphExec_t exec = (c->flags & CF_FLAG_NO_GRAPH) ? nullptr : forward_graph(c, net_in, in_format, B);
+    if (exec) HIPCHK(c, hipGraphLaunch(exec, c->stream));
     for (auto& op : c->ops) {
         if (op.kind == OP_HEAD && c->dec_pending) {       // the overlapped decode still reads heads / hm_plane
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dec, 0));
             c->dec_pending = false;
         }
+        if (exec && op.kind != OP_HEAD) continue;
         HIPCHK(c, launch_op(c, op, net_in, in_format, B));
     }
     HIPCHK(c, hipEventRecord(c->ev_fwd, c->stream));
@@ -867,6 +913,15 @@ int cf_profile_forward(cf_ctx* c, const void* in, int in_format, int in_on_devic
     }
     for (auto& e : ev) hipEventDestroy(e);
     *n_out = i;
+    return CF_OK;
+}
+
+int cf_graph_stats(cf_ctx* c, int* n_graphs, int* n_uncapturable) {
+    if (!c) return CF_EINVAL;
+    int ng = 0, nb = 0;
+    for (auto& g : c->graphs) { ng += g.exec != nullptr; nb += g.broken; }
+    if (n_graphs) *n_graphs = ng;
+    if (n_uncapturable) *n_uncapturable = nb;
     return CF_OK;
 }
 
