@@ -23,6 +23,7 @@
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace cf {
 
@@ -284,32 +285,34 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
         }
     }
 
-    // ---- combine the two k-groups: the upper group hands its partial sums over through LDS
+    // ---- combine the two k-groups: the upper group hands its partial sums over through LDS, one
+    // output n-block at a time (the buffer stays smaller than the E tile it reuses)
     if constexpr (KG == 2) {
-        __syncthreads();                                  // everyone is done with E and the stages
-        float* red = reinterpret_cast<float*>(smem) + (size_t)(pbk * 64 + lane) * (NBO * 16);
-        if (jg == 1) {
+        float* red = reinterpret_cast<float*>(smem) + (size_t)(pbk * 64 + lane) * 16;
 #pragma unroll
-            for (int i = 0; i < NBO; ++i)
+        for (int i = 0; i < NBO; ++i) {
+            __syncthreads();                              // everyone is done with E / the previous n-block
+            if (jg == 1) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float t[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) t[e] = acc[i][g * 4 + e];
-                    st16(red + i * 16 + g * 4, pack16<float>(t));
+                    st16(red + g * 4, pack16<float>(t));
                 }
-        }
-        __syncthreads();
-        if (jg == 1) return;
-#pragma unroll
-        for (int i = 0; i < NBO; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float t[4];
-                unpack16<float>(ld16(red + i * 16 + g * 4), t);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][g * 4 + e] += t[e];
             }
+            __syncthreads();
+            if (jg == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float t[4];
+                    unpack16<float>(ld16(red + g * 4), t);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][g * 4 + e] += t[e];
+                }
+            }
+        }
+        if (jg == 1) return;
     }
 
     // ---- epilogue: (+ residual) -> y
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
 // (model/centernet.py:211-219, layer1.0 .. layer4.1) in one storage type.
 struct MbEntry {
     int dtype, k, s, jx, hc, nbo, res;
-    int toh, tow, ef, nw, lds_bytes;
+    int toh, tow, ef, nw, var, lds_bytes;     // var > 0: experimental variant, selected with CF_MB_VARIANT=var
     hipError_t (*fn)(hipStream_t, const MbParams&);
 };
 
@@ -361,28 +364,37 @@ static hipError_t mb_launch(hipStream_t s, const MbParams& p) {
     return hipGetLastError();
 }
 
-template <typename T, int KS, int S, int JX, int HC, int TOH, int TOW, bool EF>
+template <typename T, int KS, int S, int JX, int HC, int TOH, int TOW, bool EF, int NBO, int NW>
 constexpr int mb_lds_bytes() {
     constexpr int ES = EF ? 4 : (int)sizeof(T);
     constexpr int IPX = ((TOH - 1) * S + KS) * ((TOW - 1) * S + KS);
     constexpr int NBE = (HC + 31) / 32;
-    return (IPX * (HC * ES + 16) + 15) / 16 * 16 + 2 * (NBE * JX * 1024 + KS * KS * HC * 4);
+    constexpr int main_bytes = (IPX * (HC * ES + 16) + 15) / 16 * 16 + 2 * (NBE * JX * 1024 + KS * KS * HC * 4);
+    // KG == 2: the epilogue reuses the space for the k-group reduction, 64 lanes x 16 floats per pixel block
+    constexpr int NPB = TOH * TOW / 32;
+    constexpr int red_bytes = NW > NPB ? NPB * 64 * 16 * 4 : 0;
+    return main_bytes > red_bytes ? main_bytes : red_bytes;
 }
 
-#define MB_ENTRY(T, DT, KS, S, JX, HC, NBO, RES, TOH, TOW, EF, NW) \
-    {DT, KS, S, JX, HC, NBO, RES, TOH, TOW, EF, NW, mb_lds_bytes<T, KS, S, JX, HC, TOH, TOW, (EF != 0)>(), \
+#define MB_ENTRY(T, DT, KS, S, JX, HC, NBO, RES, TOH, TOW, EF, NW) MB_VARIANT(0, T, DT, KS, S, JX, HC, NBO, RES, TOH, TOW, EF, NW)
+#define MB_VARIANT(V, T, DT, KS, S, JX, HC, NBO, RES, TOH, TOW, EF, NW) \
+    {DT, KS, S, JX, HC, NBO, RES, TOH, TOW, EF, NW, V, mb_lds_bytes<T, KS, S, JX, HC, TOH, TOW, (EF != 0), NBO, NW>(), \
      &mb_launch<T, KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, (EF != 0)>}
 static const MbEntry kMbTable[] = {
     // bf16 storage: KS S JX HC NBO res | tile  E-fp32 waves        layer   (per-layer best of the
-    // measured variants: E as bf16 vs fp32, tile 8x16 vs 4x16, 4 vs 8 waves -- profiles/r01_mbconv_variants.md)
+    // measured variants: E as bf16 vs fp32, tile 8x16 / 4x16 / 16x16 / 8x20 / 8x32 / 8x40, 4-16 waves, HC --
+    // profiles/r01_mbconv_variants.md)
     MB_ENTRY(bf16_t, 1, 3, 2, 1, 32, 1, 0, 8, 16, 0, 4),   // 1.0  16 ->  96 -> 24
     MB_ENTRY(bf16_t, 1, 3, 1, 2, 48, 1, 1, 8, 16, 0, 4),   // 1.1  24 -> 144 -> 24 (+res)
     MB_ENTRY(bf16_t, 1, 5, 2, 2, 48, 1, 0, 8, 16, 0, 8),   // 2.0  24 -> 144 -> 32
-    MB_ENTRY(bf16_t, 1, 5, 1, 2, 96, 1, 1, 8, 16, 0, 8),   // 2.1  32 -> 192 -> 32 (+res)
+    MB_ENTRY(bf16_t, 1, 5, 1, 2, 48, 1, 1, 8, 16, 0, 8),   // 2.1  32 -> 192 -> 32 (+res)
     MB_ENTRY(bf16_t, 1, 3, 2, 2, 32, 2, 0, 8, 16, 0, 4),   // 3.0  32 -> 192 -> 64
     MB_ENTRY(bf16_t, 1, 3, 1, 4, 32, 2, 1, 8, 16, 1, 4),   // 3.1  64 -> 384 -> 64 (+res)
-    MB_ENTRY(bf16_t, 1, 5, 1, 4, 32, 3, 0, 8, 16, 1, 8),   // 4.0  64 -> 384 -> 96
-    MB_ENTRY(bf16_t, 1, 5, 1, 6, 32, 3, 1, 8, 16, 1, 8),   // 4.1  96 -> 576 -> 96 (+res)
+    MB_ENTRY(bf16_t, 1, 5, 1, 4, 32, 3, 0, 8, 20, 0, 10),  // 4.0  64 -> 384 -> 96      8x20 tiles: a 40x40 map
+    MB_ENTRY(bf16_t, 1, 5, 1, 6, 32, 3, 1, 8, 20, 0, 10),  // 4.1  96 -> 576 -> 96 (+res)   has no edge waste
+    // experimental variants (CF_MB_VARIANT=n), kept for A/B runs through tools/profile_ops.py
+    MB_VARIANT(1, bf16_t, 1, 3, 1, 4, 32, 2, 1, 8, 20, 0, 10),  // 3.1  8x20
+    MB_VARIANT(1, bf16_t, 1, 3, 2, 2, 32, 2, 0, 8, 20, 0, 5),   // 3.0  8x20
     // fp32 storage (parity mode)
     MB_ENTRY(float, 0, 3, 2, 2, 32, 1, 0, 8, 16, 1, 4),
     MB_ENTRY(float, 0, 3, 1, 3, 48, 1, 1, 8, 16, 1, 4),
@@ -396,9 +408,14 @@ static const MbEntry kMbTable[] = {
 #undef MB_ENTRY
 
 static const MbEntry* mb_find(int dtype, int k, int s, int jx, int nbo, int res) {
+    static const int want = getenv("CF_MB_VARIANT") ? atoi(getenv("CF_MB_VARIANT")) : 0;
+    const MbEntry* base = nullptr;
     for (const MbEntry& e : kMbTable)
-        if (e.dtype == dtype && e.k == k && e.s == s && e.jx == jx && e.nbo == nbo && e.res == res) return &e;
-    return nullptr;
+        if (e.dtype == dtype && e.k == k && e.s == s && e.jx == jx && e.nbo == nbo && e.res == res) {
+            if (e.var == want) return &e;
+            if (e.var == 0) base = &e;
+        }
+    return base;
 }
 
 MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
