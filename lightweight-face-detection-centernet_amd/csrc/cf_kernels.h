@@ -55,6 +55,7 @@ struct MbGeom {
     int HC, nq;           // hidden-channel chunk and number of chunks (hid = HC * nq)
     int NBE, JX, HALF, NBO, rowb;
     size_t lds_bytes, wexp_bytes, wdw_floats, wproj_bytes;
+    int kind, S;          // kind 0: cf_mbconv.hip, 1: cf_mbconv2.hip (fp16 pixel-pair tile, bf16 storage only)
 };
 MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s);
 void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int k,
@@ -68,9 +69,15 @@ struct MbParams {
     int k, s, pad_lo, residual;
     int HC, nq, NBE, JX, HALF, rowb;
     size_t lds_bytes;
-    int nw;               // 0 = auto, 4 = force 4-wave workgroups (A/B switch)
+    int nw;               // unused
+    int kind;             // MbGeom::kind
 };
 hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p);
+// cf_mbconv2.hip
+bool mb2_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s);
+void mb2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+                      void* wexp_host, float* wdw_host, void* wproj_host);
+hipError_t mb2_launch(hipStream_t s, const MbParams& p);
 
 // ------------------------------------------------------------------ stem 3x3 s2 3->32 + Swish
 struct StemParams {

@@ -1,0 +1,449 @@
+// Fused MBConv block, second generation (bf16 storage only): the same expand 1x1 (+Swish) ->
+// depthwise k x k (+Swish) -> project 1x1 (+residual) fusion as cf_mbconv.hip
+// (MBConvBlock.forward, model/centernet.py:89-140), restructured around what the VALU
+// microbenchmarks (profiles/r01_valu_microbench.md) say the depthwise taps cost:
+//
+//   * the expanded tile E lives in LDS as fp16 PIXEL PAIRS: one dword = (E[y][x even][c], E[y][x+1][c]).
+//     The expand GEMM is run as D = X . We^T (lane = hidden channel, registers = 16 pixels, of which
+//     rows 2t / 2t+1 are x-neighbours), so a pair is two registers of one lane: Swish, one
+//     v_cvt_pkrtz_f16_f32, one ds_write_b32 -- no cross-lane traffic.
+//   * a depthwise row of k taps is then ceil((k+1)/2) `v_dot2c_f32_f16` per channel instead of k
+//     (unpack + fma): 6 instead of 2x9 VALU instructions for 3x3, 15 instead of 2x25 for 5x5, with fp32
+//     accumulation.  The second operand is the tap PAIR (w[2t], w[2t+1]) (or (0,w0),(w1,w2).. for odd
+//     x) as fp16 -- wave-uniform, so it comes from SGPRs (s_load from a pre-paired table): no LDS
+//     reads and no VGPRs for depthwise weights at all.
+//   * wave-uniform tap pairs need every lane of a wave to work on the same hidden channels and the
+//     same x parity: a wave owns 64 output pixels (two 32-pixel blocks, same parity), computes the
+//     depthwise for channel chunk A (8 channels) and chunk B on all 64 lanes, and one
+//     v_permlane32_swap per register turns (A, B) into the two MFMA B-operand fragments of the project
+//     GEMM (lanes 0-31 = k-slots 0-7, lanes 32-63 = k-slots 8-15) for pixel block 0 and block 1;
+//     both MFMAs share one project-weight fragment.
+// fp16 has a narrower range than bf16: v_cvt_pkrtz saturates to +-65504 instead of overflowing, and
+// E is post-Swish (>= -0.28).  Everything outside the tile E stays bf16 (HBM tensors, project operand).
+#include "cf_common.h"
+#include "cf_kernels.h"
+#include <cstdlib>
+
+namespace cf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
+typedef __attribute__((ext_vector_type(2))) __fp16 f16x2;
+#define CF_AS4 __attribute__((address_space(4)))
+
+static inline int slot_channel2(int nb, int i) {
+    int h = (i >> 2) & 1;
+    int r = (i & 3) + 4 * (i >> 3);
+    return nb * 32 + h * 16 + r;
+}
+
+static inline uint16_t host_f32_to_f16(float f) {       // round-to-nearest-even, saturating
+    uint32_t u; __builtin_memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t exp = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+    uint32_t man = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+    if (exp >= 31) return (uint16_t)(sign | 0x7bffu);
+    if (exp <= 0) {
+        if (exp < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - exp;
+        uint32_t half = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+        if (rem > mid || (rem == mid && (half & 1))) ++half;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)exp << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1))) ++half;
+    if (half >= 0x7c00u) half = 0x7bffu;
+    return (uint16_t)(sign | half);
+}
+
+// acc += w.lo * e.lo + w.hi * e.hi (fp16 inputs, fp32 accumulate); w is wave-uniform (SGPR)
+// (the builtin, not inline asm: DOT results have read-after-write wait states the compiler must see)
+typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
+__device__ __forceinline__ void dot2c(float& acc, uint32_t w, uint32_t e) {
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(hf2, w), __builtin_bit_cast(hf2, e), acc, false);
+}
+
+// ---------------------------------------------------------------- geometry shared by host and device
+template <int KS, int S, int HC, int TOH, int TOW, int JX, int NW>
+struct Px {
+    static constexpr int IH = (TOH - 1) * S + KS, IW0 = (TOW - 1) * S + KS, IWP = (IW0 + 1) & ~1;
+    static constexpr int IPX = IH * IWP, NIB = (IPX + 31) / 32, NPAIR = IPX / 2;
+    static constexpr int NT = (KS + 1) / 2, NPARW = S == 1 ? 2 : 1;
+    static constexpr int NPIX = TOH * TOW, NPB = NPIX / 32, NPP = NPB / 2, KG = NW / NPP;
+    static constexpr int NBE = (HC + 31) / 32, HALF = HC / 16, JS = HALF / KG;
+    static constexpr int PITCH = HC * 4 + 16;
+    static constexpr int WXB = NBE * JX * 1024;
+    static constexpr int EBYTES = NIB * 16 * PITCH;          // whole pixel blocks: phase 1 stores are unconditional
+    static constexpr int RED = (KG - 1) * NPP * 64 * 64;
+    static constexpr int LDS = (EBYTES + 2 * WXB) > RED ? (EBYTES + 2 * WXB) : RED;
+    static_assert(NPB * 32 == NPIX && NPP * 2 == NPB && NPP * KG == NW, "tile / wave geometry");
+    static_assert(HC % 16 == 0 && JS * KG == HALF, "hidden chunk / k-group geometry");
+    static_assert(S == 2 || (NPIX / 2) % 64 == 0, "a wave's 64 pixels must share one x parity");
+};
+
+// ---------------------------------------------------------------- device
+template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW>
+__global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
+    typedef Px<KS, S, HC, TOH, TOW, JX, NW> G;
+    constexpr int IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, NPAIR = G::NPAIR, NT = G::NT, NPARW = G::NPARW;
+    constexpr int NPP = G::NPP, KG = G::KG, NBE = G::NBE, HALF = G::HALF, JS = G::JS, PITCH = G::PITCH, WXB = G::WXB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* E = smem;
+    char* Wst = smem + G::EBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH, b = blockIdx.z;
+    const int nq = p.nq;
+    const int pp = wave % NPP, jg = wave / NPP;
+
+    // tile pixel u -> (oy, ox); stride 1: all even-x pixels first, then all odd-x ones
+    auto tile_pixel = [](int u, int& oy, int& ox) {
+        if constexpr (S == 1) {
+            constexpr int HP = TOH * TOW / 2, HW = TOW / 2;
+            const int par = u / HP, r = u - par * HP;
+            oy = r / HW; ox = 2 * (r - oy * HW) + par;
+        } else { oy = u / TOW; ox = u - oy * TOW; }
+    };
+    const int par = S == 1 ? (pp * 64) / (TOH * TOW / 2) : 0;          // wave-uniform x parity (stride 2: x0 = 2 ox is even)
+    // phase 2: this lane's depthwise pixel = pixel pl of block (2 pp + h)
+    int dy, dx; tile_pixel((pp * 2 + h) * 32 + pl, dy, dx);
+    const unsigned e_pix = (unsigned)(((dy * S) * IWP + (dx * S - par)) / 2) * (unsigned)PITCH;
+
+    f32x16 acc[2][NBO];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < NBO; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][i][r] = 0.0f;
+
+    const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+    const unsigned rowbytes = (unsigned)p.Cin * 2;
+
+    auto stage_weights = [&](int q) {
+        char* dst = Wst + (q & 1) * WXB;
+        const char* srcx = (const char*)p.wexp + (size_t)q * WXB;
+        for (int c = wave; c < WXB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+    };
+
+    // X fragments of this wave's halo pixel blocks (MFMA A operand: lane = pixel, 8 contiguous Cin per
+    // half), loaded once; clamped address + zero select = ZeroPad2d without predicated loads
+    constexpr int MAXI = (NIB + NW - 1) / NW;
+    u32x4 xf[MAXI][JX];
+#pragma unroll
+    for (int t = 0; t < MAXI; ++t) {
+        const int ib = wave + NW * t;
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < IPX ? ip : IPX - 1;
+        const int iy = ipc / IWP, ix = ipc - iy * IWP;
+        const int gy = oy0 * S - p.pad_lo + iy, gx = ox0 * S - p.pad_lo + ix;
+        const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+        const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const u32x4 v = ld16(xbase + off + j * 16);
+            xf[t][j].x = valid ? v.x : 0u; xf[t][j].y = valid ? v.y : 0u;
+            xf[t][j].z = valid ? v.z : 0u; xf[t][j].w = valid ? v.w : 0u;
+        }
+    }
+
+    // expand one halo pixel block: D[pixel][channel] = X . We^T, Swish, pixel pairs -> E
+    auto expand_block = [&](int ib, const u32x4* xfr, const char* wx) {
+#pragma unroll
+        for (int nbl = 0; nbl < NBE; ++nbl) {
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+            const char* wb = wx + (nbl * JX * 64 + lane) * 16;
+#pragma unroll
+            for (int j = 0; j < JX; ++j) {
+                const u32x4 wv = ld16(wb + j * 1024);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xfr[j]),
+                                                            __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
+            }
+            const int ch = nbl * 32 + pl;
+            const bool chok = (HC % 32 == 0) || ch < HC;
+            // registers 2t, 2t+1 = MFMA rows m, m+1 (m even): pixel pair (ib*32 + m) / 2 = ib*16 + m2(t)
+            char* ecol = E + ch * 4 + (unsigned)(ib * 16 + 2 * h) * (unsigned)PITCH;
+            uint32_t d[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f32x2 x2; x2.x = a[2 * t]; x2.y = a[2 * t + 1];
+                const f32x2 y2 = swish2(x2);
+                d[t] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
+            }
+            if (chok) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    *reinterpret_cast<uint32_t*>(ecol + ((t & 1) + 4 * (t >> 1)) * PITCH) = d[t];
+            }
+        }
+    };
+
+    const CF_AS4 u32x8* wtab = (const CF_AS4 u32x8*)p.wdw;
+
+    // depthwise + Swish for hidden chunk c (8 channels) of chunk group q on this lane's pixel -> bf16x8
+    auto dw_chunk = [&](int q, int c) -> u32x4 {
+        float a8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = 0.0f;
+        const CF_AS4 u32x8* wq = wtab + (size_t)(((q * NPARW + par) * (HC / 8) + c) * KS) * NT;
+        const char* eb = E + e_pix + c * 32;
+        // software pipeline by one kernel row: row ky+1's tap pairs (SGPRs) and tile dwords (VGPRs) are
+        // requested before row ky's 8*NT dot products issue
+        u32x8 wn[NT]; u32x4 en[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { wn[t] = wq[t]; en[t][0] = ld16(eb + t * PITCH); en[t][1] = ld16(eb + t * PITCH + 16); }
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            u32x8 wc[NT]; u32x4 ec[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { wc[t] = wn[t]; ec[t][0] = en[t][0]; ec[t][1] = en[t][1]; }
+            if (ky + 1 < KS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const char* et = eb + ((ky + 1) * (IWP / 2) + t) * PITCH;
+                    wn[t] = wq[(ky + 1) * NT + t]; en[t][0] = ld16(et); en[t][1] = ld16(et + 16);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                dot2c(a8[0], wc[t][0], ec[t][0].x); dot2c(a8[1], wc[t][1], ec[t][0].y);
+                dot2c(a8[2], wc[t][2], ec[t][0].z); dot2c(a8[3], wc[t][3], ec[t][0].w);
+                dot2c(a8[4], wc[t][4], ec[t][1].x); dot2c(a8[5], wc[t][5], ec[t][1].y);
+                dot2c(a8[6], wc[t][6], ec[t][1].z); dot2c(a8[7], wc[t][7], ec[t][1].w);
+            }
+        }
+        act_arr<1, 8>(a8);
+        return pack16<bf16_t>(a8);
+    };
+
+    stage_weights(0);
+    for (int q = 0; q < nq; ++q) {
+        const char* wx = Wst + (q & 1) * WXB;
+        __syncthreads();      // previous chunk's depthwise done with E; this stage's expand weights landed
+
+#pragma unroll
+        for (int t = 0; t < MAXI; ++t) {
+            const int ib = wave + NW * t;
+            if (ib < NIB) expand_block(ib, xf[t], wx);
+        }
+        __syncthreads();
+        if (q + 1 < nq) stage_weights(q + 1);
+
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            if (KG > 1 && (j / JS) != jg) continue;                // wave-uniform: k-steps of this k-group
+            u32x4 wpc[NBO];
+#pragma unroll
+            for (int i = 0; i < NBO; ++i)
+                wpc[i] = ld16((const char*)p.wproj + ((((size_t)i * nq + q) * HALF + j) * 64 + lane) * 16);
+            const u32x4 dA = dw_chunk(q, j), dB = dw_chunk(q, HALF + j);
+            // (A, B) -> project fragments: block 0 = {A.lo, B.lo}, block 1 = {A.hi, B.hi}
+            u32x4 x0, x1;
+            {
+                auto s0 = __builtin_amdgcn_permlane32_swap(dA.x, dB.x, false, false); x0.x = s0[0]; x1.x = s0[1];
+                auto s1 = __builtin_amdgcn_permlane32_swap(dA.y, dB.y, false, false); x0.y = s1[0]; x1.y = s1[1];
+                auto s2 = __builtin_amdgcn_permlane32_swap(dA.z, dB.z, false, false); x0.z = s2[0]; x1.z = s2[1];
+                auto s3 = __builtin_amdgcn_permlane32_swap(dA.w, dB.w, false, false); x0.w = s3[0]; x1.w = s3[1];
+            }
+#pragma unroll
+            for (int i = 0; i < NBO; ++i) {
+                acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, wpc[i]),
+                                                                    __builtin_bit_cast(mfma_bf16x8, x0), acc[0][i], 0, 0, 0);
+                acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, wpc[i]),
+                                                                    __builtin_bit_cast(mfma_bf16x8, x1), acc[1][i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- combine the k-groups through LDS, one accumulator block at a time
+    if constexpr (KG > 1) {
+        float* red = reinterpret_cast<float*>(smem) + (size_t)(pp * 64 + lane) * 16;
+        constexpr int GSTRIDE = NPP * 64 * 16;                         // floats per k-group slab
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < NBO; ++i) {
+                __syncthreads();
+                if (jg > 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = acc[k][i][g * 4 + e];
+                        st16(red + (jg - 1) * GSTRIDE + g * 4, pack16<float>(t));
+                    }
+                }
+                __syncthreads();
+                if (jg == 0) {
+#pragma unroll
+                    for (int gk = 0; gk < KG - 1; ++gk)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float t[4];
+                            unpack16<float>(ld16(red + gk * GSTRIDE + g * 4), t);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[k][i][g * 4 + e] += t[e];
+                        }
+                }
+            }
+        if (jg > 0) return;
+    }
+
+    // ---- epilogue: accumulator k holds pixel block 2 pp + k (lane = pixel pl, half h = 16 channels)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int oy, ox; tile_pixel((pp * 2 + k) * 32 + pl, oy, ox);
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        if (gy >= p.Hout || gx >= p.Wout) continue;
+        const size_t opix = ((size_t)b * p.Hout + gy) * p.Wout + gx;
+#pragma unroll
+        for (int i = 0; i < NBO; ++i) {
+            const int cb = i * 32 + h * 16;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int ch = cb + g * 8;
+                if (ch >= p.Cout) break;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[k][i][g * 8 + e];
+                if constexpr (RESID) {
+                    float r[8];
+                    unpack16<bf16_t>(ld16((const char*)p.x + (opix * p.Cin + ch) * 2), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = r[e] + v[e];
+                }
+                st16((char*)p.y + (opix * p.Cout + ch) * 2, pack16<bf16_t>(v));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+struct Mb2Entry {
+    int k, s, jx, hc, nbo, res, toh, tow, nw, var;
+    int lds_bytes, nt, nparw, nbe, half;
+    hipError_t (*fn)(hipStream_t, const MbParams&);
+};
+
+template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW>
+static hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
+    auto kfn = mbconv_px_kernel<KS, S, NBO, RESID, NW, JX, HC, TOH, TOW>;
+    constexpr int LDS = Px<KS, S, HC, TOH, TOW, JX, NW>::LDS;
+    static thread_local bool configured = false;
+    if (LDS > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
+    set_kernel_tag("void cf::mbconv_px_kernel<%d, %d, %d, %s, %d, %d, %d, %d, %d>(cf::MbParams)", KS, S, NBO, RESID ? "true" : "false", NW, JX, HC, TOH, TOW);
+    hipLaunchKernelGGL(kfn, grid, blk, LDS, s, p);
+    return hipGetLastError();
+}
+
+#define MB2(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW)                                                               \
+    {KS, S, JX, HC, NBO, RES, TOH, TOW, NW, V, Px<KS, S, HC, TOH, TOW, JX, NW>::LDS, Px<KS, S, HC, TOH, TOW, JX, NW>::NT, \
+     Px<KS, S, HC, TOH, TOW, JX, NW>::NPARW, Px<KS, S, HC, TOH, TOW, JX, NW>::NBE, Px<KS, S, HC, TOH, TOW, JX, NW>::HALF,  \
+     &mb2_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW>}
+static const Mb2Entry kMb2Table[] = {
+    //  var KS S JX HC NBO res  tile  waves
+    MB2(0, 3, 2, 1, 32, 1, 0, 8, 16, 4),    // 1.0  16 ->  96 -> 24
+    MB2(0, 3, 1, 2, 48, 1, 1, 16, 16, 4),   // 1.1  24 -> 144 -> 24 (+res)
+    MB2(0, 5, 2, 2, 48, 1, 0, 8, 16, 6),    // 2.0  24 -> 144 -> 32
+    MB2(0, 5, 1, 2, 64, 1, 1, 8, 16, 4),    // 2.1  32 -> 192 -> 32 (+res)
+    MB2(0, 3, 2, 2, 32, 2, 0, 8, 16, 4),    // 3.0  32 -> 192 -> 64
+    MB2(0, 3, 1, 4, 64, 2, 1, 8, 16, 4),    // 3.1  64 -> 384 -> 64 (+res)
+    MB2(0, 5, 1, 4, 64, 3, 0, 8, 16, 4),    // 4.0  64 -> 384 -> 96
+    MB2(0, 5, 1, 6, 64, 3, 1, 8, 16, 4),    // 4.1  96 -> 576 -> 96 (+res)
+};
+#undef MB2
+
+static const Mb2Entry* mb2_find(int k, int s, int jx, int nbo, int res) {
+    static const int want = getenv("CF_MB2_VARIANT") ? atoi(getenv("CF_MB2_VARIANT")) : 0;
+    const Mb2Entry* base = nullptr;
+    for (const Mb2Entry& e : kMb2Table)
+        if (e.k == k && e.s == s && e.jx == jx && e.nbo == nbo && e.res == res) {
+            if (e.var == want) return &e;
+            if (e.var == 0) base = &e;
+        }
+    return base;
+}
+
+bool mb2_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
+    static const bool off = getenv("CF_MB_KIND") && atoi(getenv("CF_MB_KIND")) == 0;
+    if (off) return false;
+    const int jx = (Cin * 2 / 16 + 1) / 2, nbo = (Cout + 31) / 32;
+    const Mb2Entry* e = mb2_find(k, s, jx, nbo, (Cin == Cout && s == 1) ? 1 : 0);
+    if (!e || hid % e->hc) return false;
+    g.ok = true; g.kind = 1; g.S = s;
+    g.JX = jx; g.NBO = nbo; g.HC = e->hc; g.nq = hid / e->hc; g.NBE = e->nbe; g.HALF = e->half;
+    g.rowb = e->hc * 4 + 16;
+    g.lds_bytes = (size_t)e->lds_bytes;
+    g.wexp_bytes = (size_t)g.nq * g.NBE * g.JX * 64 * 16;
+    g.wdw_floats = (size_t)g.nq * e->nparw * (g.HC / 8) * k * e->nt * 8;    // dwords (fp16 tap pairs)
+    g.wproj_bytes = (size_t)g.NBO * g.nq * g.HALF * 64 * 16;
+    return true;
+}
+
+// we [hid][Cin], wd [hid][k*k], wp [Cout][hid]
+void mb2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+                      void* wexp_host, float* wdw_host, void* wproj_host) {
+    const int NCx = Cin * 2 / 16, NT = (k + 1) / 2, NPARW = g.S == 1 ? 2 : 1;
+    __builtin_memset(wexp_host, 0, g.wexp_bytes);
+    __builtin_memset(wproj_host, 0, g.wproj_bytes);
+    uint32_t* wt = reinterpret_cast<uint32_t*>(wdw_host);
+    for (int q = 0; q < g.nq; ++q) {
+        // expand, MFMA B operand: lane (n = channel, half h) holds Cin chunk h*JX + j of hidden channel q*HC + nbl*32 + n
+        for (int nbl = 0; nbl < g.NBE; ++nbl)
+            for (int j = 0; j < g.JX; ++j)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int n = lane & 31, hh = lane >> 5;
+                    const int cl = nbl * 32 + n, c = hh * g.JX + j;
+                    if (cl >= g.HC || c >= NCx) continue;
+                    uint16_t* dst = (uint16_t*)((char*)wexp_host + ((((size_t)q * g.NBE + nbl) * g.JX + j) * 64 + lane) * 16);
+                    for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(we[(size_t)(q * g.HC + cl) * Cin + (size_t)c * 8 + e]);
+                }
+        // depthwise tap pairs: [q][parity][chunk][ky][t][8 channels]; even x0: (w[2t], w[2t+1]), odd x0: (w[2t-1], w[2t])
+        for (int par = 0; par < NPARW; ++par)
+            for (int c = 0; c < g.HC / 8; ++c)
+                for (int ky = 0; ky < k; ++ky)
+                    for (int t = 0; t < NT; ++t)
+                        for (int i = 0; i < 8; ++i) {
+                            const float* wrow = wd + (size_t)(q * g.HC + c * 8 + i) * k * k + (size_t)ky * k;
+                            const int k0 = 2 * t - par, k1 = k0 + 1;
+                            const uint16_t lo = (k0 >= 0 && k0 < k) ? host_f32_to_f16(wrow[k0]) : 0;
+                            const uint16_t hi = (k1 >= 0 && k1 < k) ? host_f32_to_f16(wrow[k1]) : 0;
+                            wt[((((size_t)(q * NPARW + par) * (g.HC / 8) + c) * k + ky) * NT + t) * 8 + i] = (uint32_t)lo | ((uint32_t)hi << 16);
+                        }
+        // project, MFMA A operand (same layout as cf_mbconv.hip)
+        for (int nbo = 0; nbo < g.NBO; ++nbo)
+            for (int j = 0; j < g.HALF; ++j)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, hh = lane >> 5;
+                    const int co = slot_channel2(nbo, i);
+                    if (co >= Cout) continue;
+                    const int hc = q * g.HC + (hh * g.HALF + j) * 8;
+                    uint16_t* dst = (uint16_t*)((char*)wproj_host + ((((size_t)nbo * g.nq + q) * g.HALF + j) * 64 + lane) * 16);
+                    for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(wp[(size_t)co * hid + hc + e]);
+                }
+    }
+}
+
+hipError_t mb2_launch(hipStream_t s, const MbParams& p) {
+    const Mb2Entry* e = mb2_find(p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
+    if (!e || e->hc != p.HC) return hipErrorInvalidValue;
+    return e->fn(s, p);
+}
+
+}  // namespace cf

@@ -153,7 +153,7 @@ int cf_op_mbconv(int device, int dtype, const float* x, const float* w_exp, cons
     p.wexp = sc.up(we.data(), we.size()); p.wdw = sc.upv(wd); p.wproj = sc.up(wp.data(), wp.size());
     p.B = B; p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.Cin = Cin; p.hid = hid; p.Cout = Cout;
     p.k = k; p.s = stride; p.pad_lo = pd / 2; p.residual = (Cin == Cout && stride == 1) ? 1 : 0;
-    p.HC = g.HC; p.nq = g.nq; p.NBE = g.NBE; p.JX = g.JX; p.HALF = g.HALF; p.rowb = g.rowb; p.lds_bytes = g.lds_bytes;
+    p.HC = g.HC; p.nq = g.nq; p.NBE = g.NBE; p.JX = g.JX; p.HALF = g.HALF; p.rowb = g.rowb; p.lds_bytes = g.lds_bytes; p.kind = g.kind;
     if (sc.err == hipSuccess) sc.chk(launch_mbconv(sc.s, dtype, p));
     sc.to_host_nchw(dtype, p.y, y, B, Cout, Ho, Wo);
     return sc.result("cf_op_mbconv");

@@ -518,8 +518,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
             p.B = B; p.Hin = op.Hin; p.Win = op.Win; p.Hout = op.Hout; p.Wout = op.Wout; p.Cin = op.Cin; p.hid = op.hid; p.Cout = op.Cout;
             p.k = op.k; p.s = op.s; p.pad_lo = op.pad_lo; p.residual = op.residual ? 1 : 0;
             p.HC = op.geo.HC; p.nq = op.geo.nq; p.NBE = op.geo.NBE; p.JX = op.geo.JX; p.HALF = op.geo.HALF; p.rowb = op.geo.rowb;
-            p.lds_bytes = op.geo.lds_bytes;
-            { static const int nw_env = getenv("CF_MB_NW") ? atoi(getenv("CF_MB_NW")) : 0; p.nw = nw_env; }
+            p.lds_bytes = op.geo.lds_bytes; p.kind = op.geo.kind;
             return launch_mbconv(c->stream, c->dtype, p);
         }
         case OP_HEAD: {
