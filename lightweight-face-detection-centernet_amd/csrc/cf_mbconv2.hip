@@ -18,6 +18,9 @@
 //     v_permlane32_swap per register turns (A, B) into the two MFMA B-operand fragments of the project
 //     GEMM (lanes 0-31 = k-slots 0-7, lanes 32-63 = k-slots 8-15) for pixel block 0 and block 1;
 //     both MFMAs share one project-weight fragment.
+//   * Swish arguments arrive pre-scaled by -log2(e) (folded into the expand weights; the depthwise is
+//     linear, so its output is pre-scaled too) and the leftover factor is folded into the project
+//     weights (x -ln 2): x * sigmoid(x) costs exp2 + rcp + one packed add + one packed multiply.
 // fp16 has a narrower range than bf16: v_cvt_pkrtz saturates to +-65504 instead of overflowing, and
 // E is post-Swish (>= -0.28).  Everything outside the tile E stays bf16 (HBM tensors, project operand).
 #include "cf_common.h"
@@ -66,6 +69,17 @@ typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
 __device__ __forceinline__ void dot2c(float& acc, uint32_t w, uint32_t e) {
     acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(hf2, w), __builtin_bit_cast(hf2, e), acc, false);
 }
+
+// Swish with the input pre-scaled by -log2(e) (folded into the weights that produce it):
+// u = -log2(e) x  ->  u / (1 + 2^u) = -log2(e) swish(x); the constant factor of the result is folded into
+// the NEXT linear layer's weights (x -ln 2).  One packed multiply less per pair than swish2().
+__device__ __forceinline__ f32x2 swish2_prescaled(f32x2 u) {
+    f32x2 e; e.x = __builtin_amdgcn_exp2f(u.x); e.y = __builtin_amdgcn_exp2f(u.y);
+    const f32x2 den = e + 1.0f;
+    f32x2 r; r.x = __builtin_amdgcn_rcpf(den.x); r.y = __builtin_amdgcn_rcpf(den.y);
+    return u * r;
+}
+static constexpr float kNegLog2e = -1.44269504088896341f, kNegLn2 = -0.69314718055994531f;
 
 // ---------------------------------------------------------------- geometry shared by host and device
 template <int KS, int S, int HC, int TOH, int TOW, int JX, int NW>
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 f32x2 x2; x2.x = a[2 * t]; x2.y = a[2 * t + 1];
-                const f32x2 y2 = swish2(x2);
+                const f32x2 y2 = swish2_prescaled(x2);            // E' = -log2(e) swish(expand)
                 d[t] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
             }
             if (chok) {
@@ -223,7 +237,13 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
                 dot2c(a8[6], wc[t][6], ec[t][1].z); dot2c(a8[7], wc[t][7], ec[t][1].w);
             }
         }
-        act_arr<1, 8>(a8);
+        // a8 = sum w E' = -log2(e) * depthwise output: already the pre-scaled Swish argument
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            f32x2 u; u.x = a8[i]; u.y = a8[i + 1];
+            const f32x2 y = swish2_prescaled(u);
+            a8[i] = y.x; a8[i + 1] = y.y;
+        }
         return pack16<bf16_t>(a8);
     };
 
@@ -360,12 +380,34 @@ static const Mb2Entry kMb2Table[] = {
     //  var KS S JX HC NBO res  tile  waves
     MB2(0, 3, 2, 1, 32, 1, 0, 8, 16, 4),    // 1.0  16 ->  96 -> 24
     MB2(0, 3, 1, 2, 48, 1, 1, 16, 16, 4),   // 1.1  24 -> 144 -> 24 (+res)
-    MB2(0, 5, 2, 2, 48, 1, 0, 8, 16, 6),    // 2.0  24 -> 144 -> 32
+    MB2(0, 5, 2, 2, 48, 1, 0, 8, 8, 3),     // 2.0  24 -> 144 -> 32   (small tile: 48 KB of LDS, 3 workgroups per CU)
     MB2(0, 5, 1, 2, 64, 1, 1, 8, 16, 4),    // 2.1  32 -> 192 -> 32 (+res)
     MB2(0, 3, 2, 2, 32, 2, 0, 8, 16, 4),    // 3.0  32 -> 192 -> 64
     MB2(0, 3, 1, 4, 64, 2, 1, 8, 16, 4),    // 3.1  64 -> 384 -> 64 (+res)
     MB2(0, 5, 1, 4, 64, 3, 0, 8, 16, 4),    // 4.0  64 -> 384 -> 96
     MB2(0, 5, 1, 6, 64, 3, 1, 8, 16, 4),    // 4.1  96 -> 576 -> 96 (+res)
+    // experimental variants (CF_MB2_VARIANT=n)
+    MB2(1, 3, 2, 1, 48, 1, 0, 8, 16, 6),    // 1.0 HC48 KG3
+    MB2(1, 3, 1, 2, 48, 1, 1, 8, 16, 6),    // 1.1 8x16 KG3
+    MB2(1, 5, 2, 2, 48, 1, 0, 8, 16, 6),    // 2.0 8x16 KG3
+    MB2(1, 5, 1, 2, 96, 1, 1, 8, 16, 4),    // 2.1 HC96
+    MB2(1, 3, 1, 4, 32, 2, 1, 8, 16, 4),    // 3.1 HC32
+    MB2(1, 5, 1, 4, 32, 3, 0, 8, 16, 4),    // 4.0 HC32
+    MB2(1, 5, 1, 6, 32, 3, 1, 8, 16, 4),    // 4.1 HC32
+    MB2(2, 3, 2, 1, 32, 1, 0, 4, 32, 4),    // 1.0 4x32
+    MB2(2, 3, 1, 2, 48, 1, 1, 8, 32, 4),    // 1.1 8x32 KG1
+    MB2(2, 5, 2, 2, 48, 1, 0, 4, 16, 3),    // 2.0 4x16 KG3
+    MB2(2, 5, 1, 2, 64, 1, 1, 16, 16, 8),   // 2.1 16x16 KG2
+    MB2(2, 3, 1, 4, 128, 2, 1, 8, 16, 4),   // 3.1 HC128
+    MB2(2, 5, 1, 4, 128, 3, 0, 8, 16, 4),   // 4.0 HC128
+    MB2(2, 5, 1, 6, 96, 3, 1, 8, 16, 4),    // 4.1 HC96
+    MB2(3, 3, 1, 2, 48, 1, 1, 16, 16, 12),  // 1.1 16x16 KG3
+    MB2(3, 5, 1, 2, 64, 1, 1, 8, 16, 8),    // 2.1 KG4
+    MB2(3, 3, 1, 4, 64, 2, 1, 8, 16, 8),    // 3.1 KG4
+    MB2(3, 5, 1, 4, 64, 3, 0, 8, 16, 8),    // 4.0 KG4
+    MB2(3, 5, 1, 6, 64, 3, 1, 8, 16, 8),    // 4.1 KG4
+    MB2(3, 5, 2, 2, 48, 1, 0, 8, 16, 2),    // 2.0 KG1 (2 waves)
+    MB2(3, 3, 2, 1, 96, 1, 0, 4, 16, 2),    // 1.0 4x16 HC96 KG... 
 };
 #undef MB2
 
@@ -412,7 +454,7 @@ void mb2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const 
                     const int cl = nbl * 32 + n, c = hh * g.JX + j;
                     if (cl >= g.HC || c >= NCx) continue;
                     uint16_t* dst = (uint16_t*)((char*)wexp_host + ((((size_t)q * g.NBE + nbl) * g.JX + j) * 64 + lane) * 16);
-                    for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(we[(size_t)(q * g.HC + cl) * Cin + (size_t)c * 8 + e]);
+                    for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLog2e * we[(size_t)(q * g.HC + cl) * Cin + (size_t)c * 8 + e]);
                 }
         // depthwise tap pairs: [q][parity][chunk][ky][t][8 channels]; even x0: (w[2t], w[2t+1]), odd x0: (w[2t-1], w[2t])
         for (int par = 0; par < NPARW; ++par)
@@ -435,7 +477,7 @@ void mb2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const 
                     if (co >= Cout) continue;
                     const int hc = q * g.HC + (hh * g.HALF + j) * 8;
                     uint16_t* dst = (uint16_t*)((char*)wproj_host + ((((size_t)nbo * g.nq + q) * g.HALF + j) * 64 + lane) * 16);
-                    for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(wp[(size_t)co * hid + hc + e]);
+                    for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLn2 * wp[(size_t)co * hid + hc + e]);
                 }
     }
 }
