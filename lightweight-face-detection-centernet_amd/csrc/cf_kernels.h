@@ -101,7 +101,12 @@ struct Stem0Params {
     const void* wproj;    // stem0_pack_proj
     void* y;              // [B][H/2][W/2][16] T
     int B, H, W;
+    int kind;             // 0: stem0_kernel; 1: stem0_px_kernel (bf16 storage; weights from stem0px_pack)
 };
+size_t stem0px_wstem_bytes();
+size_t stem0px_wdw_dwords();
+void stem0px_pack(const float* ws /*[32][3][3][3]*/, const float* wd /*[32][9]*/, const float* wp /*[16][32]*/,
+                  void* wstem_out, uint32_t* wdw_out, void* wproj_out);
 void stem0_lut(float* lut /*[3][256]*/);
 size_t stem0_proj_bytes(int dtype);
 void stem0_pack_proj(int dtype, const float* wp /*[16][32]*/, void* out_host);

@@ -408,11 +408,18 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
             stem_pack_weights(dt, ws.f(op.wkey), w.data());
             int r = upload_bytes(c, w, &op.wp); if (r) return r;
         } else if (op.kind == OP_STEM0) {
-            std::vector<char> w(stem_packed_bytes(dt)), wp(stem0_proj_bytes(dt));
-            std::vector<float> wd(9 * 32), lut(768);
-            stem_pack_weights(dt, ws.f(op.wkey), w.data());
-            dw_pack_weights(ws.f(op.wkey_dw), 32, 3, wd.data());
-            stem0_pack_proj(dt, ws.f(op.wkey_proj), wp.data());
+            static const bool px_off = getenv("CF_STEM0_KIND") && atoi(getenv("CF_STEM0_KIND")) == 0;
+            const bool px = dt == CF_BF16 && !px_off;                 // second-generation kernel (cf_stem0.hip)
+            op.geo.kind = px ? 1 : 0;
+            std::vector<char> w(px ? stem0px_wstem_bytes() : stem_packed_bytes(dt)), wp(stem0_proj_bytes(dt));
+            std::vector<float> wd(px ? stem0px_wdw_dwords() : 9 * 32), lut(768);
+            if (px) {
+                stem0px_pack(ws.f(op.wkey), ws.f(op.wkey_dw), ws.f(op.wkey_proj), w.data(), reinterpret_cast<uint32_t*>(wd.data()), wp.data());
+            } else {
+                stem_pack_weights(dt, ws.f(op.wkey), w.data());
+                dw_pack_weights(ws.f(op.wkey_dw), 32, 3, wd.data());
+                stem0_pack_proj(dt, ws.f(op.wkey_proj), wp.data());
+            }
             stem0_lut(lut.data());
             int r = upload_bytes(c, w, &op.wp); if (r) return r;
             r = upload(c, wd, &op.wdw); if (r) return r;
@@ -510,7 +517,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
         }
         case OP_STEM0: {
             Stem0Params p{}; p.x = net_in; p.in_format = in_format; p.lut = op.upw; p.wstem = op.wp; p.wdw = op.wdw;
-            p.wproj = op.wproj; p.y = bp(op.out); p.B = B; p.H = op.Hin; p.W = op.Win;
+            p.wproj = op.wproj; p.y = bp(op.out); p.B = B; p.H = op.Hin; p.W = op.Win; p.kind = op.geo.kind;
             return launch_stem0(c->stream, c->dtype, p);
         }
         case OP_MB: {

@@ -256,9 +256,275 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
     }
 }
 
+
+// ================================================================== second generation (bf16 storage)
+// Same fusion, with the depthwise restructured as in cf_mbconv2.hip: the stem GEMM runs as
+// D = X . Ws^T (lane = stem channel, registers = 16 pixels), so x-neighbour pairs sit in one lane and go
+// to LDS as fp16 pixel pairs; the 3x3 depthwise is then 6 v_dot2c_f32_f16 per channel against
+// wave-uniform tap pairs from SGPRs; a wave owns 64 same-parity pixels and a v_permlane32_swap builds the
+// two project-MFMA fragments.  Swish arguments are pre-scaled by -log2(e) through the stem weights and
+// the leftover -ln 2 sits in the project weights.  4 waves per 16x16 tile.
+typedef __attribute__((ext_vector_type(8))) uint32_t s0_u32x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 s0_hf2;
+#define S0_AS4 __attribute__((address_space(4)))
+constexpr int S0P_NT = 256, S0P_NW = 4;
+constexpr int S0P_PITCH = 32 * 4 + 16;                             // one pixel pair, 32 channels (fp16 x 2) + pad
+constexpr int S0P_NIB = (S0_IPX + 31) / 32;                        // 11 halo pixel blocks
+static constexpr float kS0NegLog2e = -1.44269504088896341f, kS0NegLn2 = -0.69314718055994531f;
+
+static inline uint16_t s0_f32_to_f16(float f) {                    // RNE, saturating
+    uint32_t u; __builtin_memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t exp = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+    uint32_t man = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+    if (exp >= 31) return (uint16_t)(sign | 0x7bffu);
+    if (exp <= 0) {
+        if (exp < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - exp;
+        uint32_t half = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+        if (rem > mid || (rem == mid && (half & 1))) ++half;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)exp << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1))) ++half;
+    if (half >= 0x7c00u) half = 0x7bffu;
+    return (uint16_t)(sign | half);
+}
+
+size_t stem0px_wstem_bytes() { return 2 * 64 * 16; }
+size_t stem0px_wdw_dwords() { return 2 * 4 * 3 * 2 * 8; }
+// ws [32][3][3][3] (co, ci, ky, kx), wd [32][9], wp [16][32]
+void stem0px_pack(const float* ws, const float* wd, const float* wp, void* wstem_out, uint32_t* wdw_out, void* wproj_out) {
+    // stem, MFMA B operand: lane (n = channel, half h), chunk c, element e <-> tap t = c*16 + h*8 + e, t = ky*9 + kx*3 + ci
+    __builtin_memset(wstem_out, 0, stem0px_wstem_bytes());
+    for (int c = 0; c < 2; ++c)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int co = lane & 31, h = lane >> 5;
+            uint16_t* dst = (uint16_t*)((char*)wstem_out + ((size_t)c * 64 + lane) * 16);
+            for (int e = 0; e < 8; ++e) {
+                const int t = c * 16 + h * 8 + e;
+                if (t >= 27) continue;
+                const int ky = t / 9, kx = (t % 9) / 3, ci = t % 3;
+                dst[e] = host_f32_to_bf16(kS0NegLog2e * ws[((co * 3 + ci) * 3 + ky) * 3 + kx]);
+            }
+        }
+    // depthwise tap pairs [parity][chunk][ky][t][8]: even x0 -> (w[2t], w[2t+1]); odd x0 -> (w[2t-1], w[2t])
+    for (int par = 0; par < 2; ++par)
+        for (int c = 0; c < 4; ++c)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int t = 0; t < 2; ++t)
+                    for (int i = 0; i < 8; ++i) {
+                        const float* wrow = wd + (c * 8 + i) * 9 + ky * 3;
+                        const int k0 = 2 * t - par, k1 = k0 + 1;
+                        const uint16_t lo = (k0 >= 0 && k0 < 3) ? s0_f32_to_f16(wrow[k0]) : 0;
+                        const uint16_t hi = (k1 >= 0 && k1 < 3) ? s0_f32_to_f16(wrow[k1]) : 0;
+                        wdw_out[((((par * 4 + c) * 3 + ky) * 2 + t) * 8) + i] = (uint32_t)lo | ((uint32_t)hi << 16);
+                    }
+    // project (A operand, as stem0_pack_proj) x -ln 2
+    __builtin_memset(wproj_out, 0, stem0_proj_bytes(1));
+    for (int j = 0; j < 2; ++j)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, h = lane >> 5, co = slot_channel(0, i);
+            if (co >= 16) continue;
+            uint16_t* dst = (uint16_t*)((char*)wproj_out + ((size_t)j * 64 + lane) * 16);
+            for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kS0NegLn2 * wp[co * 32 + (h * 2 + j) * 8 + e]);
+        }
+}
+
+__device__ __forceinline__ f32x2 s0_swish2_prescaled(f32x2 u) {
+    f32x2 e; e.x = __builtin_amdgcn_exp2f(u.x); e.y = __builtin_amdgcn_exp2f(u.y);
+    const f32x2 den = e + 1.0f;
+    f32x2 r; r.x = __builtin_amdgcn_rcpf(den.x); r.y = __builtin_amdgcn_rcpf(den.y);
+    return u * r;
+}
+__device__ __forceinline__ void s0_dot2c(float& acc, uint32_t w, uint32_t e) {
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(s0_hf2, w), __builtin_bit_cast(s0_hf2, e), acc, false);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
+    typedef bf16_t T;
+    __shared__ __attribute__((aligned(16))) char E[S0P_NIB * 16 * S0P_PITCH];
+    __shared__ __attribute__((aligned(16))) T Xs[S0_PH * S0_PROW];
+    __shared__ float lut[FMT == CF_IN_U8_HWC_BGR ? 768 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const int ox0 = blockIdx.x * S0_TOW, oy0 = blockIdx.y * S0_TOH, b = blockIdx.z;
+
+    // ---- stage the normalised image patch (as stem0_kernel, 256 threads: 2 patch rows per pass)
+    const int iy0 = 2 * (oy0 - 1), ix0 = 2 * (ox0 - 1);
+    constexpr int ECOLS = S0_PW * 3, RSTEP = S0P_NT / ECOLS, NIT = (S0_PH + RSTEP - 1) / RSTEP;
+    {
+        const int e = tid % ECOLS, r0 = tid / ECOLS;
+        const bool tact = r0 < RSTEP;
+        const int col = e / 3, ci = e - col * 3;
+        const int ix = ix0 + col;
+        const bool xok = tact && (unsigned)ix < (unsigned)p.W;
+        const int cx = min(max(ix, 0), p.W - 1);
+        float v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = r0 + it * RSTEP;
+            const int iy = iy0 + r;
+            const bool ok = xok && r < S0_PH && (unsigned)iy < (unsigned)p.H;
+            const int cy = min(max(iy, 0), p.H - 1);
+            if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+                const uint32_t u = ((const uint8_t*)p.x)[(((size_t)b * p.H + cy) * p.W + cx) * 3 + ci];
+                v[it] = __uint_as_float(ok ? (u | (uint32_t)(ci << 8)) : 0xffffffffu);
+            } else {
+                const float f = ((const float*)p.x)[(((size_t)b * 3 + ci) * p.H + cy) * p.W + cx];
+                v[it] = ok ? f : 0.0f;
+            }
+        }
+        if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+            for (int i = tid; i < 768; i += S0P_NT) lut[i] = p.lut[i];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = r0 + it * RSTEP;
+            float val = v[it];
+            if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+                const uint32_t idx = __float_as_uint(v[it]);
+                val = idx == 0xffffffffu ? 0.0f : lut[idx];
+            }
+            if (tact && r < S0_PH) Xs[r * S0_PROW + e] = (T)(pack_bf16x2(val, 0.0f) & 0xffffu);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: stem conv D[pixel][channel] = X . Ws^T, Swish (pre-scaled), pixel pairs -> E
+    u32x4 ws[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) ws[c] = ld16((const char*)p.wstem + ((size_t)c * 64 + lane) * 16);
+    for (int ib = wave; ib < S0P_NIB; ib += S0P_NW) {
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < S0_IPX ? ip : S0_IPX - 1;
+        const int ty = ipc / S0_IW, tx = ipc - ty * S0_IW;
+        const int y = oy0 - 1 + ty, x = ox0 - 1 + tx;
+        // a halo pixel outside the map is the depthwise conv's zero padding: zero operand row -> swish(0) = 0
+        const bool inmap = ip < S0_IPX && (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo;
+        const T* xp = Xs + (2 * ty) * S0_PROW + (2 * tx) * 3;
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint32_t w4[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const int t0 = c * 16 + h * 8 + 2 * e2, t1 = t0 + 1;
+                const int ky0 = t0 / 9, r0 = t0 - 9 * ky0, ky1 = t1 / 9, r1 = t1 - 9 * ky1;
+                const uint32_t lo = t0 < 27 ? (uint32_t)xp[ky0 * S0_PROW + r0] : 0u;
+                const uint32_t hi = t1 < 27 ? (uint32_t)xp[ky1 * S0_PROW + r1] : 0u;
+                w4[e2] = inmap ? (lo | (hi << 16)) : 0u;
+            }
+            u32x4 xc; xc.x = w4[0]; xc.y = w4[1]; xc.z = w4[2]; xc.w = w4[3];
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xc),
+                                                        __builtin_bit_cast(mfma_bf16x8, ws[c]), a, 0, 0, 0);
+        }
+        char* ecol = E + pl * 4 + (unsigned)(ib * 16 + 2 * h) * (unsigned)S0P_PITCH;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x2 x2; x2.x = a[2 * t]; x2.y = a[2 * t + 1];
+            const f32x2 y2 = s0_swish2_prescaled(x2);
+            *reinterpret_cast<uint32_t*>(ecol + ((t & 1) + 4 * (t >> 1)) * S0P_PITCH) =
+                __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2 + 3: depthwise 3x3 + Swish on 64 same-parity pixels per wave -> project 32 -> 16
+    const int par = wave >> 1;                                      // waves 0,1: even x; 2,3: odd x
+    auto tile_pixel = [](int u, int& oy, int& ox) {
+        const int pr = u >> 7, r = u & 127;
+        oy = r >> 3; ox = 2 * (r & 7) + pr;
+    };
+    int dy, dx; tile_pixel((wave * 2 + h) * 32 + pl, dy, dx);
+    const char* eb0 = E + (unsigned)((dy * S0_IW + (dx - par)) / 2) * (unsigned)S0P_PITCH;
+    const S0_AS4 s0_u32x8* wtab = (const S0_AS4 s0_u32x8*)p.wdw;
+
+    auto dw_chunk = [&](int c) -> u32x4 {
+        float a8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = 0.0f;
+        const S0_AS4 s0_u32x8* wq = wtab + ((par * 4 + c) * 3) * 2;
+        const char* eb = eb0 + c * 32;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const s0_u32x8 wv = wq[ky * 2 + t];
+                const char* et = eb + (ky * (S0_IW / 2) + t) * S0P_PITCH;
+                const u32x4 e0 = ld16(et), e1 = ld16(et + 16);
+                s0_dot2c(a8[0], wv[0], e0.x); s0_dot2c(a8[1], wv[1], e0.y);
+                s0_dot2c(a8[2], wv[2], e0.z); s0_dot2c(a8[3], wv[3], e0.w);
+                s0_dot2c(a8[4], wv[4], e1.x); s0_dot2c(a8[5], wv[5], e1.y);
+                s0_dot2c(a8[6], wv[6], e1.z); s0_dot2c(a8[7], wv[7], e1.w);
+            }
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            f32x2 u; u.x = a8[i]; u.y = a8[i + 1];
+            const f32x2 yv = s0_swish2_prescaled(u);
+            a8[i] = yv.x; a8[i + 1] = yv.y;
+        }
+        return pack16<T>(a8);
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const u32x4 wpc = ld16((const char*)p.wproj + ((size_t)j * 64 + lane) * 16);
+        const u32x4 dA = dw_chunk(j), dB = dw_chunk(2 + j);
+        u32x4 x0, x1;
+        {
+            auto s0 = __builtin_amdgcn_permlane32_swap(dA.x, dB.x, false, false); x0.x = s0[0]; x1.x = s0[1];
+            auto s1 = __builtin_amdgcn_permlane32_swap(dA.y, dB.y, false, false); x0.y = s1[0]; x1.y = s1[1];
+            auto s2 = __builtin_amdgcn_permlane32_swap(dA.z, dB.z, false, false); x0.z = s2[0]; x1.z = s2[1];
+            auto s3 = __builtin_amdgcn_permlane32_swap(dA.w, dB.w, false, false); x0.w = s3[0]; x1.w = s3[1];
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, wpc), __builtin_bit_cast(mfma_bf16x8, x0), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, wpc), __builtin_bit_cast(mfma_bf16x8, x1), acc[1], 0, 0, 0);
+    }
+    if (h != 0) return;                                            // channels 0..15 live in the h == 0 lanes
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int oy, ox; tile_pixel((wave * 2 + k) * 32 + pl, oy, ox);
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        if (gy >= Ho || gx >= Wo) continue;
+        T* out = (T*)p.y + (((size_t)b * Ho + gy) * Wo + gx) * 16;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[k][g * 8 + e];
+            st16(out + g * 8, pack16<T>(v));
+        }
+    }
+}
+
 hipError_t launch_stem0(hipStream_t s, int dtype, const Stem0Params& p) {
     if (p.B <= 0) return hipSuccess;
     const int Ho = p.H / 2, Wo = p.W / 2;
+    if (p.kind == 1) {
+        if (dtype != 1) return hipErrorInvalidValue;
+        dim3 grid((Wo + S0_TOW - 1) / S0_TOW, (Ho + S0_TOH - 1) / S0_TOH, p.B), blk(S0P_NT);
+        set_kernel_tag("void cf::stem0_px_kernel<%d>(cf::Stem0Params)", p.in_format);
+        if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem0_px_kernel<CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((stem0_px_kernel<CF_IN_F32_NCHW>), grid, blk, 0, s, p);
+        return hipGetLastError();
+    }
     dim3 grid((Wo + S0_TOW - 1) / S0_TOW, (Ho + S0_TOH - 1) / S0_TOH, p.B), blk(S0_NT);
     set_kernel_tag("void cf::stem0_kernel<%s, %d>(cf::Stem0Params)", dtype == 0 ? "float" : "unsigned short", p.in_format);
     if (dtype == 0) {
