@@ -568,3 +568,27 @@ def test_batch64_bf16_properties():
     overlap = len(set(i1[0].tolist()) & set(rinds[0].tolist()))
     assert overlap >= 85, overlap
     eng.close()
+
+
+@pytest.mark.parametrize("size", [(96, 128), (160, 224), (480, 640)])
+def test_bf16_engine_tracks_fp32_engine(size):
+    """The bf16 throughput path (second-generation fused kernels: fp16 pixel-pair tiles, dot2c depthwise,
+    pre-scaled Swish) against the fp32 parity path on map sizes that are not multiples of any tile, so
+    every kernel has edge tiles: a misplaced halo or a dropped edge pixel shows up as an O(1) error
+    at the border, far outside the bf16 noise floor asserted here."""
+    H, W = size
+    rng = np.random.default_rng(H * 7 + W)
+    x = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    e32 = cfa.Engine(H, W, max_batch=2, dtype="fp32")
+    e16 = cfa.Engine(H, W, max_batch=2, dtype="bf16")
+    e32.forward_enqueue(x); e16.forward_enqueue(x)
+    h32, h16 = e32.heads(), e16.heads()
+    for k in ("hm", "wh", "lm", "reg"):
+        d = np.abs(h16[k] - h32[k])
+        scale = np.abs(h32[k]).mean() + 1e-6
+        assert d.mean() / scale < 0.03, (k, d.mean() / scale)
+        assert d.max() < 0.25 * max(1.0, float(np.abs(h32[k]).max())), (k, float(d.max()))
+        # borders are as good as the interior
+        border = np.concatenate([d[..., :2, :].ravel(), d[..., -2:, :].ravel(), d[..., :, :2].ravel(), d[..., :, -2:].ravel()])
+        assert border.mean() < 3.0 * d.mean() + 1e-3, (k, float(border.mean()), float(d.mean()))
+    e32.close(); e16.close()
