@@ -78,6 +78,9 @@ bool mb2_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s);
 void mb2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
                       void* wexp_host, float* wdw_host, void* wproj_host);
 hipError_t mb2_launch(hipStream_t s, const MbParams& p);
+// expand + depthwise only (MbGeom::kind == 2): y = depthwise output [B][Hout][Wout][hid]; packs with mb_pack_weights(wproj = nullptr)
+MbGeom expdw_geometry(int dtype, int Cin, int hid, int k, int s);
+hipError_t expdw_launch(hipStream_t s, const MbParams& p);
 
 // ------------------------------------------------------------------ stem 3x3 s2 3->32 + Swish
 struct StemParams {

@@ -349,6 +349,227 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     }
 }
 
+
+// ================================================================== expand + depthwise only
+// The blocks whose output is too wide for the accumulator budget (layer5.0 .. layer6.0: Cout 160 / 320 on
+// 20x20 maps) keep their project 1x1 as a GEMM launch (cf_pw.hip), but expand + Swish + depthwise + Swish
+// run here with the same fp16 pixel-pair tile / SGPR tap pairs, writing only the depthwise output:
+// the 6x-expanded tensor (the largest of the block) never reaches HBM.  With no project accumulators a
+// workgroup handles ONE hidden chunk of one tile, so the grid is (tiles, hid / HC, batch): enough
+// workgroups to fill the chip even on 20x20 maps.  Pixel -> lane mapping allows partly filled waves
+// (a 10x20 tile has 100 pixels per x parity: two waves of 64 lanes, 50 live in the second).
+template <int KS, int S, int HC, int TOH, int TOW, int JX>
+struct Xd {
+    static constexpr int IH = (TOH - 1) * S + KS, IW0 = (TOW - 1) * S + KS, IWP = (IW0 + 1) & ~1;
+    static constexpr int IPX = IH * IWP, NIB = (IPX + 31) / 32;
+    static constexpr int NT = (KS + 1) / 2, NPARW = S == 1 ? 2 : 1;
+    static constexpr int NPIX = TOH * TOW, PPX = S == 1 ? NPIX / 2 : NPIX;     // pixels per parity class
+    static constexpr int WPP = (PPX + 63) / 64, NW = NPARW * WPP;
+    static constexpr int NBE = HC / 32, PITCH = HC * 4 + 16, WXB = NBE * JX * 1024;
+    static constexpr int EBYTES = NIB * 16 * PITCH, LDS = EBYTES + WXB;
+    static_assert(HC % 32 == 0 && TOW % 2 == 0, "hidden chunk / tile geometry");
+};
+
+template <int KS, int S, int JX, int HC, int TOH, int TOW>
+__global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_px_kernel(MbParams p) {
+    typedef Xd<KS, S, HC, TOH, TOW, JX> G;
+    constexpr int IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, NT = G::NT, NPARW = G::NPARW, NW = G::NW;
+    constexpr int NBE = G::NBE, PITCH = G::PITCH, WXB = G::WXB, PPX = G::PPX, WPP = G::WPP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* E = smem;
+    char* Wst = smem + G::EBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.Wout + TOW - 1) / TOW;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int ox0 = txi * TOW, oy0 = tyi * TOH, b = blockIdx.z;
+    const int grp = blockIdx.y;                                      // hidden chunk of this workgroup
+
+    // expand weights of this chunk -> LDS (DMA); lands under the X loads, fenced by the barrier below
+    {
+        const char* srcx = (const char*)p.wexp + (size_t)grp * WXB;
+        for (int c = wave; c < WXB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(Wst + c * 1024), 16, 0, 0);
+    }
+    const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+    const unsigned rowbytes = (unsigned)p.Cin * 2;
+    auto load_x = [&](int ib, u32x4* xf) {
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < IPX ? ip : IPX - 1;
+        const int iy = ipc / IWP, ix = ipc - iy * IWP;
+        const int gy = oy0 * S - p.pad_lo + iy, gx = ox0 * S - p.pad_lo + ix;
+        const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+        const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const u32x4 v = ld16(xbase + off + j * 16);
+            xf[j].x = valid ? v.x : 0u; xf[j].y = valid ? v.y : 0u; xf[j].z = valid ? v.z : 0u; xf[j].w = valid ? v.w : 0u;
+        }
+    };
+    u32x4 xa[JX];
+    if (wave < NIB) load_x(wave, xa);
+    __syncthreads();
+
+    // ---- phase 1: expand + Swish -> pixel-pair tile
+    for (int ib = wave; ib < NIB; ib += NW) {
+        u32x4 xn[JX];
+        const bool more = ib + NW < NIB;
+        if (more) load_x(ib + NW, xn);                             // next block's X under this block's math
+#pragma unroll
+        for (int nbl = 0; nbl < NBE; ++nbl) {
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+            const char* wb = Wst + (nbl * JX * 64 + lane) * 16;
+#pragma unroll
+            for (int j = 0; j < JX; ++j) {
+                const u32x4 wv = ld16(wb + j * 1024);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xa[j]),
+                                                            __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
+            }
+            char* ecol = E + (nbl * 32 + pl) * 4 + (unsigned)(ib * 16 + 2 * h) * (unsigned)PITCH;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f32x2 x2; x2.x = a[2 * t]; x2.y = a[2 * t + 1];
+                const f32x2 y2 = swish2_prescaled(x2);
+                *reinterpret_cast<uint32_t*>(ecol + ((t & 1) + 4 * (t >> 1)) * PITCH) =
+                    __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xa[j] = xn[j];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: depthwise + Swish, one output pixel per lane, all HC channels of this chunk
+    const int par = S == 1 ? wave / WPP : 0;
+    const int r = (S == 1 ? wave - par * WPP : wave) * 64 + lane;      // index within the parity class
+    const bool live = r < PPX;
+    const int rc = live ? r : PPX - 1;
+    int oy, ox;
+    if constexpr (S == 1) { oy = rc / (TOW / 2); ox = 2 * (rc - oy * (TOW / 2)) + par; }
+    else { oy = rc / TOW; ox = rc - oy * TOW; }
+    const char* eb0 = E + (unsigned)(((oy * S) * IWP + (ox * S - par)) / 2) * (unsigned)PITCH;
+    const int gy = oy0 + oy, gx = ox0 + ox;
+    const bool store = live && gy < p.Hout && gx < p.Wout;
+    char* out = (char*)p.y + ((((size_t)b * p.Hout + gy) * p.Wout + gx) * p.hid + (size_t)grp * HC) * 2;
+    const CF_AS4 u32x8* wtab = (const CF_AS4 u32x8*)p.wdw;
+#pragma unroll
+    for (int c = 0; c < HC / 8; ++c) {
+        float a8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = 0.0f;
+        const CF_AS4 u32x8* wq = wtab + (size_t)(((grp * NPARW + par) * (HC / 8) + c) * KS) * NT;
+        const char* eb = eb0 + c * 32;
+        u32x8 wn[NT]; u32x4 en[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { wn[t] = wq[t]; en[t][0] = ld16(eb + t * PITCH); en[t][1] = ld16(eb + t * PITCH + 16); }
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            u32x8 wc[NT]; u32x4 ec[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { wc[t] = wn[t]; ec[t][0] = en[t][0]; ec[t][1] = en[t][1]; }
+            if (ky + 1 < KS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const char* et = eb + ((ky + 1) * (IWP / 2) + t) * PITCH;
+                    wn[t] = wq[(ky + 1) * NT + t]; en[t][0] = ld16(et); en[t][1] = ld16(et + 16);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                dot2c(a8[0], wc[t][0], ec[t][0].x); dot2c(a8[1], wc[t][1], ec[t][0].y);
+                dot2c(a8[2], wc[t][2], ec[t][0].z); dot2c(a8[3], wc[t][3], ec[t][0].w);
+                dot2c(a8[4], wc[t][4], ec[t][1].x); dot2c(a8[5], wc[t][5], ec[t][1].y);
+                dot2c(a8[6], wc[t][6], ec[t][1].z); dot2c(a8[7], wc[t][7], ec[t][1].w);
+            }
+        }
+        // a8 = -log2(e) * depthwise output -> swish, with the leftover -log2(e) taken out again
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            f32x2 u; u.x = a8[i]; u.y = a8[i + 1];
+            const f32x2 y = swish2_prescaled(u) * kNegLn2;
+            a8[i] = y.x; a8[i + 1] = y.y;
+        }
+        if (store) st16(out + c * 16, pack16<bf16_t>(a8));
+    }
+}
+
+struct XdEntry {
+    int k, s, jx, hc, toh, tow, var, lds_bytes, nt, nparw, nw;
+    hipError_t (*fn)(hipStream_t, const MbParams&);
+};
+template <int KS, int S, int JX, int HC, int TOH, int TOW>
+static hipError_t xd_launch_t(hipStream_t s, const MbParams& p) {
+    typedef Xd<KS, S, HC, TOH, TOW, JX> G;
+    auto kfn = expdw_px_kernel<KS, S, JX, HC, TOH, TOW>;
+    static thread_local bool configured = false;
+    if (G::LDS > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid(((p.Wout + TOW - 1) / TOW) * ((p.Hout + TOH - 1) / TOH), p.hid / HC, p.B), blk(G::NW * 64);
+    set_kernel_tag("void cf::expdw_px_kernel<%d, %d, %d, %d, %d, %d>(cf::MbParams)", KS, S, JX, HC, TOH, TOW);
+    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
+    return hipGetLastError();
+}
+#define XD(V, KS, S, JX, HC, TOH, TOW)                                                                             \
+    {KS, S, JX, HC, TOH, TOW, V, Xd<KS, S, HC, TOH, TOW, JX>::LDS, Xd<KS, S, HC, TOH, TOW, JX>::NT, Xd<KS, S, HC, TOH, TOW, JX>::NPARW, \
+     Xd<KS, S, HC, TOH, TOW, JX>::NW, &xd_launch_t<KS, S, JX, HC, TOH, TOW>}
+static const XdEntry kXdTable[] = {
+    //  var KS S JX HC  tile
+    XD(0, 5, 2, 6, 32, 10, 20),     // 5.0   96 -> 576, 40x40 -> 20x20
+    XD(0, 5, 1, 10, 32, 10, 20),    // 5.1  160 -> 960, 20x20
+    XD(0, 3, 1, 10, 32, 10, 20),    // 6.0  160 -> 960, 20x20
+    XD(1, 5, 2, 6, 32, 5, 20),
+    XD(1, 5, 1, 10, 64, 10, 20),
+    XD(1, 3, 1, 10, 64, 10, 20),
+    XD(2, 5, 2, 6, 64, 5, 20),
+    XD(2, 5, 1, 10, 32, 20, 20),
+    XD(2, 3, 1, 10, 32, 20, 20),
+};
+#undef XD
+static const XdEntry* xd_find(int k, int s, int jx) {
+    static const int want = getenv("CF_XD_VARIANT") ? atoi(getenv("CF_XD_VARIANT")) : 0;
+    const XdEntry* base = nullptr;
+    for (const XdEntry& e : kXdTable)
+        if (e.k == k && e.s == s && e.jx == jx) {
+            if (e.var == want) return &e;
+            if (e.var == 0) base = &e;
+        }
+    return base;
+}
+
+// geometry of the expand+depthwise kernel for a block (bf16 storage): MbGeom with kind = 2
+MbGeom expdw_geometry(int dtype, int Cin, int hid, int k, int s) {
+    MbGeom g{};
+    static const bool off = getenv("CF_XD_KIND") && atoi(getenv("CF_XD_KIND")) == 0;
+    if (off || dtype != 1 || (Cin % 8) || hid == Cin) return g;
+    const int jx = (Cin * 2 / 16 + 1) / 2;
+    const XdEntry* e = xd_find(k, s, jx);
+    if (!e || hid % e->hc) return g;
+    g.ok = true; g.kind = 2; g.S = s;
+    g.JX = jx; g.NBO = 0; g.HC = e->hc; g.nq = hid / e->hc; g.NBE = e->hc / 32; g.HALF = 0;
+    g.rowb = e->hc * 4 + 16;
+    g.lds_bytes = (size_t)e->lds_bytes;
+    g.wexp_bytes = (size_t)g.nq * g.NBE * g.JX * 64 * 16;
+    g.wdw_floats = (size_t)g.nq * e->nparw * (g.HC / 8) * k * e->nt * 8;
+    g.wproj_bytes = 0;
+    return g;
+}
+hipError_t expdw_launch(hipStream_t s, const MbParams& p) {
+    const XdEntry* e = xd_find(p.k, p.s, p.JX);
+    if (!e || e->hc != p.HC) return hipErrorInvalidValue;
+    return e->fn(s, p);
+}
+
 // ---------------------------------------------------------------- host side
 struct Mb2Entry {
     int k, s, jx, hc, nbo, res, toh, tow, nw, var;
@@ -443,7 +664,7 @@ void mb2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const 
                       void* wexp_host, float* wdw_host, void* wproj_host) {
     const int NCx = Cin * 2 / 16, NT = (k + 1) / 2, NPARW = g.S == 1 ? 2 : 1;
     __builtin_memset(wexp_host, 0, g.wexp_bytes);
-    __builtin_memset(wproj_host, 0, g.wproj_bytes);
+    if (wproj_host) __builtin_memset(wproj_host, 0, g.wproj_bytes);
     uint32_t* wt = reinterpret_cast<uint32_t*>(wdw_host);
     for (int q = 0; q < g.nq; ++q) {
         // expand, MFMA B operand: lane (n = channel, half h) holds Cin chunk h*JX + j of hidden channel q*HC + nbl*32 + n
@@ -469,7 +690,7 @@ void mb2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const 
                             wt[((((size_t)(q * NPARW + par) * (g.HC / 8) + c) * k + ky) * NT + t) * 8 + i] = (uint32_t)lo | ((uint32_t)hi << 16);
                         }
         // project, MFMA A operand (same layout as cf_mbconv.hip)
-        for (int nbo = 0; nbo < g.NBO; ++nbo)
+        for (int nbo = 0; wproj_host && nbo < g.NBO; ++nbo)
             for (int j = 0; j < g.HALF; ++j)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int i = lane & 31, hh = lane >> 5;

@@ -32,8 +32,8 @@ const int kSettings[7][5] = {  // t, c, n, s, k -- model/centernet.py:211-219
     {1, 16, 1, 1, 3}, {6, 24, 2, 2, 3}, {6, 32, 2, 2, 5}, {6, 64, 2, 2, 3},
     {6, 96, 2, 1, 5}, {6, 160, 2, 2, 5}, {6, 320, 1, 1, 3}};
 
-enum OpKind { OP_STEM = 0, OP_PW, OP_DW, OP_HEAD, OP_MB, OP_STEM0 };
-const char* kKindName[] = {"stem", "pw", "dw", "head", "mbconv", "stem0"};
+enum OpKind { OP_STEM = 0, OP_PW, OP_DW, OP_HEAD, OP_MB, OP_STEM0, OP_EXPDW };
+const char* kKindName[] = {"stem", "pw", "dw", "head", "mbconv", "stem0", "expdw"};
 
 struct Op {
     OpKind kind;
@@ -160,6 +160,17 @@ void build_plan(cf_ctx* c) {
                 continue;
             }
             int src = cur, j = 0;
+            MbGeom xg = (t != 1 && !(c->flags & CF_FLAG_NO_FUSE)) ? expdw_geometry(c->dtype, cin, hid, k, s) : MbGeom{};
+            if (xg.ok) {
+                // expand + depthwise in one launch (cf_mbconv2.hip), project stays a GEMM: blocks too wide to fuse fully
+                Op m; m.kind = OP_EXPDW; m.name = std::string(pre) + ".expand+dw"; m.in = cur; m.out = D;
+                m.Hin = curH; m.Win = curW; m.Cin = cin; m.hid = hid; m.Hout = Ho; m.Wout = Wo; m.Cout = hid;
+                m.k = k; m.s = s; m.pad_lo = p / 2; m.geo = xg;
+                m.wkey = std::string(pre) + ".conv.0.1.weight"; m.wkey_dw = std::string(pre) + ".conv.1.1.weight";
+                m.macs = (double)curH * curW * cin * hid + (double)Ho * Wo * hid * k * k;
+                push(m);
+                j = 1;
+            } else {
             if (t != 1) {                         // expand pw + Swish (:109-110)
                 Op e; e.kind = OP_PW; e.name = std::string(pre) + ".expand"; e.in = cur; e.out = E;
                 e.Hin = e.Hout = curH; e.Win = e.Wout = curW; e.Cin = cin; e.Cout = hid; e.act = 1;
@@ -172,6 +183,7 @@ void build_plan(cf_ctx* c) {
             d.wkey = std::string(pre) + ".conv." + std::to_string(j) + ".1.weight";
             d.macs = (double)Ho * Wo * hid * k * k;
             push(d);
+            }
             Op pr; pr.kind = OP_PW; pr.name = std::string(pre) + ".project"; pr.in = D; pr.out = dst;
             pr.res = residual ? cur : -1;
             pr.Hin = pr.Hout = Ho; pr.Win = pr.Wout = Wo; pr.Cin = hid; pr.Cout = cout; pr.act = 0;
@@ -376,6 +388,11 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
             if (!r) r = expect(c, ws, op.wkey_proj, {op.Cout, op.hid, 1, 1});
             expected_keys += 3;
         }
+        else if (op.kind == OP_EXPDW) {
+            r = expect(c, ws, op.wkey, {op.hid, op.Cin, 1, 1});
+            if (!r) r = expect(c, ws, op.wkey_dw, {op.hid, 1, op.k, op.k});
+            expected_keys += 2;
+        }
         else if (op.kind == OP_PW) {
             r = expect(c, ws, op.wkey, {op.Cout, op.Cin, 1, 1}); expected_keys += 1;
             if (!r && !op.bnkey.empty()) { r = expect_bn(c, ws, op.bnkey, op.Cout); expected_keys += 5; }
@@ -425,6 +442,12 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
             r = upload(c, wd, &op.wdw); if (r) return r;
             r = upload_bytes(c, wp, &op.wproj); if (r) return r;
             r = upload(c, lut, &op.upw); if (r) return r;
+        } else if (op.kind == OP_EXPDW) {
+            std::vector<char> we(op.geo.wexp_bytes);
+            std::vector<float> wd(op.geo.wdw_floats);
+            mb_pack_weights(dt, op.geo, op.Cin, op.hid, op.hid, op.k, ws.f(op.wkey), ws.f(op.wkey_dw), nullptr, we.data(), wd.data(), nullptr);
+            int r = upload_bytes(c, we, &op.wexp); if (r) return r;
+            r = upload(c, wd, &op.wdw); if (r) return r;
         } else if (op.kind == OP_MB) {
             std::vector<char> we(op.geo.wexp_bytes), wp(op.geo.wproj_bytes);
             std::vector<float> wd(op.geo.wdw_floats);
@@ -520,6 +543,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
             p.wproj = op.wproj; p.y = bp(op.out); p.B = B; p.H = op.Hin; p.W = op.Win; p.kind = op.geo.kind;
             return launch_stem0(c->stream, c->dtype, p);
         }
+        case OP_EXPDW:
         case OP_MB: {
             MbParams p{}; p.x = bp(op.in); p.y = bp(op.out); p.wexp = op.wexp; p.wdw = op.wdw; p.wproj = op.wproj;
             p.B = B; p.Hin = op.Hin; p.Win = op.Win; p.Hout = op.Hout; p.Wout = op.Wout; p.Cin = op.Cin; p.hid = op.hid; p.Cout = op.Cout;
