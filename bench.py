@@ -196,9 +196,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch=%d %dx%d %s on 1 MI355X per rank, forward + top-%d peak decode%s; "
+            "config": {"workload": "%s: batch=%d %dx%d %s on 1 MI355X per rank, forward + top-%d peak decode%s; "
                                    "synthetic uint8 images resident in HBM, calibrated synthetic weights (seed 0)"
-                                   % (B, S, S, args.dtype, K, " + RCCL all-gather of boxes" if world > 1 else ""),
+                                   % ("BASELINE configs[1]" if (B, S, K, args.dtype) == (64, 640, 100, "bf16") else
+                                      "BASELINE configs[4] per-GPU shard" if (S, K) == (1280, 1000) else "custom (not a BASELINE config)",
+                                      B, S, S, args.dtype, K, " + RCCL all-gather of boxes" if world > 1 else ""),
                        "batch_per_gpu": B, "global_batch": B * world, "image": [S, S], "topk": K,
                        "parallelism": "dp%d" % world},
             "roofline": roofline,
