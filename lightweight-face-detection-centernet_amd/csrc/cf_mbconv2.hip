@@ -87,16 +87,23 @@ struct Px {
     static constexpr int IH = (TOH - 1) * S + KS, IW0 = (TOW - 1) * S + KS, IWP = (IW0 + 1) & ~1;
     static constexpr int IPX = IH * IWP, NIB = (IPX + 31) / 32, NPAIR = IPX / 2;
     static constexpr int NT = (KS + 1) / 2, NPARW = S == 1 ? 2 : 1;
-    static constexpr int NPIX = TOH * TOW, NPB = NPIX / 32, NPP = NPB / 2, KG = NW / NPP;
+    // a wave owns 64 output pixels of one x parity (stride 1) -- the last wave of a parity class may be
+    // partly filled (8x40 tile: 160 pixels per parity = 2.5 waves)
+    static constexpr int NPIX = TOH * TOW, PPX = S == 1 ? NPIX / 2 : NPIX, WPP = (PPX + 63) / 64;
+    static constexpr int NPP = NPARW * WPP, KG = NW / NPP;
     static constexpr int NBE = (HC + 31) / 32, HALF = HC / 16, JS = HALF / KG;
+    // a trailing half block of 16 channels (hid = 144 = 3 x 48) runs on two 16x16x32 MFMAs (16 pixels x 16
+    // channels each, K = 32 >= Cin) instead of a half-empty 32x32 block: no Swish on dead lanes
+    static constexpr bool PART = (HC % 32 == 16);
+    static constexpr int NBF = HC / 32;
     static constexpr int PITCH = HC * 4 + 16;
-    static constexpr int WXB = NBE * JX * 1024;
+    static constexpr int WXB = (NBF * JX + (PART ? 1 : 0)) * 1024;
+    static_assert(!PART || JX <= 2, "half block needs Cin <= 32");
     static constexpr int EBYTES = NIB * 16 * PITCH;          // whole pixel blocks: phase 1 stores are unconditional
     static constexpr int RED = (KG - 1) * NPP * 64 * 64;
     static constexpr int LDS = (EBYTES + 2 * WXB) > RED ? (EBYTES + 2 * WXB) : RED;
-    static_assert(NPB * 32 == NPIX && NPP * 2 == NPB && NPP * KG == NW, "tile / wave geometry");
+    static_assert(NPP * KG == NW && TOW % 2 == 0, "tile / wave geometry");
     static_assert(HC % 16 == 0 && JS * KG == HALF, "hidden chunk / k-group geometry");
-    static_assert(S == 2 || (NPIX / 2) % 64 == 0, "a wave's 64 pixels must share one x parity");
 };
 
 // ---------------------------------------------------------------- device
@@ -104,7 +111,8 @@ template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, i
 __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     typedef Px<KS, S, HC, TOH, TOW, JX, NW> G;
     constexpr int IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, NPAIR = G::NPAIR, NT = G::NT, NPARW = G::NPARW;
-    constexpr int NPP = G::NPP, KG = G::KG, NBE = G::NBE, HALF = G::HALF, JS = G::JS, PITCH = G::PITCH, WXB = G::WXB;
+    constexpr int NPP = G::NPP, KG = G::KG, NBF = G::NBF, HALF = G::HALF, JS = G::JS, PITCH = G::PITCH, WXB = G::WXB;
+    constexpr bool PART = G::PART;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* E = smem;
     char* Wst = smem + G::EBYTES;
@@ -116,17 +124,19 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     const int nq = p.nq;
     const int pp = wave % NPP, jg = wave / NPP;
 
-    // tile pixel u -> (oy, ox); stride 1: all even-x pixels first, then all odd-x ones
-    auto tile_pixel = [](int u, int& oy, int& ox) {
-        if constexpr (S == 1) {
-            constexpr int HP = TOH * TOW / 2, HW = TOW / 2;
-            const int par = u / HP, r = u - par * HP;
-            oy = r / HW; ox = 2 * (r - oy * HW) + par;
-        } else { oy = u / TOW; ox = u - oy * TOW; }
+    // wave-uniform x parity (stride 2: x0 = 2 ox is always even) and the wave's first pixel in its class
+    const int par = S == 1 ? pp / G::WPP : 0;
+    const int r0 = (S == 1 ? pp - par * G::WPP : pp) * 64;
+    // pixel `blk * 32 + lane` of this wave -> (oy, ox); false when the slot is past the end of the class
+    auto tile_pixel = [&](int blk, int lane31, int& oy, int& ox) -> bool {
+        const int r = r0 + blk * 32 + lane31;
+        const int rc = r < G::PPX ? r : G::PPX - 1;
+        if constexpr (S == 1) { oy = rc / (TOW / 2); ox = 2 * (rc - oy * (TOW / 2)) + par; }
+        else { oy = rc / TOW; ox = rc - oy * TOW; }
+        return r < G::PPX;
     };
-    const int par = S == 1 ? (pp * 64) / (TOH * TOW / 2) : 0;          // wave-uniform x parity (stride 2: x0 = 2 ox is even)
-    // phase 2: this lane's depthwise pixel = pixel pl of block (2 pp + h)
-    int dy, dx; tile_pixel((pp * 2 + h) * 32 + pl, dy, dx);
+    // phase 2: this lane's depthwise pixel = pixel pl of block h of the wave
+    int dy, dx; tile_pixel(h, pl, dy, dx);
     const unsigned e_pix = (unsigned)(((dy * S) * IWP + (dx * S - par)) / 2) * (unsigned)PITCH;
 
     f32x16 acc[2][NBO];
@@ -170,10 +180,48 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
         }
     }
 
-    // expand one halo pixel block: D[pixel][channel] = X . We^T, Swish, pixel pairs -> E
-    auto expand_block = [&](int ib, const u32x4* xfr, const char* wx) {
+    // half block: A operands of the 16x16x32 MFMAs, lane (m = pixel of the 16-pixel sub-block, kg = Cin chunk)
+    u32x4 xh[PART ? MAXI : 1][2];
+    if constexpr (PART) {
 #pragma unroll
-        for (int nbl = 0; nbl < NBE; ++nbl) {
+        for (int t = 0; t < MAXI; ++t)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int ib = wave + NW * t;
+                const int ip = ib * 32 + sub * 16 + (lane & 15), kg = lane >> 4;
+                const int ipc = ip < IPX ? ip : IPX - 1;
+                const int iy = ipc / IWP, ix = ipc - iy * IWP;
+                const int gy = oy0 * S - p.pad_lo + iy, gx = ox0 * S - p.pad_lo + ix;
+                const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win && kg * 8 < p.Cin;
+                const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+                const u32x4 v = ld16(xbase + ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(min(kg * 8, p.Cin - 8) * 2));
+                xh[t][sub].x = valid ? v.x : 0u; xh[t][sub].y = valid ? v.y : 0u;
+                xh[t][sub].z = valid ? v.z : 0u; xh[t][sub].w = valid ? v.w : 0u;
+            }
+    }
+
+    // expand one halo pixel block: D[pixel][channel] = X . We^T, Swish, pixel pairs -> E
+    auto expand_block = [&](int ib, const u32x4* xfr, const u32x4* xhr, const char* wx) {
+        if constexpr (PART) {
+            const u32x4 wv = ld16(wx + (NBF * JX * 64 + lane) * 16);
+            char* ecol = E + (NBF * 32 + (lane & 15)) * 4 + (unsigned)(ib * 16 + 2 * (lane >> 4)) * (unsigned)PITCH;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, xhr[sub]),
+                                                             __builtin_bit_cast(mfma_bf16x8, wv), a4, 0, 0, 0);
+                // lane (channel n, row group g): rows 4g .. 4g+3 of the sub-block = pixel pairs 2g, 2g+1
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x2 x2; x2.x = a4[2 * t]; x2.y = a4[2 * t + 1];
+                    const f32x2 y2 = swish2_prescaled(x2);
+                    *reinterpret_cast<uint32_t*>(ecol + (sub * 8 + t) * PITCH) =
+                        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
+                }
+            }
+        }
+#pragma unroll
+        for (int nbl = 0; nbl < NBF; ++nbl) {
             f32x16 a;
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = 0.0f;
@@ -185,7 +233,6 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
                                                             __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
             }
             const int ch = nbl * 32 + pl;
-            const bool chok = (HC % 32 == 0) || ch < HC;
             // registers 2t, 2t+1 = MFMA rows m, m+1 (m even): pixel pair (ib*32 + m) / 2 = ib*16 + m2(t)
             char* ecol = E + ch * 4 + (unsigned)(ib * 16 + 2 * h) * (unsigned)PITCH;
             uint32_t d[8];
@@ -195,11 +242,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
                 const f32x2 y2 = swish2_prescaled(x2);            // E' = -log2(e) swish(expand)
                 d[t] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
             }
-            if (chok) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    *reinterpret_cast<uint32_t*>(ecol + ((t & 1) + 4 * (t >> 1)) * PITCH) = d[t];
-            }
+            for (int t = 0; t < 8; ++t)
+                *reinterpret_cast<uint32_t*>(ecol + ((t & 1) + 4 * (t >> 1)) * PITCH) = d[t];
         }
     };
 
@@ -255,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
 #pragma unroll
         for (int t = 0; t < MAXI; ++t) {
             const int ib = wave + NW * t;
-            if (ib < NIB) expand_block(ib, xf[t], wx);
+            if (ib < NIB) expand_block(ib, xf[t], xh[PART ? t : 0], wx);
         }
         __syncthreads();
         if (q + 1 < nq) stage_weights(q + 1);
@@ -323,9 +368,10 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     // ---- epilogue: accumulator k holds pixel block 2 pp + k (lane = pixel pl, half h = 16 channels)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        int oy, ox; tile_pixel((pp * 2 + k) * 32 + pl, oy, ox);
+        int oy, ox;
+        const bool livepx = tile_pixel(k, pl, oy, ox);
         const int gy = oy0 + oy, gx = ox0 + ox;
-        if (gy >= p.Hout || gx >= p.Wout) continue;
+        if (!livepx || gy >= p.Hout || gx >= p.Wout) continue;
         const size_t opix = ((size_t)b * p.Hout + gy) * p.Wout + gx;
 #pragma unroll
         for (int i = 0; i < NBO; ++i) {
@@ -573,7 +619,7 @@ hipError_t expdw_launch(hipStream_t s, const MbParams& p) {
 // ---------------------------------------------------------------- host side
 struct Mb2Entry {
     int k, s, jx, hc, nbo, res, toh, tow, nw, var;
-    int lds_bytes, nt, nparw, nbe, half;
+    int lds_bytes, nt, nparw, nbe, half, wxb;
     hipError_t (*fn)(hipStream_t, const MbParams&);
 };
 
@@ -596,7 +642,7 @@ static hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
 #define MB2(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW)                                                               \
     {KS, S, JX, HC, NBO, RES, TOH, TOW, NW, V, Px<KS, S, HC, TOH, TOW, JX, NW>::LDS, Px<KS, S, HC, TOH, TOW, JX, NW>::NT, \
      Px<KS, S, HC, TOH, TOW, JX, NW>::NPARW, Px<KS, S, HC, TOH, TOW, JX, NW>::NBE, Px<KS, S, HC, TOH, TOW, JX, NW>::HALF,  \
-     &mb2_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW>}
+     Px<KS, S, HC, TOH, TOW, JX, NW>::WXB, &mb2_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW>}
 static const Mb2Entry kMb2Table[] = {
     //  var KS S JX HC NBO res  tile  waves
     MB2(0, 3, 2, 1, 32, 1, 0, 8, 16, 4),    // 1.0  16 ->  96 -> 24
@@ -653,7 +699,7 @@ bool mb2_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
     g.JX = jx; g.NBO = nbo; g.HC = e->hc; g.nq = hid / e->hc; g.NBE = e->nbe; g.HALF = e->half;
     g.rowb = e->hc * 4 + 16;
     g.lds_bytes = (size_t)e->lds_bytes;
-    g.wexp_bytes = (size_t)g.nq * g.NBE * g.JX * 64 * 16;
+    g.wexp_bytes = (size_t)g.nq * e->wxb;
     g.wdw_floats = (size_t)g.nq * e->nparw * (g.HC / 8) * k * e->nt * 8;    // dwords (fp16 tap pairs)
     g.wproj_bytes = (size_t)g.NBO * g.nq * g.HALF * 64 * 16;
     return true;
@@ -667,16 +713,27 @@ void mb2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const 
     if (wproj_host) __builtin_memset(wproj_host, 0, g.wproj_bytes);
     uint32_t* wt = reinterpret_cast<uint32_t*>(wdw_host);
     for (int q = 0; q < g.nq; ++q) {
-        // expand, MFMA B operand: lane (n = channel, half h) holds Cin chunk h*JX + j of hidden channel q*HC + nbl*32 + n
-        for (int nbl = 0; nbl < g.NBE; ++nbl)
+        // expand, MFMA B operand: lane (n = channel, half h) holds Cin chunk h*JX + j of hidden channel q*HC + nbl*32 + n;
+        // a trailing 16-channel half block (kind 1 only) is one 16x16x32 fragment: lane (n = channel, kg = Cin chunk)
+        const bool part = g.kind == 1 && (g.HC % 32 == 16);
+        const int nbf = part ? g.HC / 32 : g.NBE;
+        const size_t wxb = ((size_t)nbf * g.JX + (part ? 1 : 0)) * 1024;
+        for (int nbl = 0; nbl < nbf; ++nbl)
             for (int j = 0; j < g.JX; ++j)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int n = lane & 31, hh = lane >> 5;
                     const int cl = nbl * 32 + n, c = hh * g.JX + j;
                     if (cl >= g.HC || c >= NCx) continue;
-                    uint16_t* dst = (uint16_t*)((char*)wexp_host + ((((size_t)q * g.NBE + nbl) * g.JX + j) * 64 + lane) * 16);
+                    uint16_t* dst = (uint16_t*)((char*)wexp_host + (size_t)q * wxb + (((size_t)nbl * g.JX + j) * 64 + lane) * 16);
                     for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLog2e * we[(size_t)(q * g.HC + cl) * Cin + (size_t)c * 8 + e]);
                 }
+        if (part)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 15, kg = lane >> 4;
+                if (kg >= NCx) continue;
+                uint16_t* dst = (uint16_t*)((char*)wexp_host + (size_t)q * wxb + ((size_t)nbf * g.JX * 64 + lane) * 16);
+                for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLog2e * we[(size_t)(q * g.HC + nbf * 32 + n) * Cin + (size_t)kg * 8 + e]);
+            }
         // depthwise tap pairs: [q][parity][chunk][ky][t][8 channels]; even x0: (w[2t], w[2t+1]), odd x0: (w[2t-1], w[2t])
         for (int par = 0; par < NPARW; ++par)
             for (int c = 0; c < g.HC / 8; ++c)
