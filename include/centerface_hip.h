@@ -78,7 +78,8 @@ int cf_load_weights(cf_ctx* ctx, const cf_tensor_desc* tensors, int n);
 
 /* ---- forward: replaces net(img)[0] (centerface.py:41, eval_widerface.py:83-84) ------------- */
 /* `in` is a host pointer (in_on_device = 0; copied H2D on the ctx stream) or a device pointer on
- * ctx's GPU (in_on_device = 1).  Asynchronous: returns after enqueueing. */
+ * ctx's GPU (in_on_device = 1; 4-byte aligned -- CF_EINVAL otherwise).  Asynchronous: returns after
+ * enqueueing. */
 int cf_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B);
 /* cv2.resize + forward in one enqueue (centerface.py:30-41): imgs uint8 [B,h,w,3] BGR of ANY size are
  * stretch-resized on the device to the ctx's (H, W) (bilinear, half-pixel centres, float32, round to

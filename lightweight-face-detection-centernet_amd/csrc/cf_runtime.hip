@@ -581,6 +581,8 @@ int stage_input(cf_ctx* c, const void* in, int in_format, int in_on_device, int 
     if (in_format != CF_IN_U8_HWC_BGR && in_format != CF_IN_F32_NCHW) return c->fail(CF_EINVAL, "unknown input format %d", in_format);
     HIPCHK(c, hipSetDevice(c->device));
     *net_in = in;
+    if (in_on_device && (reinterpret_cast<uintptr_t>(in) & 3))
+        return c->fail(CF_EINVAL, "cf_forward: device input must be 4-byte aligned (the stem reads it as dwords)");
     if (!in_on_device) {
         size_t bytes = (size_t)B * 3 * c->H * c->W * (in_format == CF_IN_U8_HWC_BGR ? 1 : 4);
         HIPCHK(c, hipMemcpyAsync(c->bufs[c->buf_in].p, in, bytes, hipMemcpyHostToDevice, c->stream));

@@ -268,6 +268,8 @@ typedef __attribute__((ext_vector_type(8))) uint32_t s0_u32x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 s0_hf2;
 #define S0_AS4 __attribute__((address_space(4)))
 constexpr int S0P_NT = 256, S0P_NW = 4;
+constexpr int S0P_ND = (S0_PW * 3 + 2 + 3) / 4;                     // 29 dwords cover a patch row (+2 bytes in front)
+constexpr int S0P_PROW = 120;                                      // >= 4 * S0P_ND elements, row pitch a multiple of 8 bytes
 constexpr int S0P_PITCH = 32 * 4 + 16;                             // one pixel pair, 32 channels (fp16 x 2) + pad
 constexpr int S0P_NIB = (S0_IPX + 31) / 32;                        // 11 halo pixel blocks
 static constexpr float kS0NegLog2e = -1.44269504088896341f, kS0NegLn2 = -0.69314718055994531f;
@@ -349,8 +351,7 @@ template <int FMT>
 __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
     typedef bf16_t T;
     __shared__ __attribute__((aligned(16))) char E[S0P_NIB * 16 * S0P_PITCH];
-    __shared__ __attribute__((aligned(16))) T Xs[S0_PH * S0_PROW];
-    __shared__ float lut[FMT == CF_IN_U8_HWC_BGR ? 768 : 1];
+    __shared__ __attribute__((aligned(16))) T Xs[S0_PH * S0P_PROW];      // patch row: 2 pad elements, then e = col*3 + ci
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -358,10 +359,54 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
     const int Ho = p.H >> 1, Wo = p.W >> 1;
     const int ox0 = blockIdx.x * S0_TOW, oy0 = blockIdx.y * S0_TOH, b = blockIdx.z;
 
-    // ---- stage the normalised image patch (as stem0_kernel, 256 threads: 2 patch rows per pass)
+    // ---- stage the normalised image patch
     const int iy0 = 2 * (oy0 - 1), ix0 = 2 * (ox0 - 1);
-    constexpr int ECOLS = S0_PW * 3, RSTEP = S0P_NT / ECOLS, NIT = (S0_PH + RSTEP - 1) / RSTEP;
-    {
+    if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+        // uint8 input: DWORD loads.  The patch row starts 6 (ox0 - 1) bytes into the image row, i.e. 2 bytes
+        // past a dword boundary (ox0 is a multiple of 16, W of 32), so the row is read as 29 aligned
+        // dwords starting 2 bytes early, and a dword lies entirely inside or entirely outside the image row.
+        // Thread = one dword column (fixed channel phase, fixed column validity) walking down the rows;
+        // normalisation is (u/255 - mean)/std as one fma per byte (1 ulp from the reference's two
+        // divisions, far below the bf16 rounding that follows); outside the image: exact 0 (ZeroPad2d).
+        constexpr int ND = S0P_ND, RG = S0P_NT / ND, NITD = (S0_PH + RG - 1) / RG;
+        const int d = tid % ND, rg = tid / ND;
+        const bool tact = rg < RG;
+        const int boff = ix0 * 3 - 2 + 4 * d;
+        const bool din = tact && boff >= 0 && boff + 4 <= p.W * 3;
+        const int cboff = min(max(boff, 0), p.W * 3 - 4);
+        float sc[4], sh[4]; bool bok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * d - 2 + i;                         // element of the patch row, e = col*3 + ci
+            bok[i] = din && e >= 0 && e < S0_PW * 3;
+            const int ci = (e + 3) % 3;
+            // centerface.py:12-15 (BGR): mean 0.408 0.447 0.470, std 0.289 0.274 0.278
+            sc[i] = ci == 0 ? 1.0f / (255.0f * 0.289f) : ci == 1 ? 1.0f / (255.0f * 0.274f) : 1.0f / (255.0f * 0.278f);
+            sh[i] = ci == 0 ? -0.408f / 0.289f : ci == 1 ? -0.447f / 0.274f : -0.470f / 0.278f;
+        }
+        uint32_t v[NITD];
+#pragma unroll
+        for (int it = 0; it < NITD; ++it) {
+            const int cy = min(max(iy0 + rg + it * RG, 0), p.H - 1);
+            v[it] = *reinterpret_cast<const uint32_t*>((const uint8_t*)p.x + ((size_t)b * p.H + cy) * p.W * 3 + cboff);
+        }
+#pragma unroll
+        for (int it = 0; it < NITD; ++it) {
+            const int r = rg + it * RG, iy = iy0 + r;
+            const bool rowok = (unsigned)iy < (unsigned)p.H;
+            float f[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float u = (float)((v[it] >> (8 * i)) & 0xffu);                 // v_cvt_f32_ubyteN
+                f[i] = (rowok && bok[i]) ? fmaf(u, sc[i], sh[i]) : 0.0f;
+            }
+            if (tact && r < S0_PH) {
+                u32x2 o; o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(Xs) + r * (S0P_PROW * 2) + d * 8) = o;
+            }
+        }
+    } else {
+        constexpr int ECOLS = S0_PW * 3, RSTEP = S0P_NT / ECOLS, NIT = (S0_PH + RSTEP - 1) / RSTEP;
         const int e = tid % ECOLS, r0 = tid / ECOLS;
         const bool tact = r0 < RSTEP;
         const int col = e / 3, ci = e - col * 3;
@@ -375,27 +420,13 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
             const int iy = iy0 + r;
             const bool ok = xok && r < S0_PH && (unsigned)iy < (unsigned)p.H;
             const int cy = min(max(iy, 0), p.H - 1);
-            if constexpr (FMT == CF_IN_U8_HWC_BGR) {
-                const uint32_t u = ((const uint8_t*)p.x)[(((size_t)b * p.H + cy) * p.W + cx) * 3 + ci];
-                v[it] = __uint_as_float(ok ? (u | (uint32_t)(ci << 8)) : 0xffffffffu);
-            } else {
-                const float f = ((const float*)p.x)[(((size_t)b * 3 + ci) * p.H + cy) * p.W + cx];
-                v[it] = ok ? f : 0.0f;
-            }
-        }
-        if constexpr (FMT == CF_IN_U8_HWC_BGR) {
-            for (int i = tid; i < 768; i += S0P_NT) lut[i] = p.lut[i];
-            __syncthreads();
+            const float f = ((const float*)p.x)[(((size_t)b * 3 + ci) * p.H + cy) * p.W + cx];
+            v[it] = ok ? f : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int r = r0 + it * RSTEP;
-            float val = v[it];
-            if constexpr (FMT == CF_IN_U8_HWC_BGR) {
-                const uint32_t idx = __float_as_uint(v[it]);
-                val = idx == 0xffffffffu ? 0.0f : lut[idx];
-            }
-            if (tact && r < S0_PH) Xs[r * S0_PROW + e] = (T)(pack_bf16x2(val, 0.0f) & 0xffffu);
+            if (tact && r < S0_PH) Xs[r * S0P_PROW + 2 + e] = (T)(pack_bf16x2(v[it], 0.0f) & 0xffffu);
         }
     }
     __syncthreads();
@@ -411,7 +442,7 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
         const int y = oy0 - 1 + ty, x = ox0 - 1 + tx;
         // a halo pixel outside the map is the depthwise conv's zero padding: zero operand row -> swish(0) = 0
         const bool inmap = ip < S0_IPX && (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo;
-        const T* xp = Xs + (2 * ty) * S0_PROW + (2 * tx) * 3;
+        const T* xp = Xs + (2 * ty) * S0P_PROW + (2 * tx) * 3 + 2;
         f32x16 a;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.0f;
@@ -422,8 +453,8 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
             for (int e2 = 0; e2 < 4; ++e2) {
                 const int t0 = c * 16 + h * 8 + 2 * e2, t1 = t0 + 1;
                 const int ky0 = t0 / 9, r0 = t0 - 9 * ky0, ky1 = t1 / 9, r1 = t1 - 9 * ky1;
-                const uint32_t lo = t0 < 27 ? (uint32_t)xp[ky0 * S0_PROW + r0] : 0u;
-                const uint32_t hi = t1 < 27 ? (uint32_t)xp[ky1 * S0_PROW + r1] : 0u;
+                const uint32_t lo = t0 < 27 ? (uint32_t)xp[ky0 * S0P_PROW + r0] : 0u;
+                const uint32_t hi = t1 < 27 ? (uint32_t)xp[ky1 * S0P_PROW + r1] : 0u;
                 w4[e2] = inmap ? (lo | (hi << 16)) : 0u;
             }
             u32x4 xc; xc.x = w4[0]; xc.y = w4[1]; xc.z = w4[2]; xc.w = w4[3];
