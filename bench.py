@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exercise-gather-path", action="store_true",
+                    help="run the N>1 step (stream-chained pack + gather, identity at world 1) on one GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--profile-reps", type=int, default=5)
     ap.add_argument("--traffic-json", default=None,
@@ -121,14 +123,18 @@ def main():
     torch.cuda.synchronize()
 
     eng = cfa.Engine(S, S, max_batch=B, dtype=args.dtype, device=local_rank)
+    # N > 1: the decode stream of the context and torch's stream (pack + RCCL all-gather) are chained with
+    # stream waits, never a host sync: the gather of step i runs underneath the forward of step i+1
+    multi = world > 1 or args.exercise_gather_path
+    dec_stream = torch.cuda.ExternalStream(eng.streams()[1], device=dev) if multi else None
 
     def step():
         eng.forward_enqueue(d_in.data_ptr(), on_device=True, B=B, in_format=cfa._lib.CF_IN_U8_HWC_BGR)
-        if world > 1:
-            torch.cuda.current_stream().synchronize()   # last step's pack/gather has consumed d_dets / d_lms
+        if multi:
+            dec_stream.wait_stream(torch.cuda.current_stream())      # last step's pack has consumed d_dets / d_lms
         eng.decode_topk_device(K, d_dets.data_ptr(), d_lms.data_ptr(), d_inds.data_ptr())
-        if world > 1:
-            eng.synchronize()                      # hand-off ctx stream -> torch stream for RCCL
+        if multi:
+            torch.cuda.current_stream().wait_stream(dec_stream)      # boxes are final before the pack reads them
             rec = cfa.distributed.pack_records(d_dets, d_lms)
             return cfa.distributed.gather_records(rec)
         return None

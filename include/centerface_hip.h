@@ -151,6 +151,11 @@ typedef struct cf_op_time {
 } cf_op_time;
 int cf_profile_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int K,
                        cf_op_time* out, int cap, int* n_out);
+/* The context's HIP streams as opaque hipStream_t values: `main_stream` carries the forward (and the
+ * host-output decodes), `decode_stream` the device-output top-K decode.  For callers that chain their own
+ * device work (e.g. an RCCL all-gather of the decoded boxes on another stream) with stream/event waits
+ * instead of cf_synchronize(). */
+int cf_get_streams(cf_ctx* ctx, void** main_stream, void** decode_stream);
 /* hipGraph replay state: number of captured forward graphs held by the context, and how many
  * (input, format, batch) keys could not be captured and run as eager launches instead. */
 int cf_graph_stats(cf_ctx* ctx, int* n_graphs, int* n_uncapturable);

@@ -205,6 +205,12 @@ class Engine(object):
         return [dict(name=r.name.decode(), kind=r.kind.decode(), kernel=r.kernel.decode(), ms=r.ms, algo_bytes=r.algo_bytes, flops=r.flops)
                 for r in rec[:n.value]]
 
+    def streams(self):
+        """(main, decode) hipStream_t handles as ints, e.g. for torch.cuda.ExternalStream."""
+        a, b = C.c_void_p(), C.c_void_p()
+        self._chk(self._L.cf_get_streams(self._h, C.byref(a), C.byref(b)))
+        return a.value or 0, b.value or 0
+
     def graph_stats(self):
         """(captured forward graphs, keys that fell back to eager launches)."""
         a, b = C.c_int(), C.c_int()

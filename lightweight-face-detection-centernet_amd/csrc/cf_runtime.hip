@@ -948,6 +948,13 @@ int cf_profile_forward(cf_ctx* c, const void* in, int in_format, int in_on_devic
     return CF_OK;
 }
 
+int cf_get_streams(cf_ctx* c, void** main_stream, void** decode_stream) {
+    if (!c) return CF_EINVAL;
+    if (main_stream) *main_stream = (void*)c->stream;
+    if (decode_stream) *decode_stream = (void*)c->stream2;
+    return CF_OK;
+}
+
 int cf_graph_stats(cf_ctx* c, int* n_graphs, int* n_uncapturable) {
     if (!c) return CF_EINVAL;
     int ng = 0, nb = 0;
