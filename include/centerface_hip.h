@@ -182,6 +182,12 @@ int cf_op_pwconv(int device, int dtype, const float* x, const float* w, const fl
 int cf_op_mbconv(int device, int dtype, const float* x, const float* w_exp, const float* w_dw,
                  const float* w_proj, float* y, int B, int Cin, int hid, int Cout, int H, int W,
                  int k, int stride);
+/* The first two thirds of MBConvBlock.forward (model/centernet.py:109-114): expand 1x1 + Swish, depthwise
+ * k x k (stride, `_get_padding`) + Swish, as ONE kernel (bf16 storage only; the path the engine uses for
+ * the blocks whose Cout is too wide to fuse the project conv as well).  y [B,hid,Ho,Wo].
+ * Returns CF_EINVAL for shapes / dtypes the kernel does not cover. */
+int cf_op_expand_dw(int device, int dtype, const float* x, const float* w_exp, const float* w_dw, float* y,
+                    int B, int Cin, int hid, int H, int W, int k, int stride);
 /* stem: ConvReLU(3,32,3,stride 2) on a normalised float NCHW tensor or a uint8 HWC BGR image
  * (model/centernet.py:224 ; centerface.py:32-37). y [B,32,H/2,W/2] */
 int cf_op_stem(int device, int dtype, const void* x, int in_format, const float* w, float* y,

@@ -159,6 +159,29 @@ int cf_op_mbconv(int device, int dtype, const float* x, const float* w_exp, cons
     return sc.result("cf_op_mbconv");
 }
 
+int cf_op_expand_dw(int device, int dtype, const float* x, const float* w_exp, const float* w_dw, float* y,
+                    int B, int Cin, int hid, int H, int W, int k, int stride) {
+    if (bad_dtype(dtype) || !x || !w_exp || !w_dw || !y || B < 1) return CF_EINVAL;
+    MbGeom g = expdw_geometry(dtype, Cin, hid, k, stride);
+    if (!g.ok) { g_op_error = "shape / dtype not covered by the expand+depthwise kernel"; return CF_EINVAL; }
+    const int pd = k - stride > 0 ? k - stride : 0;
+    const int Ho = (H + pd - k) / stride + 1, Wo = (W + pd - k) / stride + 1;
+    Scope sc(device);
+    std::vector<char> we(g.wexp_bytes);
+    std::vector<float> wd(g.wdw_floats);
+    mb_pack_weights(dtype, g, Cin, hid, hid, k, w_exp, w_dw, nullptr, we.data(), wd.data(), nullptr);
+    MbParams p{};
+    p.x = sc.to_nhwc(dtype, x, B, Cin, H, W);
+    p.y = sc.alloc((size_t)B * Ho * Wo * hid * elem_size(dtype));
+    p.wexp = sc.up(we.data(), we.size()); p.wdw = sc.upv(wd);
+    p.B = B; p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.Cin = Cin; p.hid = hid; p.Cout = hid;
+    p.k = k; p.s = stride; p.pad_lo = pd / 2;
+    p.HC = g.HC; p.nq = g.nq; p.NBE = g.NBE; p.JX = g.JX; p.rowb = g.rowb; p.lds_bytes = g.lds_bytes; p.kind = g.kind;
+    if (sc.err == hipSuccess) sc.chk(launch_mbconv(sc.s, dtype, p));
+    sc.to_host_nchw(dtype, p.y, y, B, hid, Ho, Wo);
+    return sc.result("cf_op_expand_dw");
+}
+
 int cf_op_stem(int device, int dtype, const void* x, int in_format, const float* w, float* y, int B, int H, int W) {
     if (bad_dtype(dtype) || !x || !w || !y || (H % 2) || (W % 2)) return CF_EINVAL;
     if (in_format != CF_IN_U8_HWC_BGR && in_format != CF_IN_F32_NCHW) return CF_EINVAL;

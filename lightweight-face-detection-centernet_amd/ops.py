@@ -56,6 +56,22 @@ def mbconv(x, w_exp, w_dw, w_proj, k, stride, dtype="fp32", device=0):
     return y
 
 
+def expand_dw(x, w_exp, w_dw, k, stride, dtype="bf16", device=0):
+    """Expand 1x1 + Swish -> depthwise k x k + Swish of an MBConv block (model/centernet.py:109-114) as the
+    single kernel the engine uses for the wide late blocks (bf16 storage only)."""
+    x = f32(x)
+    B, Cin, H, W = x.shape
+    w_exp = f32(np.asarray(w_exp).reshape(w_exp.shape[0], -1))
+    hid = w_exp.shape[0]
+    w_dw = f32(np.asarray(w_dw).reshape(hid, k * k))
+    p = max(k - stride, 0)
+    Ho, Wo = (H + p - k) // stride + 1, (W + p - k) // stride + 1
+    y = np.empty((B, hid, Ho, Wo), np.float32)
+    _lib.check(_lib.lib().cf_op_expand_dw(device, _DT[dtype], ptr(x), ptr(w_exp), ptr(w_dw), ptr(y),
+                                          B, Cin, hid, H, W, k, stride), op=True)
+    return y
+
+
 def stem(x, w, dtype="fp32", device=0):
     """first_conv (model/centernet.py:224): x uint8 [B,H,W,3] BGR (normalisation fused) or float32 [B,3,H,W]."""
     x = np.ascontiguousarray(x)

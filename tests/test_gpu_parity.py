@@ -570,6 +570,28 @@ def test_batch64_bf16_properties():
     eng.close()
 
 
+@pytest.mark.parametrize("cfg", [(96, 5, 2, 40, 40), (96, 5, 2, 23, 31), (160, 5, 1, 20, 20), (160, 5, 1, 13, 27),
+                                 (160, 3, 1, 20, 20), (160, 3, 1, 9, 41)])
+def test_expand_dw_kernel_vs_oracle(cfg):
+    """The expand+depthwise kernel of the wide late blocks (layer5.0 / 5.1 / 6.0 shapes; bf16 storage, fp16
+    tile) against the oracle's fp32 expand -> Swish -> depthwise -> Swish, incl. odd map sizes (edge tiles,
+    partly filled waves) and batch > 1."""
+    cin, k, s, H, W = cfg
+    rng = np.random.default_rng(cin + 10 * k + s + H)
+    hid = cin * 6
+    we = (rng.standard_normal((hid, cin, 1, 1)) * 1.5 / np.sqrt(cin)).astype(np.float32)
+    wd = (rng.standard_normal((hid, 1, k, k)) * 1.5 / k).astype(np.float32)
+    x = rng.standard_normal((2, cin, H, W)).astype(np.float32)
+    t = torch.from_numpy(x)
+    ref = O.conv_swish(O.conv_swish(t, torch.from_numpy(we), 1, 1), torch.from_numpy(wd), k, s, groups=hid).numpy()
+    y = ops.expand_dw(x, we, wd, k, s, dtype="bf16")
+    assert y.shape == ref.shape
+    d = np.abs(y - ref)
+    assert d.max() < 0.08 and d.mean() < 0.006, (float(d.max()), float(d.mean()))
+    with pytest.raises(ValueError):
+        ops.expand_dw(x, we, wd, k, s, dtype="fp32")           # bf16-only kernel: loud, no fallback
+
+
 @pytest.mark.parametrize("size", [(96, 128), (160, 224), (480, 640)])
 def test_bf16_engine_tracks_fp32_engine(size):
     """The bf16 throughput path (second-generation fused kernels: fp16 pixel-pair tiles, dot2c depthwise,
