@@ -194,6 +194,10 @@ def main():
             "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": avg_bytes,
             "launches_per_forward": dom["launches"] // args.profile_reps, "layers": sorted(dom["layers"]),
             "forward_ms_sum_of_kernels": round(tot_ms, 3),
+            # the fused kernels are VALU-issue bound (Swish: two transcendentals per expanded element), not HBM- or
+            # MFMA-bound: DESIGN.md section 4, profiles/r01_valu_microbench.md; whole-forward algorithmic rate:
+            "forward_algo_GBps": round(sum(a["bytes"] for a in agg.values()) / args.profile_reps / (tot_ms * 1e-3) / 1e9, 1),
+            "forward_TFLOPs": round(sum(a["flops"] for a in agg.values()) / args.profile_reps / (tot_ms * 1e-3) / 1e12, 1),
             "by_kind": {k: {"ms": round(v["ms"], 3), "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
                         for k, v in kinds.items()},
         }
