@@ -245,6 +245,9 @@ class CenterFace(object):
         self.engine = Engine(self.img_h_new, self.img_w_new, max_batch=max_batch, dtype=dtype,
                              device=device, weights=weights, collapse_heads=collapse_heads)
 
+    def close(self):
+        self.engine.close()
+
     # centerface.py:68-71
     def transform(self, h, w):
         img_h_new, img_w_new = int(np.ceil(h / 32) * 32), int(np.ceil(w / 32) * 32)
@@ -320,3 +323,52 @@ class CenterFace(object):
         _lib.check(L.cf_op_nms(self.device, _lib.ptr(boxes), _lib.ptr(scores), n, float(nms_thresh),
                                _lib.ptr(keep), C.byref(nk)), op=True)
         return [int(k) for k in keep[:nk.value]]
+
+
+class CenterFaceBuckets(object):
+    """Variable-size input (BASELINE configs[3]: WIDER-style images of different shapes in one batch).
+
+    The reference builds one ``CenterFace(h, w)`` per image shape (demo.py:76 even per image).  Here images are
+    bucketed by their network shape ``transform(h, w)`` (multiples of 32, centerface.py:68-71), every bucket
+    owns one ``CenterFace`` (one cf_ctx on the GPU, created on first use, all sharing the same weights), and
+    each bucket runs as full batches.  Results come back in the order of ``imgs``; every image gets exactly
+    what ``CenterFace(h, w)(img)`` returns for it."""
+
+    def __init__(self, landmarks=True, *, weights=None, dtype="fp32", device=0, max_batch=32, max_buckets=8, **kw):
+        self.landmarks, self.dtype, self.device, self.max_batch, self.max_buckets = landmarks, dtype, device, max_batch, max_buckets
+        self._weights = _weights.synthetic_state_dict(0) if weights is None else (
+            _weights.load_checkpoint(weights) if isinstance(weights, str) else weights)
+        self._kw = kw
+        self._buckets = {}          # (h, w) -> CenterFace, in least-recently-used order
+
+    def _detector(self, h, w):
+        key = (int(h), int(w))
+        det = self._buckets.pop(key, None)
+        if det is None:
+            if len(self._buckets) >= self.max_buckets:             # evict the least recently used context
+                old = next(iter(self._buckets))
+                self._buckets.pop(old).close()
+            det = CenterFace(h, w, self.landmarks, weights=self._weights, dtype=self.dtype, device=self.device,
+                             max_batch=self.max_batch, **self._kw)
+        self._buckets[key] = det
+        return det
+
+    def detect(self, imgs, threshold=0.2):
+        order = {}
+        for i, im in enumerate(imgs):
+            im = np.asarray(im)
+            order.setdefault(im.shape[:2], []).append(i)
+        out = [None] * len(imgs)
+        for (h, w), idx in order.items():
+            det = self._detector(h, w)
+            res = det.detect_batch([imgs[i] for i in idx], threshold)
+            for i, r in zip(idx, res):
+                out[i] = r
+        return out
+
+    __call__ = detect
+
+    def close(self):
+        for det in self._buckets.values():
+            det.close()
+        self._buckets = {}

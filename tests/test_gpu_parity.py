@@ -614,3 +614,23 @@ def test_bf16_engine_tracks_fp32_engine(size):
         border = np.concatenate([d[..., :2, :].ravel(), d[..., -2:, :].ravel(), d[..., :, :2].ravel(), d[..., :, -2:].ravel()])
         assert border.mean() < 3.0 * d.mean() + 1e-3, (k, float(border.mean()), float(d.mean()))
     e32.close(); e16.close()
+
+
+def test_variable_size_buckets_match_per_shape_detectors():
+    """BASELINE configs[3] (VGA-class images of different shapes in one batch): CenterFaceBuckets groups by
+    network shape and must return, per image and in input order, exactly what CenterFace(h, w)(img) returns."""
+    rng = np.random.default_rng(2024)
+    shapes = [(480, 640), (640, 480), (640, 640), (448, 640), (640, 416), (478, 720), (300, 500)]
+    imgs = [rng.integers(0, 256, shapes[i % len(shapes)] + (3,), dtype=np.uint8) for i in range(17)]
+    pool = cfa.CenterFaceBuckets(dtype="fp32", max_batch=4, max_buckets=4)        # fewer contexts than shapes: eviction
+    got = pool.detect(imgs)
+    assert len(got) == len(imgs)
+    for (h, w) in shapes:
+        one = cfa.CenterFace(h, w, dtype="fp32")
+        for i, im in enumerate(imgs):
+            if im.shape[:2] != (h, w):
+                continue
+            d, l = one(im)
+            assert d.shape == got[i][0].shape and np.array_equal(d, got[i][0]) and np.array_equal(l, got[i][1]), (i, h, w)
+        one.close()
+    pool.close()
