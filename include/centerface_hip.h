@@ -50,6 +50,8 @@ extern "C" {
 #define CF_FLAG_NO_GRAPH        2u   /* launch kernels eagerly instead of replaying a hipGraph */
 #define CF_FLAG_NO_FUSE         4u   /* run every MBConv block as three kernels (expand, dw, project)
                                         instead of the fused kernel that keeps the 6x tensor in LDS */
+#define CF_FLAG_NO_UPHEAD       8u   /* keep the last IDAUp stage and the heads as two kernels (bf16 +
+                                        collapsed heads fuse them, the neck output stays in LDS) */
 
 typedef struct cf_ctx cf_ctx;
 

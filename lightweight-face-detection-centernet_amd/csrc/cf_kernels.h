@@ -134,6 +134,22 @@ void head_pack_weights(int dtype, int collapsed, const float* w0, const float* b
                        float* w1d_host /*[96][16]*/, float* b1_host /*[16]*/);
 hipError_t launch_heads(hipStream_t s, int dtype, const HeadParams& p);
 
+// ------------------------------------------------------------------ IDAUp stage 3 + heads fused (bf16, collapsed heads)
+struct UpHeadParams {
+    const void* skip;     // [B][h][w][24] bf16: the IDAUp skip input (layer1 output)
+    const void* low;      // [B][h/2][w/2][24] bf16: previous IDAUp stage
+    const void* wcv;      // pw_pack_weights(24 -> 24, BN folded)
+    const float* bias;    // [24] BN shift of the 1x1 conv
+    const float* upw;     // [4][24] deconv tap * BN scale
+    const float* upb;     // [24]
+    const void* w0p;      // head_pack_weights(collapsed)
+    const float* b0;      // [16]
+    float* heads;         // [B][h][w][16] fp32
+    float* hm_plane;      // [B][h][w] or nullptr
+    int B, h, w;
+};
+hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p);
+
 // ------------------------------------------------------------------ decode
 // D3: 3x3 peak test + top-K (radix select + bitonic sort) + gather, one workgroup per image.
 struct TopkParams {

@@ -51,6 +51,9 @@ struct Op {
     int hid = 0; bool residual = false; std::string wkey_dw, wkey_proj;
     MbGeom geo{}; void* wexp = nullptr; float* wdw = nullptr; void* wproj = nullptr;
     double macs = 0;                                  // per image
+    // IDAUp stage 3 fused into the head kernel (cf_uphead.hip): the OP_PW op keeps its weights but is not
+    // launched (fused_away); the OP_HEAD op launches the fused kernel with its partner's operands
+    bool fused_away = false; int partner = -1;
 };
 
 struct Buf { std::string name; size_t elems = 0; bool f32 = false; void* p = nullptr; };
@@ -217,6 +220,13 @@ void build_plan(cf_ctx* c) {
     hd.macs = (c->flags & CF_FLAG_COLLAPSE_HEADS) ? (double)curH * curW * 216 * 15
                                                   : (double)curH * curW * (4 * 216 * 24 + 15 * 24);
     push(hd);
+    if (fuse && !(c->flags & CF_FLAG_NO_UPHEAD) && c->dtype == CF_BF16 && (c->flags & CF_FLAG_COLLAPSE_HEADS)) {
+        const int ih = (int)c->ops.size() - 1, iu = ih - 1;               // heads, up3
+        c->ops[iu].fused_away = true;
+        c->ops[ih].partner = iu;
+        c->ops[ih].name = "up3+heads";
+        c->ops[ih].macs += c->ops[iu].macs;
+    }
 }
 
 struct WeightSet {
@@ -520,6 +530,13 @@ namespace {
 
 hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format, int B) {
     auto bp = [&](int id) -> void* { return id < 0 ? nullptr : c->bufs[id].p; };
+    if (op.fused_away) return hipSuccess;
+    if (op.kind == OP_HEAD && op.partner >= 0) {
+        const Op& u = c->ops[op.partner];
+        UpHeadParams p{}; p.skip = bp(u.in); p.low = bp(u.low); p.wcv = u.wp; p.bias = u.bias; p.upw = u.upw; p.upb = u.upb;
+        p.w0p = op.wp; p.b0 = op.bias; p.heads = (float*)bp(op.out); p.hm_plane = c->hm_plane; p.B = B; p.h = op.Hout; p.w = op.Wout;
+        return launch_uphead(c->stream, p);
+    }
     switch (op.kind) {
         case OP_STEM: {
             StemParams p{}; p.x = net_in; p.in_format = in_format; p.w = op.wp; p.y = bp(op.out);
@@ -570,6 +587,7 @@ double op_bytes(const cf_ctx* c, const Op& op, int in_format, int B) {
     else in_b = (double)op.Hin * op.Win * op.Cin * es;
     if (op.kind == OP_HEAD) out_b = (double)op.Hout * op.Wout * 16 * 4;
     else out_b = (double)op.Hout * op.Wout * op.Cout * es;
+    if (op.kind == OP_HEAD && op.partner >= 0) in_b += (double)(op.Hout / 2) * (op.Wout / 2) * 24 * es;   // + the low IDAUp input
     if (op.res >= 0) in_b += (double)op.Hout * op.Wout * op.Cout * es;
     if (op.low >= 0) in_b += (double)(op.Hout / 2) * (op.Wout / 2) * op.Cout * es;
     return (in_b + out_b) * B;
@@ -900,7 +918,9 @@ int cf_profile_forward(cf_ctx* c, const void* in, int in_format, int in_on_devic
     const void* net_in = nullptr;
     int r = stage_input(c, in, in_format, in_on_device, B, &net_in);
     if (r) return r;
-    const int nops = (int)c->ops.size() + (K > 0 ? 1 : 0);
+    int nlaunch = 0;
+    for (auto& op : c->ops) nlaunch += op.fused_away ? 0 : 1;
+    const int nops = nlaunch + (K > 0 ? 1 : 0);
     if (cap < nops) return c->fail(CF_EINVAL, "cf_profile_forward: need room for %d records", nops);
     if (K > 0) { r = ensure_topk_ws(c, K); if (r) return r; }
     std::vector<hipEvent_t> ev(nops + 1);
@@ -909,6 +929,7 @@ int cf_profile_forward(cf_ctx* c, const void* in, int in_format, int in_on_devic
     HIPCHK(c, hipEventRecord(ev[0], c->stream));
     int i = 0;
     for (auto& op : c->ops) {
+        if (op.fused_away) continue;
         HIPCHK(c, launch_op(c, op, net_in, in_format, B));
         tags.push_back(last_kernel_tag());
         HIPCHK(c, hipEventRecord(ev[++i], c->stream));
@@ -922,6 +943,7 @@ int cf_profile_forward(cf_ctx* c, const void* in, int in_format, int in_on_devic
     HIPCHK(c, hipStreamSynchronize(c->stream));
     i = 0;
     for (auto& op : c->ops) {
+        if (op.fused_away) continue;
         cf_op_time& t = out[i];
         memset(&t, 0, sizeof t);
         snprintf(t.name, sizeof t.name, "%s", op.name.c_str());

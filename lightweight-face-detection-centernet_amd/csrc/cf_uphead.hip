@@ -1,0 +1,126 @@
+// Last IDAUp stage + the four heads as ONE kernel (bf16 storage, collapsed heads): the 24-channel
+// stride-4 neck output lives only in LDS.
+//
+// Replaces, fused: IDAUp.forward for up3 (model/centernet.py:200-204: relu(bn(conv1x1(skip))) +
+// relu(bn_up(deconv2x2(low)))), called at :274) and, per head, Conv2d(24,24,3,padding=1) -> Conv2d(24,c,1)
+// (:247-261, :277-279) + the sigmoid/clamp on hm (centerface.py:43).  Layer by layer the neck output is
+// written once (79 MB per batch of 64) and read back ~1.5-2x through the 3x3 window; here a workgroup
+// computes it for an 8x32 tile plus a one-pixel halo straight into LDS (exactly the bf16 values the
+// unfused kernel would store, pixels outside the map = the 3x3 conv's zero padding) and the head conv
+// reads its 3 x 72 contiguous elements per output pixel from there.  Same arithmetic, same operation
+// order as cf_pw.hip (IDAUp epilogue) followed by cf_head.hip (collapsed), so results are bit-identical
+// to the two-kernel path.
+#include "cf_common.h"
+#include "cf_kernels.h"
+
+namespace cf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+constexpr int UH_TH = 8, UH_TW = 32, UH_IH = UH_TH + 2, UH_IW = UH_TW + 2, UH_IPX = UH_IH * UH_IW;   // 10 x 34 = 340
+constexpr int UH_NIB = (UH_IPX + 31) / 32;                                                            // 11
+constexpr int UH_PIT = 48;                        // bytes per pixel: 24 bf16 channels = 3 x 16-byte chunks
+constexpr int UH_WHB = 3 * 5 * 1024;              // collapsed bf16 head fragments: 3 kernel rows x 5 k-steps
+
+__device__ __forceinline__ f32x16 uh_mma(f32x16 acc, const u32x4& w, const u32x4& x) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w), __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
+    __shared__ __attribute__((aligned(16))) char T3[UH_NIB * 32 * UH_PIT];      // neck tile incl. halo, bf16
+    __shared__ __attribute__((aligned(16))) char Wh[UH_WHB];                   // head weight fragments
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 31, h = lane >> 5;
+    const int ox0 = blockIdx.x * UH_TW, oy0 = blockIdx.y * UH_TH, b = blockIdx.z;
+
+    // head weights -> LDS by DMA; lands under phase A, fenced by the barrier
+    for (int c = wave; c < UH_WHB / 1024; c += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)p.w0p + c * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(Wh + c * 1024), 16, 0, 0);
+
+    // ---- phase A: up3 on the halo tile.  1x1 conv 24 -> 24 as in cf_pw.hip (K = 3 chunks: lane half 0 owns
+    // chunks 0,1, half 1 chunk 2), epilogue bias + ReLU, + ReLU(low * tap weight + shift), bf16 -> LDS
+    const u32x4 wc0 = ld16((const char*)p.wcv + (size_t)(0 * 64 + lane) * 16);
+    const u32x4 wc1 = ld16((const char*)p.wcv + (size_t)(1 * 64 + lane) * 16);
+    for (int ib = wave; ib < UH_NIB; ib += 4) {
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < UH_IPX ? ip : UH_IPX - 1;
+        const int ty = ipc / UH_IW, tx = ipc - ty * UH_IW;
+        const int gy = oy0 - 1 + ty, gx = ox0 - 1 + tx;
+        const bool valid = ip < UH_IPX && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
+        const int cy = min(max(gy, 0), p.h - 1), cx = min(max(gx, 0), p.w - 1);
+        const char* xrow = (const char*)p.skip + (((size_t)b * p.h + cy) * p.w + cx) * UH_PIT + h * 32;
+        const u32x4 x0 = ld16(xrow);
+        u32x4 x1 = ld16(xrow + (h == 0 ? 16 : 0));                 // half 1 has no second chunk
+        if (h != 0) x1 = zero16();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        acc = uh_mma(acc, wc0, x0);
+        acc = uh_mma(acc, wc1, x1);
+        const size_t low_row = ((size_t)b * (p.h >> 1) + (cy >> 1)) * (p.w >> 1) + (cx >> 1);
+        const int tap = ((cy & 1) << 1) | (cx & 1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int ch = h * 16 + g * 8;
+            if (ch >= 24) break;
+            float v[8], r[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = relu_f(acc[g * 8 + e] + p.bias[ch + e]);
+            unpack16<bf16_t>(ld16((const char*)p.low + (low_row * 24 + ch) * 2), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += relu_f(r[e] * p.upw[tap * 24 + ch + e] + p.upb[ch + e]);
+            u32x4 o = pack16<bf16_t>(v);
+            if (!valid) o = zero16();
+            st16(T3 + ip * UH_PIT + ch * 2, o);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: collapsed 3x3 head conv from the LDS tile (cf_head.hip: kernel row dy = 72 contiguous
+    // elements = 9 chunks; lane half 0 owns chunks 0-4, half 1 chunks 5-8)
+    for (int ob = wave; ob < UH_TH * UH_TW / 32; ob += 4) {
+        const int o = ob * 32 + pl;
+        const int oy = o / UH_TW, ox = o - oy * UH_TW;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const char* row = T3 + ((oy + dy) * UH_IW + ox) * UH_PIT;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int c = h * 5 + j;
+                u32x4 xc = ld16(row + (c < 9 ? c : 8) * 16);
+                if (c >= 9) xc = zero16();
+                acc = uh_mma(acc, ld16(Wh + ((dy * 5 + j) * 64 + lane) * 16), xc);
+            }
+        }
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        if (h != 0 || gy >= p.h || gx >= p.w) continue;
+        float out[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = acc[r] + p.b0[r];
+        const float raw = out[0];
+        // centerface.py:43: clamp(sigmoid(hm), 1e-4, 1 - 1e-4); precise exp + IEEE divide
+        float sg = 1.0f / (1.0f + expf(-raw));
+        sg = fminf(fmaxf(sg, 1e-4f), 1.0f - 1e-4f);
+        out[0] = sg;
+        out[15] = raw;
+        const size_t m = ((size_t)b * p.h + gy) * p.w + gx;
+        if (p.hm_plane) p.hm_plane[m] = sg;
+        float* dst = p.heads + m * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st16(dst + g * 4, pack16<float>(&out[g * 4]));
+    }
+}
+
+hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p) {
+    if (p.B <= 0) return hipSuccess;
+    dim3 grid((p.w + UH_TW - 1) / UH_TW, (p.h + UH_TH - 1) / UH_TH, p.B), blk(256);
+    set_kernel_tag("cf::uphead_kernel(cf::UpHeadParams)");
+    hipLaunchKernelGGL(uphead_kernel, grid, blk, 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace cf

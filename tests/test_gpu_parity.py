@@ -634,3 +634,22 @@ def test_variable_size_buckets_match_per_shape_detectors():
             assert d.shape == got[i][0].shape and np.array_equal(d, got[i][0]) and np.array_equal(l, got[i][1]), (i, h, w)
         one.close()
     pool.close()
+
+
+@pytest.mark.parametrize("size", [(96, 128), (160, 224), (352, 640)])
+def test_fused_up3_heads_bit_equal_to_two_kernels(size):
+    """cf_uphead.hip (last IDAUp stage + collapsed heads, neck output only in LDS) performs the same arithmetic
+    in the same order as cf_pw.hip's IDAUp epilogue followed by cf_head.hip: bit-identical head maps, on map
+    sizes with partial tiles in both directions."""
+    H, W = size
+    rng = np.random.default_rng(H + W)
+    x = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+    ef = cfa.Engine(H, W, max_batch=3, dtype="bf16", uphead=True)
+    e2 = cfa.Engine(H, W, max_batch=3, dtype="bf16", uphead=False)
+    ef.forward_enqueue(x); e2.forward_enqueue(x)
+    hf, h2 = ef.heads(sigmoid_hm=True), e2.heads(sigmoid_hm=True)
+    for k in ("hm", "wh", "lm", "reg", "hm_sigmoid"):
+        assert np.array_equal(hf[k], h2[k]), k
+    df, d2 = ef.decode_topk(50), e2.decode_topk(50)
+    assert np.array_equal(df[2], d2[2]) and np.array_equal(df[0], d2[0])
+    ef.close(); e2.close()
