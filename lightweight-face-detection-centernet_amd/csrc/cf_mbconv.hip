@@ -352,7 +352,10 @@ struct MbEntry {
 template <typename T, int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW, bool EF>
 static hipError_t mb_launch(hipStream_t s, const MbParams& p) {
     auto kfn = mbconv_kernel<T, KS, S, NBO, RESID, NW, JX, HC, TOH, TOW, EF>;
-    static thread_local size_t configured = 0;
+    // function attributes are per device: remember what was set for each
+    static thread_local size_t configured_dev[32] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    size_t& configured = configured_dev[dev & 31];
     if (p.lds_bytes > 64 * 1024 && configured < p.lds_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;

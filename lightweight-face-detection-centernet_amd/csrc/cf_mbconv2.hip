@@ -555,7 +555,9 @@ template <int KS, int S, int JX, int HC, int TOH, int TOW>
 static hipError_t xd_launch_t(hipStream_t s, const MbParams& p) {
     typedef Xd<KS, S, HC, TOH, TOW, JX> G;
     auto kfn = expdw_px_kernel<KS, S, JX, HC, TOH, TOW>;
-    static thread_local bool configured = false;
+    static thread_local bool configured_dev[32] = {};               // function attributes are per device
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool& configured = configured_dev[dev & 31];
     if (G::LDS > 64 * 1024 && !configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         if (e != hipSuccess) return e;
@@ -627,7 +629,9 @@ template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, i
 static hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
     auto kfn = mbconv_px_kernel<KS, S, NBO, RESID, NW, JX, HC, TOH, TOW>;
     constexpr int LDS = Px<KS, S, HC, TOH, TOW, JX, NW>::LDS;
-    static thread_local bool configured = false;
+    static thread_local bool configured_dev[32] = {};               // function attributes are per device
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool& configured = configured_dev[dev & 31];
     if (LDS > 64 * 1024 && !configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;

@@ -350,8 +350,12 @@ __device__ __forceinline__ void s0_dot2c(float& acc, uint32_t w, uint32_t e) {
 template <int FMT>
 __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
     typedef bf16_t T;
+    // The normalised patch Xs is dead once every wave has gathered its MFMA operands, so it shares the
+    // LDS bytes of the tile E that phase 1 then writes: 25 KB per workgroup instead of 34 (6 instead of 4
+    // workgroups per CU).
     __shared__ __attribute__((aligned(16))) char E[S0P_NIB * 16 * S0P_PITCH];
-    __shared__ __attribute__((aligned(16))) T Xs[S0_PH * S0P_PROW];      // patch row: 2 pad elements, then e = col*3 + ci
+    static_assert(S0_PH * S0P_PROW * 2 <= S0P_NIB * 16 * S0P_PITCH, "patch must fit under the tile");
+    T* Xs = reinterpret_cast<T*>(E);                                     // patch row: 2 pad elements, then e = col*3 + ci
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -435,7 +439,11 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
     u32x4 ws[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) ws[c] = ld16((const char*)p.wstem + ((size_t)c * 64 + lane) * 16);
-    for (int ib = wave; ib < S0P_NIB; ib += S0P_NW) {
+    constexpr int MAXB = (S0P_NIB + S0P_NW - 1) / S0P_NW;           // 3 halo pixel blocks per wave
+    u32x4 xg[MAXB][2];
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        const int ib = wave + S0P_NW * t;
         const int ip = ib * 32 + pl;
         const int ipc = ip < S0_IPX ? ip : S0_IPX - 1;
         const int ty = ipc / S0_IW, tx = ipc - ty * S0_IW;
@@ -443,9 +451,6 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
         // a halo pixel outside the map is the depthwise conv's zero padding: zero operand row -> swish(0) = 0
         const bool inmap = ip < S0_IPX && (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo;
         const T* xp = Xs + (2 * ty) * S0P_PROW + (2 * tx) * 3 + 2;
-        f32x16 a;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = 0.0f;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             uint32_t w4[4];
@@ -457,16 +462,27 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
                 const uint32_t hi = t1 < 27 ? (uint32_t)xp[ky1 * S0P_PROW + r1] : 0u;
                 w4[e2] = inmap ? (lo | (hi << 16)) : 0u;
             }
-            u32x4 xc; xc.x = w4[0]; xc.y = w4[1]; xc.z = w4[2]; xc.w = w4[3];
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xc),
-                                                        __builtin_bit_cast(mfma_bf16x8, ws[c]), a, 0, 0, 0);
+            xg[t][c].x = w4[0]; xg[t][c].y = w4[1]; xg[t][c].z = w4[2]; xg[t][c].w = w4[3];
         }
+    }
+    __syncthreads();                                              // every wave has its operands: Xs may be overwritten
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        const int ib = wave + S0P_NW * t;
+        if (ib >= S0P_NIB) break;
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xg[t][c]),
+                                                        __builtin_bit_cast(mfma_bf16x8, ws[c]), a, 0, 0, 0);
         char* ecol = E + pl * 4 + (unsigned)(ib * 16 + 2 * h) * (unsigned)S0P_PITCH;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            f32x2 x2; x2.x = a[2 * t]; x2.y = a[2 * t + 1];
+        for (int tt = 0; tt < 8; ++tt) {
+            f32x2 x2; x2.x = a[2 * tt]; x2.y = a[2 * tt + 1];
             const f32x2 y2 = s0_swish2_prescaled(x2);
-            *reinterpret_cast<uint32_t*>(ecol + ((t & 1) + 4 * (t >> 1)) * S0P_PITCH) =
+            *reinterpret_cast<uint32_t*>(ecol + ((tt & 1) + 4 * (tt >> 1)) * S0P_PITCH) =
                 __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
         }
     }
