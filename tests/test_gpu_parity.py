@@ -653,3 +653,25 @@ def test_fused_up3_heads_bit_equal_to_two_kernels(size):
     df, d2 = ef.decode_topk(50), e2.decode_topk(50)
     assert np.array_equal(df[2], d2[2]) and np.array_equal(df[0], d2[0])
     ef.close(); e2.close()
+
+
+@pytest.mark.parametrize("size", [(32, 32), (64, 96), (32, 640)])
+def test_bf16_engine_on_maps_smaller_than_a_tile(size):
+    """Smallest legal inputs: the stride-32 map is 1 x 1, every fused kernel runs a single partly filled
+    tile (halo entirely in the zero padding).  bf16 path vs fp32 path: finite, close, same top peaks."""
+    H, W = size
+    rng = np.random.default_rng(H * 3 + W)
+    x = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    e32 = cfa.Engine(H, W, max_batch=2, dtype="fp32")
+    e16 = cfa.Engine(H, W, max_batch=2, dtype="bf16")
+    e32.forward_enqueue(x); e16.forward_enqueue(x)
+    h32, h16 = e32.heads(), e16.heads()
+    for k in ("hm", "wh", "lm", "reg"):
+        assert np.isfinite(h16[k]).all()
+        d = np.abs(h16[k] - h32[k])
+        assert d.mean() < 0.03 * (np.abs(h32[k]).mean() + 1e-6) + 2e-3, (k, float(d.mean()))
+        assert d.max() < 0.25 * max(1.0, float(np.abs(h32[k]).max())), (k, float(d.max()))
+    K = min(10, (H // 4) * (W // 4))
+    d16, d32 = e16.decode_topk(K), e32.decode_topk(K)
+    assert d16[0].shape == d32[0].shape and np.isfinite(d16[0]).all()
+    e32.close(); e16.close()
