@@ -78,6 +78,17 @@ int cf_destroy(cf_ctx* ctx);
  * folds BatchNorm (eval mode, centerface.py:25), repacks to kernel layouts, uploads. */
 int cf_load_weights(cf_ctx* ctx, const cf_tensor_desc* tensors, int n);
 
+/* ---- training-side pieces that share the detector's tensors (forward evaluation only) ----------------- */
+/* CtdetLoss.forward (model/losses.py:347-374: focal loss :142-167 on clamp(sigmoid(hm), 1e-5, 1-1e-5),
+ * RegL1Loss :239-250 on wh / reg / lm gathered at ind) evaluated on the head maps of the LAST cf_forward of
+ * ctx.  Targets are host arrays as dataset/dataset.py:223-226 returns them: gt_hm [B,1,h,w] f32,
+ * reg_mask / lm_mask [B,M] u8, ind / lm_ind [B,M] i64, wh_t / reg_t [B,M,2], lm_t [B,M,10].
+ * weights = {hm_w, wh_w, off_w, lm_w} (reference defaults 1, 0.1, 1, 1).  out[5] = loss, hm_loss, wh_loss,
+ * off_loss, lm_loss.  Blocking. */
+int cf_ctdet_loss(cf_ctx* ctx, const float* gt_hm, const uint8_t* reg_mask, const int64_t* ind, const float* wh_t,
+                  const float* reg_t, const uint8_t* lm_mask, const int64_t* lm_ind, const float* lm_t,
+                  int max_objs, const float* weights4, float* out5);
+
 /* ---- forward: replaces net(img)[0] (centerface.py:41, eval_widerface.py:83-84) ------------- */
 /* `in` is a host pointer (in_on_device = 0; copied H2D on the ctx stream) or a device pointer on
  * ctx's GPU (in_on_device = 1; 4-byte aligned -- CF_EINVAL otherwise).  Asynchronous: returns after
@@ -190,6 +201,17 @@ int cf_op_mbconv(int device, int dtype, const float* x, const float* w_exp, cons
  * Returns CF_EINVAL for shapes / dtypes the kernel does not cover. */
 int cf_op_expand_dw(int device, int dtype, const float* x, const float* w_exp, const float* w_dw, float* y,
                     int B, int Cin, int hid, int H, int W, int k, int stride);
+/* CtdetLoss.forward on explicit NCHW head maps (hm as logits), same targets as cf_ctdet_loss. */
+int cf_op_ctdet_loss(int device, const float* hm_raw, const float* wh, const float* reg, const float* lm,
+                     int B, int h, int w, const float* gt_hm, const uint8_t* reg_mask, const int64_t* ind,
+                     const float* wh_t, const float* reg_t, const uint8_t* lm_mask, const int64_t* lm_ind,
+                     const float* lm_t, int max_objs, const float* weights4, float* out5);
+/* Target maps of dataset/dataset.py:160-217 for boxes [B,M,4] / landmarks [B,M,10] given in OUTPUT-MAP
+ * coordinates (after the affine of :172-179), counts [B]: Gaussian heat map (utils/image.py:95-141, radius in
+ * float64), wh, reg, ind, reg_mask, landmarks, lm_ind, lm_mask -- all [B,M,...] except hm [B,1,h,w]. */
+int cf_op_encode_targets(int device, const float* boxes, const float* lms, const int32_t* counts, int B, int h, int w,
+                         int max_objs, float* hm, float* wh, float* reg, int64_t* ind, uint8_t* reg_mask,
+                         float* landmarks, int64_t* lm_ind, uint8_t* lm_mask);
 /* stem: ConvReLU(3,32,3,stride 2) on a normalised float NCHW tensor or a uint8 HWC BGR image
  * (model/centernet.py:224 ; centerface.py:32-37). y [B,32,H/2,W/2] */
 int cf_op_stem(int device, int dtype, const void* x, int in_format, const float* w, float* y,

@@ -134,6 +134,28 @@ void head_pack_weights(int dtype, int collapsed, const float* w0, const float* b
                        float* w1d_host /*[96][16]*/, float* b1_host /*[16]*/);
 hipError_t launch_heads(hipStream_t s, int dtype, const HeadParams& p);
 
+// ------------------------------------------------------------------ detection loss + target encoder (cf_loss.hip)
+struct LossParams {
+    const float* heads;   // [B][h][w][16] head records of a forward (used when the explicit maps are null)
+    const float* hm_raw;  // explicit NCHW maps (op-level entry): hm logits [B,1,h,w], wh [B,2,h,w], reg [B,2,h,w], lm [B,10,h,w]
+    const float* wh; const float* reg; const float* lm;
+    const float* gt_hm;   // [B][h][w]
+    const unsigned char* reg_mask; const long long* ind; const float* wh_t; const float* reg_t;   // [B][M](,2)
+    const unsigned char* lm_mask; const long long* lm_ind; const float* lm_t;                     // [B][M](,10)
+    int B, h, w, M;
+    float hm_w, wh_w, off_w, lm_w;
+};
+hipError_t launch_ctdet_loss(hipStream_t s, const LossParams& p, double* ws /*[3 * nblocks + 6]*/, int nblocks, float* out_dev /*[5]*/);
+struct EncodeParams {
+    const float* boxes;   // [B][M][4] x1,y1,x2,y2 in output-map coordinates
+    const float* lms;     // [B][M][10], lms[.][0] < 0: no landmarks
+    const int* counts;    // [B] objects per image (<= M)
+    float* hm; float* wh; float* reg; long long* ind; unsigned char* reg_mask;
+    float* landmarks; long long* lm_ind; unsigned char* lm_mask;
+    int B, h, w, M;
+};
+hipError_t launch_encode_targets(hipStream_t s, const EncodeParams& p);
+
 // ------------------------------------------------------------------ IDAUp stage 3 + heads fused (bf16, collapsed heads)
 struct UpHeadParams {
     const void* skip;     // [B][h][w][24] bf16: the IDAUp skip input (layer1 output)

@@ -182,6 +182,53 @@ int cf_op_expand_dw(int device, int dtype, const float* x, const float* w_exp, c
     return sc.result("cf_op_expand_dw");
 }
 
+int cf_op_ctdet_loss(int device, const float* hm_raw, const float* wh, const float* reg, const float* lm,
+                     int B, int h, int w, const float* gt_hm, const uint8_t* reg_mask, const int64_t* ind,
+                     const float* wh_t, const float* reg_t, const uint8_t* lm_mask, const int64_t* lm_ind,
+                     const float* lm_t, int max_objs, const float* weights4, float* out5) {
+    if (!hm_raw || !wh || !reg || !lm || !gt_hm || !reg_mask || !ind || !wh_t || !reg_t || !lm_mask || !lm_ind || !lm_t ||
+        !weights4 || !out5 || B < 1 || h < 1 || w < 1 || max_objs < 1) return CF_EINVAL;
+    Scope sc(device);
+    const size_t hw = (size_t)h * w, bm = (size_t)B * max_objs;
+    LossParams p{};
+    p.hm_raw = (const float*)sc.up(hm_raw, B * hw * 4); p.wh = (const float*)sc.up(wh, B * 2 * hw * 4);
+    p.reg = (const float*)sc.up(reg, B * 2 * hw * 4); p.lm = (const float*)sc.up(lm, B * 10 * hw * 4);
+    p.gt_hm = (const float*)sc.up(gt_hm, B * hw * 4);
+    p.reg_mask = (const unsigned char*)sc.up(reg_mask, bm); p.ind = (const long long*)sc.up(ind, bm * 8);
+    p.wh_t = (const float*)sc.up(wh_t, bm * 8); p.reg_t = (const float*)sc.up(reg_t, bm * 8);
+    p.lm_mask = (const unsigned char*)sc.up(lm_mask, bm); p.lm_ind = (const long long*)sc.up(lm_ind, bm * 8);
+    p.lm_t = (const float*)sc.up(lm_t, bm * 40);
+    p.B = B; p.h = h; p.w = w; p.M = max_objs;
+    p.hm_w = weights4[0]; p.wh_w = weights4[1]; p.off_w = weights4[2]; p.lm_w = weights4[3];
+    const int nblocks = 256;
+    double* ws = (double*)sc.alloc((3 * nblocks + 6) * sizeof(double));
+    float* out = (float*)sc.alloc(5 * sizeof(float));
+    if (sc.err == hipSuccess) sc.chk(launch_ctdet_loss(sc.s, p, ws, nblocks, out));
+    if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(out5, out, 5 * sizeof(float), hipMemcpyDeviceToHost, sc.s));
+    return sc.result("cf_op_ctdet_loss");
+}
+
+int cf_op_encode_targets(int device, const float* boxes, const float* lms, const int32_t* counts, int B, int h, int w,
+                         int max_objs, float* hm, float* wh, float* reg, int64_t* ind, uint8_t* reg_mask,
+                         float* landmarks, int64_t* lm_ind, uint8_t* lm_mask) {
+    if (!boxes || !lms || !counts || !hm || !wh || !reg || !ind || !reg_mask || !landmarks || !lm_ind || !lm_mask ||
+        B < 1 || h < 1 || w < 1 || max_objs < 1) return CF_EINVAL;
+    for (int b = 0; b < B; ++b) if (counts[b] < 0 || counts[b] > max_objs) return CF_EINVAL;
+    Scope sc(device);
+    const size_t hw = (size_t)h * w, bm = (size_t)B * max_objs;
+    EncodeParams p{};
+    p.boxes = (const float*)sc.up(boxes, bm * 16); p.lms = (const float*)sc.up(lms, bm * 40); p.counts = (const int*)sc.up(counts, (size_t)B * 4);
+    p.hm = (float*)sc.alloc(B * hw * 4); p.wh = (float*)sc.alloc(bm * 8); p.reg = (float*)sc.alloc(bm * 8);
+    p.ind = (long long*)sc.alloc(bm * 8); p.reg_mask = (unsigned char*)sc.alloc(bm);
+    p.landmarks = (float*)sc.alloc(bm * 40); p.lm_ind = (long long*)sc.alloc(bm * 8); p.lm_mask = (unsigned char*)sc.alloc(bm);
+    p.B = B; p.h = h; p.w = w; p.M = max_objs;
+    if (sc.err == hipSuccess) sc.chk(launch_encode_targets(sc.s, p));
+    auto down = [&](void* dst, const void* src, size_t bytes) { if (sc.err == hipSuccess) sc.chk(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, sc.s)); };
+    down(hm, p.hm, B * hw * 4); down(wh, p.wh, bm * 8); down(reg, p.reg, bm * 8); down(ind, p.ind, bm * 8);
+    down(reg_mask, p.reg_mask, bm); down(landmarks, p.landmarks, bm * 40); down(lm_ind, p.lm_ind, bm * 8); down(lm_mask, p.lm_mask, bm);
+    return sc.result("cf_op_encode_targets");
+}
+
 int cf_op_stem(int device, int dtype, const void* x, int in_format, const float* w, float* y, int B, int H, int W) {
     if (bad_dtype(dtype) || !x || !w || !y || (H % 2) || (W % 2)) return CF_EINVAL;
     if (in_format != CF_IN_U8_HWC_BGR && in_format != CF_IN_F32_NCHW) return CF_EINVAL;

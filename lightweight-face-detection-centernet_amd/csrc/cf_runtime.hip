@@ -970,6 +970,47 @@ int cf_profile_forward(cf_ctx* c, const void* in, int in_format, int in_on_devic
     return CF_OK;
 }
 
+int cf_ctdet_loss(cf_ctx* c, const float* gt_hm, const uint8_t* reg_mask, const int64_t* ind, const float* wh_t,
+                  const float* reg_t, const uint8_t* lm_mask, const int64_t* lm_ind, const float* lm_t,
+                  int max_objs, const float* weights4, float* out5) {
+    if (!c) return CF_EINVAL;
+    if (!gt_hm || !reg_mask || !ind || !wh_t || !reg_t || !lm_mask || !lm_ind || !lm_t || !weights4 || !out5 || max_objs < 1)
+        return c->fail(CF_EINVAL, "cf_ctdet_loss: null argument or max_objs < 1");
+    if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_ctdet_loss before cf_forward");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int B = c->last_B, h = c->H / 4, w = c->W / 4, nblocks = 256;
+    const size_t hw = (size_t)h * w, bm = (size_t)B * max_objs;
+    // one staging allocation per call: validation-loss evaluation is not on the per-image hot path
+    const size_t off_gt = 0, off_wh = off_gt + B * hw * 4, off_reg = off_wh + bm * 8, off_lm = off_reg + bm * 8,
+                 off_ind = off_lm + bm * 40, off_lmind = off_ind + bm * 8, off_ws = off_lmind + bm * 8,
+                 off_out = off_ws + (3 * nblocks + 6) * 8, off_rm = off_out + 64, off_lmm = off_rm + ((bm + 15) / 16) * 16,
+                 total = off_lmm + ((bm + 15) / 16) * 16;
+    char* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, total));
+    auto up = [&](size_t off, const void* src, size_t bytes) { return hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, c->stream); };
+    hipError_t e = up(off_gt, gt_hm, B * hw * 4);
+    if (e == hipSuccess) e = up(off_wh, wh_t, bm * 8);
+    if (e == hipSuccess) e = up(off_reg, reg_t, bm * 8);
+    if (e == hipSuccess) e = up(off_lm, lm_t, bm * 40);
+    if (e == hipSuccess) e = up(off_ind, ind, bm * 8);
+    if (e == hipSuccess) e = up(off_lmind, lm_ind, bm * 8);
+    if (e == hipSuccess) e = up(off_rm, reg_mask, bm);
+    if (e == hipSuccess) e = up(off_lmm, lm_mask, bm);
+    LossParams p{};
+    p.heads = (const float*)c->bufs[c->buf_heads].p;
+    p.gt_hm = (const float*)(d + off_gt); p.wh_t = (const float*)(d + off_wh); p.reg_t = (const float*)(d + off_reg);
+    p.lm_t = (const float*)(d + off_lm); p.ind = (const long long*)(d + off_ind); p.lm_ind = (const long long*)(d + off_lmind);
+    p.reg_mask = (const unsigned char*)(d + off_rm); p.lm_mask = (const unsigned char*)(d + off_lmm);
+    p.B = B; p.h = h; p.w = w; p.M = max_objs;
+    p.hm_w = weights4[0]; p.wh_w = weights4[1]; p.off_w = weights4[2]; p.lm_w = weights4[3];
+    if (e == hipSuccess) e = launch_ctdet_loss(c->stream, p, (double*)(d + off_ws), nblocks, (float*)(d + off_out));
+    if (e == hipSuccess) e = hipMemcpyAsync(out5, d + off_out, 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return c->fail(CF_EHIP, "cf_ctdet_loss: %s", hipGetErrorString(e));
+    return CF_OK;
+}
+
 int cf_get_streams(cf_ctx* c, void** main_stream, void** decode_stream) {
     if (!c) return CF_EINVAL;
     if (main_stream) *main_stream = (void*)c->stream;

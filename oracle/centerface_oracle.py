@@ -16,6 +16,7 @@ rescale) is restated in numpy with explicit loops/ops so that integer/index resu
 
 Each function cites the reference file:line it follows (paths relative to the reference root).
 """
+import math
 from collections import OrderedDict
 
 import numpy as np
@@ -420,3 +421,113 @@ def detect(sd, img_bgr_u8, threshold=0.2):
     dets, lms = decode_d1(hm, out["wh"].numpy(), out["reg"].numpy(), out["lm"].numpy(),
                           (h_new, w_new), threshold)
     return rescale(dets, lms, sh, sw)
+
+
+# ----------------------------------------------------------------------------- training-side pieces
+def gaussian_radius(det_size, min_overlap=0.7):
+    """utils/image.py:95-115 (float64 numpy arithmetic)."""
+    height, width = det_size
+    b1 = height + width
+    c1 = width * height * (1 - min_overlap) / (1 + min_overlap)
+    r1 = (b1 + np.sqrt(b1 ** 2 - 4 * c1)) / 2
+    b2 = 2 * (height + width)
+    c2 = (1 - min_overlap) * width * height
+    r2 = (b2 + np.sqrt(b2 ** 2 - 16 * c2)) / 2
+    a3 = 4 * min_overlap
+    b3 = -2 * min_overlap * (height + width)
+    c3 = (min_overlap - 1) * width * height
+    r3 = (b3 + np.sqrt(b3 ** 2 - 4 * a3 * c3)) / 2
+    return min(r1, r2, r3)
+
+
+def draw_umich_gaussian(heatmap, center, radius):
+    """utils/image.py:118-141: max-blend a (2r+1)^2 Gaussian (sigma = diameter/6, float64) into a float32 map."""
+    diameter = 2 * radius + 1
+    sigma = diameter / 6
+    y, x = np.ogrid[-radius:radius + 1, -radius:radius + 1]
+    g = np.exp(-(x * x + y * y) / (2 * sigma * sigma))
+    g[g < np.finfo(g.dtype).eps * g.max()] = 0
+    cx, cy = int(center[0]), int(center[1])
+    height, width = heatmap.shape[0:2]
+    left, right = min(cx, radius), min(width - cx, radius + 1)
+    top, bottom = min(cy, radius), min(height - cy, radius + 1)
+    mh = heatmap[cy - top:cy + bottom, cx - left:cx + right]
+    mg = g[radius - top:radius + bottom, radius - left:radius + right]
+    if min(mg.shape) > 0 and min(mh.shape) > 0:
+        np.maximum(mh, mg, out=mh)
+    return heatmap
+
+
+def encode_targets(boxes, lms, output_h, output_w, max_objs):
+    """The per-object loop of dataset/dataset.py:160-217 for ONE image, given boxes [n,4] (x1,y1,x2,y2) and
+    landmarks [n,10] ALREADY in output-map coordinates (after the affine of :172-179; lms[k][0] < 0 = no
+    landmarks).  Returns dict(hm [1,h,w], wh [M,2], reg [M,2], ind [M] i64, reg_mask [M] u8, landmarks [M,10],
+    lm_ind [M] i64, lm_mask [M] u8), float32 unless noted."""
+    hm = np.zeros((1, output_h, output_w), np.float32)
+    wh = np.zeros((max_objs, 2), np.float32)
+    landmarks = np.zeros((max_objs, 10), np.float32)
+    reg = np.zeros((max_objs, 2), np.float32)
+    ind = np.zeros((max_objs,), np.int64)
+    reg_mask = np.zeros((max_objs,), np.uint8)
+    lm_ind = np.zeros((max_objs,), np.int64)
+    lm_mask = np.zeros((max_objs,), np.uint8)
+    for k in range(min(len(boxes), max_objs)):
+        bbox = np.array(boxes[k], dtype=np.float32).copy()
+        lm = np.array(lms[k], dtype=np.float32).copy()
+        bbox[[0, 2]] = np.clip(bbox[[0, 2]], 0, output_w - 1)          # :181-182
+        bbox[[1, 3]] = np.clip(bbox[[1, 3]], 0, output_h - 1)
+        h, w = bbox[3] - bbox[1], bbox[2] - bbox[0]
+        if h > 0 and w > 0:                                           # :185
+            radius = max(0, int(gaussian_radius((math.ceil(h), math.ceil(w)))))
+            ct = np.array([(bbox[0] + bbox[2]) / 2, (bbox[1] + bbox[3]) / 2], dtype=np.float32)
+            ct_int = ct.astype(np.int32)
+            draw_umich_gaussian(hm[0], ct_int, radius)
+            wh[k] = 1. * w, 1. * h
+            ind[k] = ct_int[1] * output_w + ct_int[0]
+            reg[k] = ct - ct_int
+            reg_mask[k] = 1
+            if lm[0] > 0 and lm[1] < output_h and lm[2] < output_w and lm[3] < output_h \
+                    and lm[6] > 0 and lm[7] > 0 and lm[8] < output_w and lm[9] > 0:      # :200-201
+                lm_ind[k] = ct_int[1] * output_w + ct_int[0]
+                if h * w > 10:
+                    lm_mask[k] = 1
+                lt = lm.copy()
+                lt[[0, 2, 4, 6, 8]] = lt[[0, 2, 4, 6, 8]] - ct_int[0]
+                lt[[1, 3, 5, 7, 9]] = lt[[1, 3, 5, 7, 9]] - ct_int[1]
+                landmarks[k] = lt
+    return dict(hm=hm, wh=wh, reg=reg, ind=ind, reg_mask=reg_mask, landmarks=landmarks, lm_ind=lm_ind, lm_mask=lm_mask)
+
+
+def neg_loss(pred, gt):
+    """Modified focal loss, model/losses.py:142-167."""
+    pos_inds = gt.eq(1).float()
+    neg_inds = gt.lt(1).float()
+    neg_weights = torch.pow(1 - gt, 4)
+    pos_loss = (torch.log(pred) * torch.pow(1 - pred, 2) * pos_inds).sum()
+    neg_loss_ = (torch.log(1 - pred) * torch.pow(pred, 2) * neg_weights * neg_inds).sum()
+    num_pos = pos_inds.sum()
+    if num_pos == 0:
+        return -neg_loss_
+    return -(pos_loss + neg_loss_) / num_pos
+
+
+def reg_l1_loss(output, mask, ind, target):
+    """RegL1Loss.forward, model/losses.py:239-250 (+ _tranpose_and_gather_feat :86-90)."""
+    B, C = output.shape[0], output.shape[1]
+    feat = output.permute(0, 2, 3, 1).contiguous().view(B, -1, C)
+    pred = feat.gather(1, ind.unsqueeze(2).expand(B, ind.shape[1], C))
+    m = mask.unsqueeze(2).expand_as(pred).float()
+    loss = torch.abs(pred * m - target * m).sum()
+    return loss / (m.sum() + 1e-4)
+
+
+def ctdet_loss(out, batch, hm_w=1., wh_w=0.1, off_w=1., lm_w=1.):
+    """CtdetLoss.forward, model/losses.py:347-374; `out` holds RAW head maps (hm as logits): the loss applies its
+    own sigmoid with a 1e-5 clamp (:345).  Returns float32 [loss, hm_loss, wh_loss, off_loss, lm_loss]."""
+    hm = torch.clamp(torch.sigmoid(out["hm"]), min=1e-5, max=1 - 1e-5)
+    hm_loss = hm_w * neg_loss(hm, batch["hm"])
+    wh_loss = wh_w * reg_l1_loss(out["wh"], batch["reg_mask"], batch["ind"], batch["wh"])
+    off_loss = off_w * reg_l1_loss(out["reg"], batch["reg_mask"], batch["ind"], batch["reg"])
+    lm_loss = lm_w * reg_l1_loss(out["lm"], batch["lm_mask"], batch["lm_ind"], batch["lm"])
+    loss = hm_loss + wh_loss + off_loss + lm_loss
+    return np.array([float(loss), float(hm_loss), float(wh_loss), float(off_loss), float(lm_loss)], np.float32)

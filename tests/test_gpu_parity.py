@@ -675,3 +675,88 @@ def test_bf16_engine_on_maps_smaller_than_a_tile(size):
     d16, d32 = e16.decode_topk(K), e32.decode_topk(K)
     assert d16[0].shape == d32[0].shape and np.isfinite(d16[0]).all()
     e32.close(); e16.close()
+
+
+# ----------------------------------------------------------------------------- N4: training-side pieces
+def _train_batch(g, idx):
+    st = lambda key: np.stack([g["b%d_%s" % (i, key)] for i in idx])
+    return {"hm": st("hm"), "reg_mask": st("reg_mask"), "ind": st("ind"), "wh": st("wh"), "reg": st("reg"),
+            "lm_mask": st("lm_mask"), "lm_ind": st("lm_ind"), "lm": st("landmarks")}
+
+
+def test_target_encoder_kernel_vs_reference_goldens(golden):
+    """cf_op_encode_targets (cf_loss.hip) against the reference's gaussian_radius / draw_umich_gaussian inside the
+    dataset loop (tests/golden/train.npz): integer outputs and fp32 targets bit-exact; the Gaussian heat map to
+    1 float32 ulp (float64 exp on the device vs glibc)."""
+    from centerface_amd import losses
+    g = golden("train")
+    H, W = g["b0_hm"].shape[1:]
+    boxes = np.stack([g["b%d_boxes" % b] for b in range(3)])
+    lms = np.stack([g["b%d_lms" % b] for b in range(3)])
+    counts = np.array([int(g["b%d_n" % b]) for b in range(3)], np.int32)
+    t = losses.encode_targets(boxes, lms, counts, H, W)
+    for b in range(3):
+        for k in ("wh", "reg", "ind", "reg_mask", "landmarks", "lm_ind", "lm_mask"):
+            assert np.array_equal(t[k][b], g["b%d_%s" % (b, k)]), (b, k)
+        np.testing.assert_allclose(t["hm"][b], g["b%d_hm" % b], rtol=2e-7, atol=1e-9)
+        assert np.array_equal(t["hm"][b] == 1.0, g["b%d_hm" % b] == 1.0)           # peaks (the focal loss's positives)
+    # a larger random case against the oracle
+    rng = np.random.default_rng(9)
+    B, M, h, w = 4, 32, 160, 160
+    bx = np.zeros((B, M, 4), np.float32); lm = -np.ones((B, M, 10), np.float32)
+    cnt = np.array([32, 17, 0, 5], np.int32)
+    for b in range(B):
+        for k in range(cnt[b]):
+            cx, cy, bw, bh = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(0.5, 60), rng.uniform(0.5, 60)
+            bx[b, k] = [cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2]
+            if k % 2 == 0:
+                lm[b, k, 0::2] = rng.uniform(bx[b, k, 0], bx[b, k, 2], 5); lm[b, k, 1::2] = rng.uniform(bx[b, k, 1], bx[b, k, 3], 5)
+    t = losses.encode_targets(bx, lm, cnt, h, w)
+    for b in range(B):
+        r = O.encode_targets(bx[b, :cnt[b]], lm[b, :cnt[b]], h, w, M)
+        for k in ("wh", "reg", "ind", "reg_mask", "landmarks", "lm_ind", "lm_mask"):
+            assert np.array_equal(t[k][b], r[k]), (b, k)
+        np.testing.assert_allclose(t["hm"][b], r["hm"], rtol=2e-7, atol=1e-9)
+
+
+def test_ctdet_loss_kernel_vs_reference_goldens(golden):
+    """cf_op_ctdet_loss against model/losses.py CtdetLoss outputs (focal + 3 x RegL1), incl. the num_pos == 0 branch;
+    fp32 terms, double sums: 2e-5 relative."""
+    from centerface_amd import losses
+    g = golden("train")
+    heads = {k: g["heads_" + k] for k in ("hm", "wh", "reg", "lm")}
+    for name in ("all", "empty"):
+        idx = [int(i) for i in g["loss_%s_idx" % name]]
+        got = losses.ctdet_loss({k: v[idx] for k, v in heads.items()}, _train_batch(g, idx))
+        np.testing.assert_allclose(got, g["loss_" + name], rtol=2e-5, atol=1e-6)
+    got = losses.ctdet_loss({k: v[[0, 1]] for k, v in heads.items()}, _train_batch(g, [0, 1]), hm_w=0.5, wh_w=1.0, off_w=2.0, lm_w=0.25)
+    ref = O.ctdet_loss({k: torch.from_numpy(v[[0, 1]].copy()) for k, v in heads.items()},
+                       {k: torch.from_numpy(v) for k, v in _train_batch(g, [0, 1]).items()}, 0.5, 1.0, 2.0, 0.25)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6)
+
+
+def test_ctdet_loss_on_engine_heads_matches_explicit_maps():
+    """cf_ctdet_loss evaluates the loss on the head maps that stay on the GPU after a forward: same numbers as
+    the op-level entry fed with cf_get_heads' copies, and as the oracle."""
+    from centerface_amd import losses
+    rng = np.random.default_rng(31)
+    H, W, B, M = 128, 160, 3, 16
+    eng = cfa.Engine(H, W, max_batch=B, dtype="fp32")
+    eng.forward_enqueue(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8))
+    hd = eng.heads()
+    h, w = H // 4, W // 4
+    bx = np.zeros((B, M, 4), np.float32); lm = -np.ones((B, M, 10), np.float32); cnt = np.array([9, 16, 3], np.int32)
+    for b in range(B):
+        for k in range(cnt[b]):
+            cx, cy, bw, bh = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(1, 14), rng.uniform(1, 14)
+            bx[b, k] = [cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2]
+            lm[b, k, 0::2] = rng.uniform(bx[b, k, 0], bx[b, k, 2], 5); lm[b, k, 1::2] = rng.uniform(bx[b, k, 1], bx[b, k, 3], 5)
+    t = losses.encode_targets(bx, lm, cnt, h, w)
+    batch = {"hm": t["hm"], "reg_mask": t["reg_mask"], "ind": t["ind"], "wh": t["wh"], "reg": t["reg"],
+             "lm_mask": t["lm_mask"], "lm_ind": t["lm_ind"], "lm": t["landmarks"]}
+    on_gpu = losses.ctdet_loss_last_forward(eng, batch)
+    explicit = losses.ctdet_loss(hd, batch)
+    assert np.array_equal(on_gpu, explicit)
+    ref = O.ctdet_loss({k: torch.from_numpy(hd[k].copy()) for k in ("hm", "wh", "reg", "lm")}, {k: torch.from_numpy(v) for k, v in batch.items()})
+    np.testing.assert_allclose(on_gpu, ref, rtol=2e-5, atol=1e-6)
+    eng.close()

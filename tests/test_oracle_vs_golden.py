@@ -160,3 +160,30 @@ def test_decode_d2_vs_reference(golden):
     assert len(g["a_boxes"]) > 10 and bool(g["empty_is_list"])
     assert O.decode_d2(np.full((1, 4, 4), 0.1, np.float32), np.ones((2, 4, 4), np.float32),
                        np.zeros((2, 4, 4), np.float32), (16, 16), threshold=0.5) == []
+
+
+# ----------------------------------------------------------------------------- N4: training-side pieces
+def test_target_encoding_and_losses_match_reference(golden):
+    """oracle.encode_targets / gaussian_radius / ctdet_loss against outputs of the reference's
+    utils/image.py primitives + model/losses.py CtdetLoss (tools/gen_goldens_train.py)."""
+    import torch
+    g = golden("train")
+    for s, r in zip(g["radius_sizes"], g["radius"]):
+        assert O.gaussian_radius((int(s[0]), int(s[1]))) == r
+    H, W = g["b0_hm"].shape[1:]
+    M = g["b0_wh"].shape[0]
+    enc = []
+    for b in range(3):
+        n = int(g["b%d_n" % b])
+        t = O.encode_targets(g["b%d_boxes" % b][:n], g["b%d_lms" % b][:n], H, W, M)
+        for k in ("hm", "wh", "reg", "ind", "reg_mask", "landmarks", "lm_ind", "lm_mask"):
+            assert np.array_equal(t[k], g["b%d_%s" % (b, k)]), (b, k)
+        enc.append(t)
+    heads = {k: g["heads_" + k] for k in ("hm", "wh", "reg", "lm")}
+    for name in ("all", "empty"):
+        idx = list(g["loss_%s_idx" % name])
+        out = {k: torch.from_numpy(v[idx].copy()) for k, v in heads.items()}
+        st = lambda key: torch.from_numpy(np.stack([enc[i][key] for i in idx]))
+        batch = {"hm": st("hm"), "reg_mask": st("reg_mask"), "ind": st("ind"), "wh": st("wh"), "reg": st("reg"),
+                 "lm_mask": st("lm_mask"), "lm_ind": st("lm_ind"), "lm": st("landmarks")}
+        np.testing.assert_allclose(O.ctdet_loss(out, batch), g["loss_" + name], rtol=1e-6, atol=1e-7)
