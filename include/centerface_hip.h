@@ -90,7 +90,9 @@ int cf_ctdet_loss(cf_ctx* ctx, const float* gt_hm, const uint8_t* reg_mask, cons
                   int max_objs, const float* weights4, float* out5);
 
 /* ---- forward: replaces net(img)[0] (centerface.py:41, eval_widerface.py:83-84) ------------- */
-/* `in` is a host pointer (in_on_device = 0; copied H2D on the ctx stream) or a device pointer on
+/* `in` is a host pointer (in_on_device = 0; copied H2D on a copy stream into one of two staging buffers, so the
+ * copy overlaps the previous forward -- keep the buffer unchanged until the NEXT cf_forward / cf_synchronize
+ * returns) or a device pointer on
  * ctx's GPU (in_on_device = 1; 4-byte aligned -- CF_EINVAL otherwise).  Asynchronous: returns after
  * enqueueing. */
 int cf_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B);

@@ -71,6 +71,10 @@ struct cf_ctx {
     std::vector<Op> ops;
     std::vector<void*> owned;                 // device allocations to free
     int buf_in = -1, buf_heads = -1;
+    // host inputs: H2D copies run on their own stream into two alternating staging buffers, so the copy of
+    // batch i+1 overlaps the forward of batch i (PCIe-inclusive rate ~ max(copy, compute), not their sum)
+    hipStream_t stream_in = nullptr; int buf_in2 = -1; int in_slot = 0; int in_slot_used = -1;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_slot_free[2] = {nullptr, nullptr}; bool slot_busy[2] = {false, false};
     bool weights_loaded = false;
     int last_B = 0;
     std::string err;
@@ -334,12 +338,19 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fwd, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
+    for (int i = 0; i < 2; ++i) {
+        if ((e = hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&c->ev_slot_free[i], hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
+    }
     if ((e = hipEventCreateWithFlags(&c->ev_dec, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
     for (auto& ev : c->events) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
     build_plan(c);
     // input staging: the larger of u8 HWC and f32 NCHW
     c->buf_in = add_buf(c, "input", true);
     need(c, c->buf_in, (size_t)3 * H * W);
+    c->buf_in2 = add_buf(c, "input2", false);
+    need(c, c->buf_in2, ((size_t)3 * H * W + elem_size(dtype) - 1) / elem_size(dtype));     // 3*H*W BYTES per image (u8 only)
     for (auto& b : c->bufs) {
         size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256;
         if ((e = hipMalloc(&b.p, bytes)) != hipSuccess) return bail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "hipMalloc(activations)", e);
@@ -358,6 +369,8 @@ int cf_destroy(cf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->ev_fwd) hipEventDestroy(c->ev_fwd);
+    if (c->stream_in) { hipStreamSynchronize(c->stream_in); hipStreamDestroy(c->stream_in); }
+    for (int i = 0; i < 2; ++i) { if (c->ev_copy[i]) hipEventDestroy(c->ev_copy[i]); if (c->ev_slot_free[i]) hipEventDestroy(c->ev_slot_free[i]); }
     if (c->ev_dec) hipEventDestroy(c->ev_dec);
     for (auto& b : c->bufs) if (b.p) hipFree(b.p);
     for (void* p : c->owned) hipFree(p);
@@ -603,8 +616,16 @@ int stage_input(cf_ctx* c, const void* in, int in_format, int in_on_device, int 
         return c->fail(CF_EINVAL, "cf_forward: device input must be 4-byte aligned (the stem reads it as dwords)");
     if (!in_on_device) {
         size_t bytes = (size_t)B * 3 * c->H * c->W * (in_format == CF_IN_U8_HWC_BGR ? 1 : 4);
-        HIPCHK(c, hipMemcpyAsync(c->bufs[c->buf_in].p, in, bytes, hipMemcpyHostToDevice, c->stream));
-        *net_in = c->bufs[c->buf_in].p;
+        // only the u8 format fits the second staging buffer; f32 NCHW input (tests) keeps the single buffer
+        const bool two = in_format == CF_IN_U8_HWC_BGR;
+        const int slot = two ? (c->in_slot ^= 1) : 0;
+        void* dst = c->bufs[slot == 0 ? c->buf_in : c->buf_in2].p;
+        if (c->slot_busy[slot]) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_slot_free[slot], 0));   // its last reader (a stem) is done
+        HIPCHK(c, hipMemcpyAsync(dst, in, bytes, hipMemcpyHostToDevice, c->stream_in));
+        HIPCHK(c, hipEventRecord(c->ev_copy[slot], c->stream_in));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy[slot], 0));
+        c->in_slot_used = slot;
+        *net_in = dst;
     }
     return CF_OK;
 }
@@ -708,6 +729,11 @@ int launch_all_ops(cf_ctx* c, const void* net_in, int in_format, int B) {
         HIPCHK(c, launch_op(c, op, net_in, in_format, B));
     }
     HIPCHK(c, hipEventRecord(c->ev_fwd, c->stream));
+    if (c->in_slot_used >= 0) {                     // this forward read a host-input staging slot: mark when it is free again
+        HIPCHK(c, hipEventRecord(c->ev_slot_free[c->in_slot_used], c->stream));
+        c->slot_busy[c->in_slot_used] = true;
+        c->in_slot_used = -1;
+    }
     return CF_OK;
 }
 
