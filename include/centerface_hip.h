@@ -91,8 +91,8 @@ int cf_ctdet_loss(cf_ctx* ctx, const float* gt_hm, const uint8_t* reg_mask, cons
 
 /* ---- forward: replaces net(img)[0] (centerface.py:41, eval_widerface.py:83-84) ------------- */
 /* `in` is a host pointer (in_on_device = 0; copied H2D on a copy stream into one of two staging buffers, so the
- * copy overlaps the previous forward -- keep the buffer unchanged until the NEXT cf_forward / cf_synchronize
- * returns) or a device pointer on
+ * copy overlaps the previous forward -- keep the buffer unchanged until a blocking call on this context has
+ * returned: cf_synchronize, cf_get_heads or a decode with host outputs) or a device pointer on
  * ctx's GPU (in_on_device = 1; 4-byte aligned -- CF_EINVAL otherwise).  Asynchronous: returns after
  * enqueueing. */
 int cf_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B);
