@@ -760,3 +760,31 @@ def test_ctdet_loss_on_engine_heads_matches_explicit_maps():
     ref = O.ctdet_loss({k: torch.from_numpy(hd[k].copy()) for k in ("hm", "wh", "reg", "lm")}, {k: torch.from_numpy(v) for k, v in batch.items()})
     np.testing.assert_allclose(on_gpu, ref, rtol=2e-5, atol=1e-6)
     eng.close()
+
+
+def test_graph_cache_eviction_and_context_churn():
+    """More (batch size) keys than the 16-entry hipGraph cache holds: evicted graphs are rebuilt, results stay
+    bit-identical to eager launches; then 12 create/destroy cycles of contexts of different shapes (no leaked
+    streams / graphs / buffers that would make a later cf_create fail)."""
+    rng = np.random.default_rng(12)
+    H, W, MB = 64, 96, 20
+    eg = cfa.Engine(H, W, max_batch=MB, dtype="bf16", graph=True)
+    ee = cfa.Engine(H, W, max_batch=MB, dtype="bf16", graph=False)
+    x = rng.integers(0, 256, (MB, H, W, 3), dtype=np.uint8)
+    dg, de = eg.device_alloc(x.nbytes), ee.device_alloc(x.nbytes)
+    eg.memcpy_h2d(dg, x); ee.memcpy_h2d(de, x)
+    for rep in range(2):
+        for B in range(1, MB + 1):
+            for again in range(3):                       # second sighting captures, third replays; 20 keys > 16 slots
+                eg.forward_enqueue(dg, on_device=True, B=B, in_format=0)
+                ee.forward_enqueue(de, on_device=True, B=B, in_format=0)
+            if B % 5 == 0:
+                assert np.array_equal(eg.heads()["hm"], ee.heads()["hm"]), B
+    ng, nb = eg.graph_stats()
+    assert 1 <= ng <= 16 and nb == 0, (ng, nb)
+    eg.close(); ee.close()
+    for i in range(12):
+        e = cfa.Engine(32 * (1 + i % 4), 32 * (2 + i % 3), max_batch=2, dtype=("bf16", "fp32")[i % 2])
+        e.forward_enqueue(rng.integers(0, 256, (2, e.H, e.W, 3), dtype=np.uint8))
+        assert np.isfinite(e.heads()["hm"]).all()
+        e.close()
