@@ -5,7 +5,8 @@ this file; the product (``lightweight-face-detection-centernet_amd/``) never doe
 
 Parity status: PINNED.  The reference ships no tests or golden vectors, so
 the pins are outputs of the reference itself, imported in the build container by
-``tools/gen_goldens.py`` and committed under ``tests/golden/``; ``tests/test_oracle_vs_golden.py``
+``tools/gen_goldens.py`` (inference path) and ``tools/gen_goldens_train.py`` (loss / target encoder) and
+committed under ``tests/golden/``; ``tests/test_oracle_vs_golden.py``
 checks every function here against them.  Unpinned: ``cv2.resize`` (centerface.py:30) -- cv2 is not
 installed anywhere we can run, so only the identity-resize case (H, W multiples of 32) is covered.
 
