@@ -81,23 +81,34 @@ __global__ __launch_bounds__(1024) void peak_topk_kernel(TopkParams p) {
     // ---- pass 0: peak test (_nms), composite keys, and the histogram of the top 11 score bits
     for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < HW; i += 1024) {
-        const int y = i / p.w, x = i - y * p.w;
-        const float v = hm[(size_t)i * hs];
-        float mx = v;
+    // four cells per thread and iteration: all 4 x 9 loads are in flight before the first compare
+    for (int i0 = tid; i0 < HW; i0 += 4096) {
+        float v[4], mx[4];
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024;
+            const int ic = i < HW ? i : HW - 1;
+            const int y = ic / p.w, x = ic - y * p.w;
+            v[u] = hm[(size_t)ic * hs];
+            mx[u] = v[u];
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = y + dy, xx = x + dx;
-                if ((unsigned)yy < (unsigned)p.h && (unsigned)xx < (unsigned)p.w)
-                    mx = fmaxf(mx, hm[((size_t)yy * p.w + xx) * hs]);
-            }
-        // heat * keep  (keep = 1.0 where hmax == heat else 0.0); "+ 0.0f" canonicalises -0 to +0
-        const float kept = (mx == v) ? v : (v * 0.0f + 0.0f);
-        const uint32_t ok = orderable(kept);
-        keys[i] = ((u64)ok << 32) | (u64)(0xffffffffu - (uint32_t)i);
-        atomicAdd(&hist[ok >> 21], 1u);
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = min(max(y + dy, 0), p.h - 1), xx = min(max(x + dx, 0), p.w - 1);   // clamped = in-range duplicate
+                    mx[u] = fmaxf(mx[u], hm[((size_t)yy * p.w + xx) * hs]);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024;
+            if (i >= HW) break;
+            // heat * keep  (keep = 1.0 where hmax == heat else 0.0); "+ 0.0f" canonicalises -0 to +0
+            const float kept = (mx[u] == v[u]) ? v[u] : (v[u] * 0.0f + 0.0f);
+            const uint32_t ok = orderable(kept);
+            keys[i] = ((u64)ok << 32) | (u64)(0xffffffffu - (uint32_t)i);
+            atomicAdd(&hist[ok >> 21], 1u);
+        }
     }
     __syncthreads();
 
@@ -115,9 +126,13 @@ __global__ __launch_bounds__(1024) void peak_topk_kernel(TopkParams p) {
         if (pass > 0) {                                  // pass 0's histogram was built with the keys
             for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < HW; i += 1024) {
-                const u64 k = keys[i];
-                if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> sh) & ((1u << wd) - 1u)], 1u);
+            for (int i0 = tid; i0 < HW; i0 += 4096) {
+                u64 k[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) k[u] = keys[min(i0 + u * 1024, HW - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * 1024 < HW && (k[u] & mask) == prefix) atomicAdd(&hist[(uint32_t)(k[u] >> sh) & ((1u << wd) - 1u)], 1u);
             }
             __syncthreads();
         }
@@ -136,16 +151,23 @@ __global__ __launch_bounds__(1024) void peak_topk_kernel(TopkParams p) {
     // ---- compaction of the K survivors (order irrelevant: sorted next)
     if (tid == 0) nsel = 0;
     __syncthreads();
-    for (int i = tid; i < HW; i += 1024) {
-        const u64 k = keys[i];
-        if (k >= thresh) { uint32_t pos = atomicAdd(&nsel, 1u); if (pos < 1024) sel[pos] = k; }
+    for (int i0 = tid; i0 < HW; i0 += 4096) {
+        u64 k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = keys[min(i0 + u * 1024, HW - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * 1024 < HW && k[u] >= thresh) { uint32_t pos = atomicAdd(&nsel, 1u); if (pos < 1024) sel[pos] = k[u]; }
     }
     __syncthreads();
     u64 mine = (tid < p.K) ? sel[tid] : 0ull;
     __syncthreads();
 
-    // ---- bitonic sort, descending, 1024 elements (one per thread)
-    for (int k2 = 2; k2 <= 1024; k2 <<= 1) {
+    // ---- bitonic sort, descending, over the next power of two >= K elements (one per thread; the padding
+    //      keys are 0 and sink to the end)
+    int sortn = 64;
+    while (sortn < p.K) sortn <<= 1;
+    for (int k2 = 2; k2 <= sortn; k2 <<= 1) {
         for (int j = k2 >> 1; j > 0; j >>= 1) {
             u64 other;
             if (j >= 64) {
