@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
 // of a workgroup share every weight fragment: KT k-steps x NBW n-blocks of fragments are DMA'd
 // HBM/L2 -> LDS (global_load_lds_dwordx4, lane-linear = fragment order, conflict-free) once per
 // workgroup and read back at 256 B/clk/CU.  Activations still stream straight into registers.
-template <typename T, int NBW, int ACT, int RES>
+template <typename T, int NBW, int ACT, int RES, int NST>
 __global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
     constexpr int P = Elem<T>::PER16;
     constexpr int KT = 4;
@@ -192,29 +192,71 @@ __global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    for (int j0 = 0; j0 < NCh; j0 += KT) {
-        const int kt = NCh - j0 < KT ? NCh - j0 : KT;
-        for (int c = wave; c < NBW * kt; c += 4) {
-            const int i = c / kt, jj = c - i * kt;
-            if (nb0 + i < NB) {
-                const char* src = (const char*)p.wp + ((((size_t)(nb0 + i) * NCh + j0 + jj) * 64) + lane) * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(smem + (i * KT + jj) * 1024), 16, 0, 0);
+    // NST-stage ring: the weight DMA and the activation loads of K tile t + NST - 1 are issued while tile t
+    // runs.  The activations of these late layers come from HBM (~2 us); the K loop of one workgroup is a
+    // chain of 15 such tiles, so the kernel time was that chain's latency at every batch size.  Waits are
+    // PARTIAL (vmcnt(n): loads return in order, so "all but the n youngest" = tile t has landed): a
+    // __syncthreads() would wait for the prefetches as well.
+    constexpr int STAGE = NBW * KT * 1024;
+    constexpr int VM_PER_TILE = NBW * KT / 4 + KT;               // vm instructions one wave issues per tile
+    const int NT = (NCh + KT - 1) / KT;
+    auto prefetch = [&](int t, char* stage, u32x4* xn) {
+        const int j0 = t * KT;
+        // always NBW*KT/4 DMA instructions per wave (clamped source for the tail / missing n-blocks) so that the
+        // outstanding-instruction count per tile is a compile-time constant
+#pragma unroll
+        for (int q = 0; q < NBW * KT / 4; ++q) {                 // straight-line: the compiler must be able to count vm ops
+            const int c = wave + 4 * q;
+            const int i = c / KT, jj = c - i * KT;
+            const int ii = nb0 + i < NB ? nb0 + i : NB - 1, jc = j0 + jj < NCh ? j0 + jj : NCh - 1;
+            const char* src = (const char*)p.wp + ((((size_t)ii * NCh + jc) * 64) + lane) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + (i * KT + jj) * 1024), 16, 0, 0);
+        }
+        // no select on the loaded value here (it would force the wait at issue time): a chunk past this
+        // half's share is read from a clamped address and meets ZERO weights (pw_pack_weights leaves the
+        // fragment of a missing chunk zero); whole k-steps past NCh are skipped at consumption
+#pragma unroll
+        for (int jj = 0; jj < KT; ++jj) xn[jj] = ld16(xrow + (size_t)(j0 + jj < jmax ? j0 + jj : 0) * 16);
+    };
+    const int nbv = NB - nb0 < NBW ? NB - nb0 : NBW;
+    u32x4 xr[NST][KT];
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+        if (s0 < NT) prefetch(s0, smem + s0 * STAGE, xr[s0]);
+    for (int t0 = 0; t0 < NT; t0 += NST) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int t = t0 + u;
+            if (t >= NT) break;
+            // tiles t+1 .. t+NST-2 may still be in flight: wait for everything older than them
+            const int younger = min(NT - 1 - t, NST - 2);
+            if (NST >= 4 && younger >= 2) __builtin_amdgcn_s_waitcnt(((2 * VM_PER_TILE) & 0xF) | (((2 * VM_PER_TILE) >> 4) << 14) | 0x0F70);
+            else if (NST >= 3 && younger >= 1) __builtin_amdgcn_s_waitcnt((VM_PER_TILE & 0xF) | ((VM_PER_TILE >> 4) << 14) | 0x0F70);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();     // every wave's share of tile t is in LDS; all are done with tile t-1's stage
+            if (t + NST - 1 < NT) prefetch(t + NST - 1, smem + ((u + NST - 1) % NST) * STAGE, xr[(u + NST - 1) % NST]);
+            const int kt = NCh - t * KT < KT ? NCh - t * KT : KT;
+            const char* st = smem + u * STAGE;
+            if (nbv == NBW) {                              // wave-uniform: all n-blocks of this workgroup exist
+#pragma unroll
+                for (int jj = 0; jj < KT; ++jj) {
+                    if (jj < kt) {
+#pragma unroll
+                        for (int i = 0; i < NBW; ++i) Mma<T>::run(acc[i], ld16(st + (i * KT + jj) * 1024 + lane * 16), xr[u][jj]);
+                    }
+                }
+            } else {                                       // last n-group of a layer whose N is not a multiple of 32 NBW
+#pragma unroll
+                for (int jj = 0; jj < KT; ++jj) {
+                    if (jj < kt) {
+#pragma unroll
+                        for (int i = 0; i < NBW; ++i)
+                            if (i < nbv) Mma<T>::run(acc[i], ld16(st + (i * KT + jj) * 1024 + lane * 16), xr[u][jj]);
+                    }
+                }
             }
         }
-        u32x4 xc[KT];
-#pragma unroll
-        for (int jj = 0; jj < KT; ++jj) xc[jj] = (j0 + jj < jmax) ? ld16(xrow + (size_t)(j0 + jj) * 16) : zero16();
-        __syncthreads();
-#pragma unroll
-        for (int jj = 0; jj < KT; ++jj) {
-            if (jj < kt) {
-#pragma unroll
-                for (int i = 0; i < NBW; ++i)
-                    if (nb0 + i < NB) Mma<T>::run(acc[i], ld16(smem + (i * KT + jj) * 1024 + lane * 16), xc[jj]);
-            }
-        }
-        __syncthreads();
     }
     if (!mvalid) return;
 #pragma unroll
@@ -240,14 +282,14 @@ __global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
     }
 }
 
-template <typename T, int NBW>
+template <typename T, int NBW, int NST>
 static hipError_t dispatch_wlds(hipStream_t s, const PwParams& p, dim3 grid) {
     dim3 blk(256);
-    const size_t lds = (size_t)NBW * 4 * 1024;
+    const size_t lds = (size_t)NST * NBW * 4 * 1024;            // NST stages of [NBW][KT = 4][1 KiB]
     const int res = p.res ? 1 : 0;
 #define CF_PWL_LAUNCH(ACT, RES) \
-    set_kernel_tag("void cf::pw_wlds_kernel<%s, %d, %d, %d>(cf::PwParams)", type_tag<T>(), NBW, ACT, RES); \
-    hipLaunchKernelGGL((pw_wlds_kernel<T, NBW, ACT, RES>), grid, blk, lds, s, p); return hipGetLastError();
+    set_kernel_tag("void cf::pw_wlds_kernel<%s, %d, %d, %d, %d>(cf::PwParams)", type_tag<T>(), NBW, ACT, RES, NST); \
+    hipLaunchKernelGGL((pw_wlds_kernel<T, NBW, ACT, RES, NST>), grid, blk, lds, s, p); return hipGetLastError();
     if (p.act == 1 && res == 0) { CF_PWL_LAUNCH(1, 0) }
     if (p.act == 0 && res == 0) { CF_PWL_LAUNCH(0, 0) }
     if (p.act == 0 && res == 1) { CF_PWL_LAUNCH(0, 1) }
@@ -281,14 +323,19 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
     // GEMM-heavy layers (no bias / IDAUp epilogue): share weight fragments through LDS
     static const int wl_env = getenv("CF_PW_WLDS") ? atoi(getenv("CF_PW_WLDS")) : -1;     // A/B: 0 off, N = force NBW
     if (wl_env != 0 && !p.bias && !p.low && p.K >= 64 && NB >= 4 && (p.act == 1 || p.act == 0)) {
-        int nbw = wl_env > 0 ? wl_env : 4;     // measured best of {4,5,6,8} on every late layer
+        (void)wl_env;                          // NBW = 4 measured best of {4,5,6,8} on every late layer
+        static const int nst_env = getenv("CF_PW_NST") ? atoi(getenv("CF_PW_NST")) : 0;       // A/B: ring depth 2..4
+        static const int nbw_env = getenv("CF_PW_NBW") ? atoi(getenv("CF_PW_NBW")) : 0;
+        const int nbw = nbw_env ? nbw_env : (NB % 5 == 0 ? 5 : 4);      // N = 160 / 320: five n-blocks per wave, activations read once / twice
         dim3 grid((unsigned)gx, (unsigned)((NB + nbw - 1) / nbw));
-        switch (nbw) {
-            case 4: return dispatch_wlds<T, 4>(s, p, grid);
-            case 5: return dispatch_wlds<T, 5>(s, p, grid);
-            case 6: return dispatch_wlds<T, 6>(s, p, grid);
-            case 8: return dispatch_wlds<T, 8>(s, p, grid);
-            default: return dispatch_wlds<T, 5>(s, p, grid);
+        // ring depth: 3-4 stages (<= 64 KB of LDS) when the grid is at most half a workgroup per CU (small batches: the
+        // K chain's latency is the kernel time), 2 stages (more workgroups per CU) otherwise -- measured
+        const int nst = nst_env ? nst_env : ((long long)grid.x * grid.y <= 128 ? (nbw == 5 ? 3 : 4) : 2);
+        if (nbw == 5) return nst == 2 ? dispatch_wlds<T, 5, 2>(s, p, grid) : dispatch_wlds<T, 5, 3>(s, p, grid);
+        switch (nst) {
+            case 2: return dispatch_wlds<T, 4, 2>(s, p, grid);
+            case 3: return dispatch_wlds<T, 4, 3>(s, p, grid);
+            default: return dispatch_wlds<T, 4, 4>(s, p, grid);
         }
     }
     // n-blocks per wave: as many as fit 64..128 accumulator VGPRs, fewer when the grid would be
