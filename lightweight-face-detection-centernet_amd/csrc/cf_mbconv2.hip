@@ -476,29 +476,37 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
     }
     const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
     const unsigned rowbytes = (unsigned)p.Cin * 2;
-    auto load_x = [&](int ib, u32x4* xf) {
+    // raw loads from a clamped address; the zero-padding select is applied when the fragment is CONSUMED
+    // (a select at issue time would make the prefetch wait for its own data)
+    auto load_x = [&](int ib, u32x4* xf) -> bool {
         const int ip = ib * 32 + pl;
         const int ipc = ip < IPX ? ip : IPX - 1;
         const int iy = ipc / IWP, ix = ipc - iy * IWP;
         const int gy = oy0 * S - p.pad_lo + iy, gx = ox0 * S - p.pad_lo + ix;
-        const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
         const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
         const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
 #pragma unroll
+        for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
+        return ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+    };
+    auto mask_x = [&](u32x4* xf, bool valid) {
+#pragma unroll
         for (int j = 0; j < JX; ++j) {
-            const u32x4 v = ld16(xbase + off + j * 16);
-            xf[j].x = valid ? v.x : 0u; xf[j].y = valid ? v.y : 0u; xf[j].z = valid ? v.z : 0u; xf[j].w = valid ? v.w : 0u;
+            xf[j].x = valid ? xf[j].x : 0u; xf[j].y = valid ? xf[j].y : 0u; xf[j].z = valid ? xf[j].z : 0u; xf[j].w = valid ? xf[j].w : 0u;
         }
     };
     u32x4 xa[JX];
-    if (wave < NIB) load_x(wave, xa);
+    bool va = false;
+    if (wave < NIB) va = load_x(wave, xa);
     __syncthreads();
+    mask_x(xa, va);
 
     // ---- phase 1: expand + Swish -> pixel-pair tile
     for (int ib = wave; ib < NIB; ib += NW) {
         u32x4 xn[JX];
         const bool more = ib + NW < NIB;
-        if (more) load_x(ib + NW, xn);                             // next block's X under this block's math
+        bool vn = false;
+        if (more) vn = load_x(ib + NW, xn);                        // next block's X under this block's math
 #pragma unroll
         for (int nbl = 0; nbl < NBE; ++nbl) {
             f32x16 a;
@@ -523,6 +531,7 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
         if (more) {
 #pragma unroll
             for (int j = 0; j < JX; ++j) xa[j] = xn[j];
+            mask_x(xa, vn);
         }
     }
     __syncthreads();

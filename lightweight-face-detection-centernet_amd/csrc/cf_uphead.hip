@@ -42,24 +42,39 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
     // chunks 0,1, half 1 chunk 2), epilogue bias + ReLU, + ReLU(low * tap weight + shift), bf16 -> LDS
     const u32x4 wc0 = ld16((const char*)p.wcv + (size_t)(0 * 64 + lane) * 16);
     const u32x4 wc1 = ld16((const char*)p.wcv + (size_t)(1 * 64 + lane) * 16);
-    for (int ib = wave; ib < UH_NIB; ib += 4) {
+    // All global loads of this wave's (up to three) halo blocks are issued before the first result is
+    // consumed; padding selects are applied afterwards, on the registers.
+    constexpr int MAXB = (UH_NIB + 3) / 4;
+    u32x4 x0[MAXB], x1[MAXB], lw[MAXB][2];
+    bool valid[MAXB]; int tapv[MAXB];
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        const int ib = wave + 4 * t;
         const int ip = ib * 32 + pl;
         const int ipc = ip < UH_IPX ? ip : UH_IPX - 1;
         const int ty = ipc / UH_IW, tx = ipc - ty * UH_IW;
         const int gy = oy0 - 1 + ty, gx = ox0 - 1 + tx;
-        const bool valid = ip < UH_IPX && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
+        valid[t] = ib < UH_NIB && ip < UH_IPX && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
         const int cy = min(max(gy, 0), p.h - 1), cx = min(max(gx, 0), p.w - 1);
         const char* xrow = (const char*)p.skip + (((size_t)b * p.h + cy) * p.w + cx) * UH_PIT + h * 32;
-        const u32x4 x0 = ld16(xrow);
-        u32x4 x1 = ld16(xrow + (h == 0 ? 16 : 0));                 // half 1 has no second chunk
-        if (h != 0) x1 = zero16();
+        x0[t] = ld16(xrow);
+        x1[t] = ld16(xrow + (h == 0 ? 16 : 0));                    // half 1 has no second chunk (zeroed below)
+        const size_t low_row = ((size_t)b * (p.h >> 1) + (cy >> 1)) * (p.w >> 1) + (cx >> 1);
+        tapv[t] = ((cy & 1) << 1) | (cx & 1);
+        lw[t][0] = ld16((const char*)p.low + (low_row * 24 + h * 16) * 2);
+        lw[t][1] = ld16((const char*)p.low + (low_row * 24 + (h == 0 ? 8 : 16)) * 2);   // half 1 owns channels 16..23 only
+    }
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        const int ib = wave + 4 * t;
+        if (ib >= UH_NIB) break;
+        const int ip = ib * 32 + pl;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        acc = uh_mma(acc, wc0, x0);
-        acc = uh_mma(acc, wc1, x1);
-        const size_t low_row = ((size_t)b * (p.h >> 1) + (cy >> 1)) * (p.w >> 1) + (cx >> 1);
-        const int tap = ((cy & 1) << 1) | (cx & 1);
+        acc = uh_mma(acc, wc0, x0[t]);
+        acc = uh_mma(acc, wc1, h == 0 ? x1[t] : zero16());
+        const int tap = tapv[t];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int ch = h * 16 + g * 8;
@@ -67,11 +82,11 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
             float v[8], r[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = relu_f(acc[g * 8 + e] + p.bias[ch + e]);
-            unpack16<bf16_t>(ld16((const char*)p.low + (low_row * 24 + ch) * 2), r);
+            unpack16<bf16_t>(lw[t][g], r);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += relu_f(r[e] * p.upw[tap * 24 + ch + e] + p.upb[ch + e]);
             u32x4 o = pack16<bf16_t>(v);
-            if (!valid) o = zero16();
+            if (!valid[t]) o = zero16();
             st16(T3 + ip * UH_PIT + ch * 2, o);
         }
     }
