@@ -108,13 +108,25 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    for (int j = 0; j < NCh; ++j) {
-        u32x4 xc = (j < jmax) ? ld16(xrow + (size_t)j * 16) : zero16();
+    // four k-steps per trip, every load of the trip in flight before its first MFMA; a chunk past this half's
+    // share is read from a clamped address and meets zero weights (pw_pack_weights), so no load is predicated
+    const int nbv = NB - nb0 < NBW ? NB - nb0 : NBW;
+    for (int j0 = 0; j0 < NCh; j0 += 4) {
+        u32x4 xc[4], wc[4][NBW];
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) {
-            if (nb0 + i < NB) {                               // uniform
-                u32x4 wc = ld16(wbase + ((size_t)i * NCh + j) * 1024);
-                Mma<T>::run(acc[i], wc, xc);
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u < NCh ? j0 + u : NCh - 1;
+            xc[u] = ld16(xrow + (size_t)(j < jmax ? j : 0) * 16);
+#pragma unroll
+            for (int i = 0; i < NBW; ++i)
+                wc[u][i] = ld16(wbase + ((size_t)(i < nbv ? i : 0) * NCh + j) * 1024);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u < NCh) {                               // uniform
+#pragma unroll
+                for (int i = 0; i < NBW; ++i)
+                    if (i < nbv) Mma<T>::run(acc[i], wc[u][i], xc[u]);
             }
         }
     }
