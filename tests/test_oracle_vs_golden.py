@@ -1,6 +1,7 @@
 """Pins the oracle (oracle/centerface_oracle.py) against outputs of the reference itself
 (tests/golden/*.npz, produced by tools/gen_goldens.py importing /root/reference)."""
 import numpy as np
+import pytest
 import torch
 
 import centerface_amd as cfa
@@ -187,3 +188,29 @@ def test_target_encoding_and_losses_match_reference(golden):
         batch = {"hm": st("hm"), "reg_mask": st("reg_mask"), "ind": st("ind"), "wh": st("wh"), "reg": st("reg"),
                  "lm_mask": st("lm_mask"), "lm_ind": st("lm_ind"), "lm": st("landmarks")}
         np.testing.assert_allclose(O.ctdet_loss(out, batch), g["loss_" + name], rtol=1e-6, atol=1e-7)
+
+
+def test_reference_format_checkpoint_round_trip(tmp_path):
+    """A checkpoint written the way the reference writes it (train.py:165: torch.save(model.state_dict()), an
+    OrderedDict of tensors incl. the int64 num_batches_tracked buffers) loads through weights.load_checkpoint
+    into the exact arrays; a missing / extra / mis-shaped tensor is refused like load_state_dict(strict=True)."""
+    import torch
+    import centerface_amd as cfa
+    from collections import OrderedDict
+    sd = cfa.weights.synthetic_state_dict(3)
+    path = str(tmp_path / "model_epoch_100.pt")
+    torch.save(OrderedDict((k, torch.from_numpy(np.asarray(v))) for k, v in sd.items()), path)
+    back = cfa.weights.load_checkpoint(path)
+    assert list(back) == list(sd) and cfa.weights.fingerprint(back) == cfa.weights.fingerprint(sd)
+    # wrapped form {'state_dict': ...}
+    torch.save({"state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, "epoch": 100}, path)
+    assert cfa.weights.fingerprint(cfa.weights.load_checkpoint(path)) == cfa.weights.fingerprint(sd)
+    bad = dict(sd); bad.pop("hm.1.bias")
+    with pytest.raises(ValueError):
+        cfa.weights.validate_state_dict(bad)
+    bad = dict(sd); bad["extra.weight"] = np.zeros(3, np.float32)
+    with pytest.raises(ValueError):
+        cfa.weights.validate_state_dict(bad)
+    bad = dict(sd); bad["first_conv.0.1.weight"] = np.zeros((32, 3, 5, 5), np.float32)
+    with pytest.raises(ValueError):
+        cfa.weights.validate_state_dict(bad)
