@@ -301,15 +301,21 @@ size_t stem0px_wstem_bytes() { return 2 * 64 * 16; }
 size_t stem0px_wdw_dwords() { return 2 * 4 * 3 * 2 * 8; }
 // ws [32][3][3][3] (co, ci, ky, kx), wd [32][9], wp [16][32]
 void stem0px_pack(const float* ws, const float* wd, const float* wp, void* wstem_out, uint32_t* wdw_out, void* wproj_out) {
-    // stem, MFMA B operand: lane (n = channel, half h), chunk c, element e <-> tap t = c*16 + h*8 + e, t = ky*9 + kx*3 + ci
+    // stem, MFMA B operand: lane (n = channel, half h), chunk c, element e.  The k-slot <-> tap assignment is free
+    // (sum over k): group g = 2c + h < 3 holds taps 0..7 of kernel row g (8 CONTIGUOUS patch elements = four aligned
+    // dwords in LDS), group 3 holds tap 8 of rows 0, 1, 2 in its even slots (odd slots and slots 6, 7: zero weight,
+    // the operand there is whatever follows in the patch).  tap t = ky*9 + kx*3 + ci.
     __builtin_memset(wstem_out, 0, stem0px_wstem_bytes());
     for (int c = 0; c < 2; ++c)
         for (int lane = 0; lane < 64; ++lane) {
             const int co = lane & 31, h = lane >> 5;
             uint16_t* dst = (uint16_t*)((char*)wstem_out + ((size_t)c * 64 + lane) * 16);
             for (int e = 0; e < 8; ++e) {
-                const int t = c * 16 + h * 8 + e;
-                if (t >= 27) continue;
+                const int g = 2 * c + h;
+                int t;
+                if (g < 3) t = g * 9 + e;
+                else if (e < 6 && (e & 1) == 0) t = (e >> 1) * 9 + 8;
+                else continue;
                 const int ky = t / 9, kx = (t % 9) / 3, ci = t % 3;
                 dst[e] = host_f32_to_bf16(kS0NegLog2e * ws[((co * 3 + ci) * 3 + ky) * 3 + kx]);
             }
@@ -450,17 +456,17 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
         const int y = oy0 - 1 + ty, x = ox0 - 1 + tx;
         // a halo pixel outside the map is the depthwise conv's zero padding: zero operand row -> swish(0) = 0
         const bool inmap = ip < S0_IPX && (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo;
-        const T* xp = Xs + (2 * ty) * S0P_PROW + (2 * tx) * 3 + 2;
+        // eight aligned dword reads per lane, already in operand order (see stem0px_pack): no packing ops
+        const char* xp = reinterpret_cast<const char*>(Xs) + ((2 * ty) * S0P_PROW + (2 * tx) * 3 + 2) * 2;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             uint32_t w4[4];
 #pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) {
-                const int t0 = c * 16 + h * 8 + 2 * e2, t1 = t0 + 1;
-                const int ky0 = t0 / 9, r0 = t0 - 9 * ky0, ky1 = t1 / 9, r1 = t1 - 9 * ky1;
-                const uint32_t lo = t0 < 27 ? (uint32_t)xp[ky0 * S0P_PROW + r0] : 0u;
-                const uint32_t hi = t1 < 27 ? (uint32_t)xp[ky1 * S0P_PROW + r1] : 0u;
-                w4[e2] = inmap ? (lo | (hi << 16)) : 0u;
+            for (int i = 0; i < 4; ++i) {
+                const int off = c == 0 ? h * (S0P_PROW * 2) + 4 * i
+                                       : (h == 0 ? 2 * (S0P_PROW * 2) + 4 * i : 16 + (i < 2 ? i : 2) * (S0P_PROW * 2));
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(xp + off);
+                w4[i] = inmap ? v : 0u;
             }
             xg[t][c].x = w4[0]; xg[t][c].y = w4[1]; xg[t][c].z = w4[2]; xg[t][c].w = w4[3];
         }
