@@ -788,3 +788,20 @@ def test_graph_cache_eviction_and_context_churn():
         e.forward_enqueue(rng.integers(0, 256, (2, e.H, e.W, 3), dtype=np.uint8))
         assert np.isfinite(e.heads()["hm"]).all()
         e.close()
+
+
+def test_bf16_forward_is_bit_reproducible():
+    """Run-to-run determinism of the throughput path (no atomics in the network, fixed reduction orders, exact
+    top-K): ten forwards of the same resident batch give bit-identical head maps and detections."""
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (8, 320, 448, 3), dtype=np.uint8)
+    e = cfa.Engine(320, 448, max_batch=8, dtype="bf16")
+    d = e.device_alloc(x.nbytes); e.memcpy_h2d(d, x)
+    ref = None
+    for it in range(10):
+        e.forward_enqueue(d, on_device=True, B=8, in_format=0)
+        dets, lms, inds = e.decode_topk(64)
+        cur = (dets.tobytes(), lms.tobytes(), inds.tobytes(), e.heads()["lm"].tobytes())
+        ref = ref or cur
+        assert cur == ref, it
+    e.close()
