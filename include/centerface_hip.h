@@ -133,7 +133,10 @@ int cf_affine_from_center_scale(float cx, float cy, float scale_w, int out_w, in
 /* For each image: cells with hm > score_thresh in row-major order, boxes/landmarks with the
  * reference's arithmetic (offsets ignored, x2 = min(x1c + w, W)), greedy IoU >= nms_thresh
  * suppression in descending score order.  dets [B,max_out,5], lms [B,max_out,10] (may be NULL),
- * counts [B] = number of valid rows (kept boxes, in the reference's keep order).  Host buffers.
+ * counts [B] = number of boxes that survive NMS (in the reference's keep order); only the first max_out
+ * rows are written, so counts[b] > max_out tells the caller that image b was truncated (call again with a
+ * larger max_out).  Any number of cells above the threshold is accepted, as in the reference: the candidate
+ * workspace grows to the largest count seen (CF_ENOMEM if that does not fit).  Host buffers.
  * The reference ignores its `threshold` argument and uses 0.3 (centerface.py:77); pass 0.3f. */
 int cf_decode_threshold(cf_ctx* ctx, float score_thresh, float nms_thresh, int max_out,
                         float* dets, float* lms, int32_t* counts);
@@ -143,6 +146,11 @@ int cf_decode_threshold(cf_ctx* ctx, float score_thresh, float nms_thresh, int m
  * 0.5, exactly as that file does (:102-104) -- no landmarks; same greedy NMS (:112-152). */
 int cf_decode_threshold_ex(cf_ctx* ctx, int mode, float score_thresh, float nms_thresh, int max_out,
                            float* dets, float* lms, int32_t* counts);
+
+/* Same with an explicit clamp size: the reference's get_detections clamps boxes to a hard-coded (640, 640)
+ * whatever the input size (eval_widerface.py:88); cf_decode_threshold[_ex] clamp to the context's (H, W). */
+int cf_decode_threshold_sized(cf_ctx* ctx, int mode, float score_thresh, float nms_thresh, int img_h, int img_w,
+                              int max_out, float* dets, float* lms, int32_t* counts);
 
 /* ---- fused convenience: forward + D3 decode in one enqueue (eval_widerface.py:76-90 shape) -- */
 int cf_detect_topk(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int K,
@@ -166,6 +174,20 @@ typedef struct cf_op_time {
 } cf_op_time;
 int cf_profile_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int K,
                        cf_op_time* out, int cap, int* n_out);
+/* The launch plan of a context (model/centernet.py:263-280 as kernels) and a layer-by-layer trace for parity
+ * tests: cf_forward_trace runs the forward eagerly up to and including plan entry `op_index` and copies that
+ * entry's output to the host as NCHW float32 [B, C, H, W] (the head entry: C = 16 record channels hm_sigmoid,
+ * wh0-1, lm0-9, reg0-1, hm_raw).  Entries with fused_away != 0 are not launched (their work happens inside the
+ * next entry) and cannot be traced.  Blocking. */
+typedef struct cf_op_info {
+    char    name[48];            /* e.g. "layer1.0.mbconv" */
+    char    kind[16];            /* stem0 | mbconv | expdw | pw | dw | head | stem */
+    int32_t C, H, W;             /* output tensor */
+    int32_t fused_away;
+} cf_op_info;
+int cf_plan_size(cf_ctx* ctx, int* n);
+int cf_plan_op(cf_ctx* ctx, int i, cf_op_info* out);
+int cf_forward_trace(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int op_index, float* out_nchw);
 /* The context's HIP streams as opaque hipStream_t values: `main_stream` carries the forward (and the
  * host-output decodes), `decode_stream` the device-output top-K decode.  For callers that chain their own
  * device work (e.g. an RCCL all-gather of the decoded boxes on another stream) with stream/event waits

@@ -19,9 +19,9 @@ CF_EOVERFLOW = -6
 # every symbol include/centerface_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
     "cf_version", "cf_strerror", "cf_last_error", "cf_device_count", "cf_create", "cf_destroy",
-    "cf_load_weights", "cf_forward", "cf_forward_resized", "cf_get_resized_input", "cf_get_heads", "cf_decode_topk", "cf_decode_topk_post", "cf_affine_from_center_scale", "cf_decode_threshold", "cf_decode_threshold_ex",
+    "cf_load_weights", "cf_forward", "cf_forward_resized", "cf_get_resized_input", "cf_get_heads", "cf_decode_topk", "cf_decode_topk_post", "cf_affine_from_center_scale", "cf_decode_threshold", "cf_decode_threshold_ex", "cf_decode_threshold_sized",
     "cf_detect_topk", "cf_synchronize", "cf_event_record", "cf_event_elapsed_ms",
-    "cf_profile_forward", "cf_graph_stats", "cf_get_streams", "cf_ctdet_loss", "cf_device_alloc", "cf_device_free", "cf_memcpy_h2d", "cf_memcpy_d2h",
+    "cf_profile_forward", "cf_plan_size", "cf_plan_op", "cf_forward_trace", "cf_graph_stats", "cf_get_streams", "cf_ctdet_loss", "cf_device_alloc", "cf_device_free", "cf_memcpy_h2d", "cf_memcpy_d2h",
     "cf_op_last_error", "cf_op_mbconv", "cf_op_expand_dw", "cf_op_ctdet_loss", "cf_op_encode_targets", "cf_op_dwconv", "cf_op_pwconv", "cf_op_stem", "cf_op_idaup", "cf_op_heads",
     "cf_op_ctdet_decode", "cf_op_ctdet_post_process", "cf_op_decode_threshold", "cf_op_decode_threshold_ex", "cf_op_nms",
 )
@@ -35,6 +35,11 @@ class TensorDesc(C.Structure):
 class OpTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("kind", C.c_char * 16), ("kernel", C.c_char * 160), ("ms", C.c_float),
                 ("algo_bytes", C.c_double), ("flops", C.c_double)]
+
+
+class OpInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("kind", C.c_char * 16), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("fused_away", C.c_int32)]
 
 
 def build(force=False, verbose=False):
@@ -78,6 +83,7 @@ def lib():
         L.cf_affine_from_center_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.cf_op_ctdet_post_process.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.cf_decode_threshold_ex.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cf_decode_threshold_sized.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cf_op_decode_threshold_ex.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cf_decode_threshold.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -88,6 +94,9 @@ def lib():
         L.cf_event_elapsed_ms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.cf_profile_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(OpTime), C.c_int, C.POINTER(C.c_int)]
+        L.cf_plan_size.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.cf_plan_op.argtypes = [C.c_void_p, C.c_int, C.POINTER(OpInfo)]
+        L.cf_forward_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.cf_ctdet_loss.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_void_p]
         L.cf_op_ctdet_loss.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_void_p]
         L.cf_op_encode_targets.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 8

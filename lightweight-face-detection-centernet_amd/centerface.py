@@ -168,16 +168,47 @@ class Engine(object):
                                          C.c_void_p(int(lms_ptr)) if lms_ptr else None,
                                          C.c_void_p(int(inds_ptr)) if inds_ptr else None, 1))
 
-    def decode_threshold(self, score_thresh=0.3, nms_thresh=0.3, max_out=1024, mode="d1"):
+    def decode_threshold(self, score_thresh=0.3, nms_thresh=0.3, max_out=1024, mode="d1", size=None):
         """CenterFace.decode + nms on the last forward: list of (boxes [n,5], lms [n,10]) per image.
-        mode "d2" = eval_widerface.decode (eval_widerface.py:92-110): threshold honoured, offsets used."""
+        mode "d2" = eval_widerface.decode (eval_widerface.py:92-110): threshold honoured, offsets used.
+        ``size`` = (h, w) the boxes are clamped to (default: the engine's input size)."""
+        ih, iw = (self.H, self.W) if size is None else (int(size[0]), int(size[1]))
         B = self.last_B
-        dets = np.empty((B, max_out, 5), np.float32)
-        lms = np.empty((B, max_out, 10), np.float32)
-        counts = np.empty((B,), np.int32)
-        self._chk(self._L.cf_decode_threshold_ex(self._h, {"d1": 0, "d2": 1}[mode], float(score_thresh), float(nms_thresh),
-                                                 int(max_out), _lib.ptr(dets), _lib.ptr(lms), _lib.ptr(counts)))
+        while True:
+            dets = np.empty((B, max_out, 5), np.float32)
+            lms = np.empty((B, max_out, 10), np.float32)
+            counts = np.empty((B,), np.int32)
+            self._chk(self._L.cf_decode_threshold_sized(self._h, {"d1": 0, "d2": 1}[mode], float(score_thresh), float(nms_thresh),
+                                                        ih, iw, int(max_out), _lib.ptr(dets), _lib.ptr(lms), _lib.ptr(counts)))
+            if int(counts.max(initial=0)) <= max_out:
+                break
+            max_out = int(counts.max())          # more survivors than rows: the reference keeps them all, so do we
         return [(dets[b, :counts[b]].copy(), lms[b, :counts[b]].copy()) for b in range(B)]
+
+    # -- launch plan / layer trace (parity tests) ---------------------------------------------
+    def plan(self):
+        """The context's launch plan: list of dicts name/kind/C/H/W/fused_away."""
+        n = C.c_int()
+        self._chk(self._L.cf_plan_size(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            info = _lib.OpInfo()
+            self._chk(self._L.cf_plan_op(self._h, i, C.byref(info)))
+            out.append(dict(index=i, name=info.name.decode(), kind=info.kind.decode(), C=info.C, H=info.H, W=info.W,
+                            fused_away=bool(info.fused_away)))
+        return out
+
+    def trace(self, x, op_index):
+        """Run the forward up to plan entry ``op_index`` and return that entry's output as NCHW float32."""
+        x = np.ascontiguousarray(x)
+        in_format = _lib.CF_IN_U8_HWC_BGR if x.dtype == np.uint8 else _lib.CF_IN_F32_NCHW
+        if x.dtype != np.uint8:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+        op = self.plan()[op_index]
+        out = np.empty((x.shape[0], op["C"], op["H"], op["W"]), np.float32)
+        self._chk(self._L.cf_forward_trace(self._h, _lib.ptr(x), in_format, 0, x.shape[0], int(op_index), _lib.ptr(out)))
+        self.last_B = x.shape[0] if op_index == len(self.plan()) - 1 else 0
+        return out
 
     # -- timing -----------------------------------------------------------------------------
     def event_record(self, slot):
@@ -302,12 +333,16 @@ class CenterFace(object):
         wh = _lib.f32(scale)
         lm = _lib.f32(landmark) if landmark is not None else np.zeros((1, 10, h, w), np.float32)
         cap = max(1, min(h * w, 4096))
-        dets = np.empty((1, cap, 5), np.float32)
-        lms = np.empty((1, cap, 10), np.float32)
-        cnt = np.zeros((1,), np.int32)
-        _lib.check(L.cf_op_decode_threshold(self.device, _lib.ptr(hm), _lib.ptr(wh), _lib.ptr(lm), 1, h, w,
-                                            int(size[0]), int(size[1]), 0.3, float(self.nms_thresh), cap,
-                                            _lib.ptr(dets), _lib.ptr(lms), _lib.ptr(cnt)), op=True)
+        while True:
+            dets = np.empty((1, cap, 5), np.float32)
+            lms = np.empty((1, cap, 10), np.float32)
+            cnt = np.zeros((1,), np.int32)
+            _lib.check(L.cf_op_decode_threshold(self.device, _lib.ptr(hm), _lib.ptr(wh), _lib.ptr(lm), 1, h, w,
+                                                int(size[0]), int(size[1]), 0.3, float(self.nms_thresh), cap,
+                                                _lib.ptr(dets), _lib.ptr(lms), _lib.ptr(cnt)), op=True)
+            if int(cnt[0]) <= cap:
+                break
+            cap = int(cnt[0])
         n = int(cnt[0])
         if n == 0:
             return ([], []) if self.landmarks else []
@@ -329,46 +364,62 @@ class CenterFaceBuckets(object):
     """Variable-size input (BASELINE configs[3]: WIDER-style images of different shapes in one batch).
 
     The reference builds one ``CenterFace(h, w)`` per image shape (demo.py:76 even per image).  Here images are
-    bucketed by their network shape ``transform(h, w)`` (multiples of 32, centerface.py:68-71), every bucket
-    owns one ``CenterFace`` (one cf_ctx on the GPU, created on first use, all sharing the same weights), and
-    each bucket runs as full batches.  Results come back in the order of ``imgs``; every image gets exactly
-    what ``CenterFace(h, w)(img)`` returns for it."""
+    bucketed by their NETWORK shape ``transform(h, w)[:2]`` (multiples of 32, centerface.py:68-71): every bucket
+    owns one ``Engine`` (one cf_ctx on the GPU, created on first use, all sharing the same weights, graphs
+    reused), so all raw sizes that round up to the same network shape share a context.  Inside a bucket the
+    images of one raw size run as full ``forward_resized`` batches (the device resize takes one source size per
+    launch); the floor-division rescale uses each image's own ``scale_h`` / ``scale_w``.  Results come back in
+    the order of ``imgs``; every image gets exactly what ``CenterFace(h, w)(img)`` returns for it."""
 
-    def __init__(self, landmarks=True, *, weights=None, dtype="fp32", device=0, max_batch=32, max_buckets=8, **kw):
+    def __init__(self, landmarks=True, *, weights=None, dtype="fp32", device=0, max_batch=32, max_buckets=8,
+                 nms_thresh=0.3, max_dets=1024, collapse_heads=None):
         self.landmarks, self.dtype, self.device, self.max_batch, self.max_buckets = landmarks, dtype, device, max_batch, max_buckets
+        self.nms_thresh, self.max_dets, self.collapse_heads = nms_thresh, max_dets, collapse_heads
         self._weights = _weights.synthetic_state_dict(0) if weights is None else (
             _weights.load_checkpoint(weights) if isinstance(weights, str) else weights)
-        self._kw = kw
-        self._buckets = {}          # (h, w) -> CenterFace, in least-recently-used order
+        self._buckets = {}          # network (H, W) -> Engine, in least-recently-used order
+        self.created = 0            # contexts created so far (tests: raw sizes sharing a network shape share one)
 
-    def _detector(self, h, w):
-        key = (int(h), int(w))
-        det = self._buckets.pop(key, None)
-        if det is None:
+    def _engine(self, H, W):
+        key = (int(H), int(W))
+        eng = self._buckets.pop(key, None)
+        if eng is None:
             if len(self._buckets) >= self.max_buckets:             # evict the least recently used context
                 old = next(iter(self._buckets))
                 self._buckets.pop(old).close()
-            det = CenterFace(h, w, self.landmarks, weights=self._weights, dtype=self.dtype, device=self.device,
-                             max_batch=self.max_batch, **self._kw)
-        self._buckets[key] = det
-        return det
+            eng = Engine(H, W, max_batch=self.max_batch, dtype=self.dtype, device=self.device, weights=self._weights,
+                         collapse_heads=self.collapse_heads)
+            self.created += 1
+        self._buckets[key] = eng
+        return eng
 
     def detect(self, imgs, threshold=0.2):
-        order = {}
+        del threshold                                              # ignored by the reference's decode (centerface.py:77)
+        groups = {}                                                # network shape -> raw shape -> indices
         for i, im in enumerate(imgs):
-            im = np.asarray(im)
-            order.setdefault(im.shape[:2], []).append(i)
+            h, w = np.asarray(im).shape[:2]
+            H, W = CenterFace.transform(None, h, w)[:2]
+            groups.setdefault((H, W), {}).setdefault((h, w), []).append(i)
         out = [None] * len(imgs)
-        for (h, w), idx in order.items():
-            det = self._detector(h, w)
-            res = det.detect_batch([imgs[i] for i in idx], threshold)
-            for i, r in zip(idx, res):
-                out[i] = r
+        post = CenterFace.__new__(CenterFace)                      # only for _postprocess (no engine of its own)
+        post.landmarks = self.landmarks
+        for (H, W), raws in groups.items():
+            eng = self._engine(H, W)
+            for (h, w), idx in raws.items():
+                post.scale_h, post.scale_w = H / h, W / w
+                for j in range(0, len(idx), eng.max_batch):
+                    chunk = np.stack([np.asarray(imgs[i], dtype=np.uint8) for i in idx[j:j + eng.max_batch]])
+                    if (h, w) == (H, W):
+                        eng.forward_enqueue(chunk)
+                    else:
+                        eng.forward_resized_enqueue(chunk)
+                    for i, (dets, lms) in zip(idx[j:j + eng.max_batch], eng.decode_threshold(0.3, self.nms_thresh, self.max_dets)):
+                        out[i] = post._postprocess(dets, lms)
         return out
 
     __call__ = detect
 
     def close(self):
-        for det in self._buckets.values():
-            det.close()
+        for eng in self._buckets.values():
+            eng.close()
         self._buckets = {}

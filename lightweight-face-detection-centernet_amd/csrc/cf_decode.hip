@@ -280,7 +280,7 @@ __global__ __launch_bounds__(1024) void thresh_collect_kernel(ThreshParams p) {
     }
     if (tid == 0) {
         uint32_t n = base_s;
-        if (n > (uint32_t)p.cap) { n = p.cap; *p.overflow = 1; }
+        if (n > (uint32_t)p.cap) { atomicMax(p.overflow, (int)n); n = p.cap; }     // the host grows the workspace to the largest count and reruns
         p.cand_count[b] = (int)n;
     }
 }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64) void thresh_sweep_kernel(ThreshParams p) {
         ++kept;
         __syncthreads();
     }
-    if (lane == 0) p.counts[b] = kept < p.max_out ? kept : p.max_out;
+    if (lane == 0) p.counts[b] = kept;            // may exceed max_out: rows past max_out are not written, the caller sees the truncation
 }
 
 __global__ void affine_boxes_kernel(float* dets, const double* trans, int B, int K, int stride) {

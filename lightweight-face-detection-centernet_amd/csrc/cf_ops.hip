@@ -361,12 +361,16 @@ int cf_op_decode_threshold_ex(int device, int mode, const float* hm, const float
     std::vector<float> rec = make_records(hm, wh, reg, lm, B, h, w);
     const float* d_heads = sc.upv(rec);
     const int HW = h * w;
-    const int cap = HW < 4096 ? (HW + 63) / 64 * 64 : 4096;
-    int overflow = 0;
-    int r = run_threshold(sc, mode, d_heads, B, h, w, img_h, img_w, score_thresh, nms_thresh, cap, max_out, dets, lms, counts, &overflow);
-    if (r) return r;
-    if (overflow) { g_op_error = "candidate capacity exceeded"; return CF_EOVERFLOW; }
-    return CF_OK;
+    int cap = HW < 4096 ? (HW + 63) / 64 * 64 : 4096;
+    for (int attempt = 0; attempt < 2; ++attempt) {            // grow to the largest candidate count and rerun (see cf_decode_threshold_ex)
+        int overflow = 0;
+        int r = run_threshold(sc, mode, d_heads, B, h, w, img_h, img_w, score_thresh, nms_thresh, cap, max_out, dets, lms, counts, &overflow);
+        if (r) return r;
+        if (overflow <= cap) return CF_OK;
+        cap = ((overflow < HW ? overflow : HW) + 63) / 64 * 64;
+    }
+    g_op_error = "candidate capacity exceeded";
+    return CF_EOVERFLOW;
 }
 
 int cf_op_ctdet_post_process(int device, float* dets, const float* centers, const float* scales, int B, int K, int dim,

@@ -9,6 +9,7 @@
 // reused HBM buffers (ping/pong + expanded + depthwise) so the working set of a batch stays small
 // and L2 / Infinity-Cache resident between producer and consumer where it fits.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -70,7 +71,7 @@ struct cf_ctx {
     std::vector<Buf> bufs;
     std::vector<Op> ops;
     std::vector<void*> owned;                 // device allocations to free
-    int buf_in = -1, buf_heads = -1;
+    int buf_in = -1, buf_heads = -1, buf_resized = -1;
     // host inputs: H2D copies run on their own stream into two alternating staging buffers, so the copy of
     // batch i+1 overlaps the forward of batch i (PCIe-inclusive rate ~ max(copy, compute), not their sum)
     hipStream_t stream_in = nullptr; int buf_in2 = -1; int in_slot = 0; int in_slot_used = -1;
@@ -351,6 +352,9 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
     need(c, c->buf_in, (size_t)3 * H * W);
     c->buf_in2 = add_buf(c, "input2", false);
     need(c, c->buf_in2, ((size_t)3 * H * W + elem_size(dtype) - 1) / elem_size(dtype));     // 3*H*W BYTES per image (u8 only)
+    // cf_forward_resized writes here (not into a host-input staging slot: those belong to the copy stream's protocol)
+    c->buf_resized = add_buf(c, "input_resized", false);
+    need(c, c->buf_resized, ((size_t)3 * H * W + elem_size(dtype) - 1) / elem_size(dtype));
     for (auto& b : c->bufs) {
         size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256;
         if ((e = hipMalloc(&b.p, bytes)) != hipSuccess) return bail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "hipMalloc(activations)", e);
@@ -440,6 +444,22 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
     if (ws.m.size() != expected_keys) {
         return c->fail(CF_ESCHEMA, "state_dict has %zu tensors, the CenterFace schema has %zu (unexpected keys present)",
                        ws.m.size(), expected_keys);
+    }
+
+    // A reload on a live context (e.g. one checkpoint per epoch for the validation-loss path): the captured
+    // hipGraphs have the OLD weight pointers baked into their kernel parameters and the old buffers would stay
+    // allocated until cf_destroy -- drain the streams, drop every graph, free the previous weight set.
+    if (c->weights_loaded) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        HIPCHK(c, hipStreamSynchronize(c->stream_in));
+        c->dec_pending = false;
+        for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+        c->graphs.clear();
+        for (void* p : c->owned) hipFree(p);
+        c->owned.clear();
+        for (auto& op : c->ops) { op.wp = nullptr; op.bias = op.upw = op.upb = op.b1 = op.w1d = nullptr; op.wexp = nullptr; op.wdw = nullptr; op.wproj = nullptr; }
+        c->weights_loaded = false;
     }
 
     for (auto& op : c->ops) {
@@ -769,7 +789,7 @@ int cf_forward_resized(cf_ctx* c, const void* imgs, int in_on_device, int B, int
         HIPCHK(c, hipMemcpyAsync(c->src_stage, imgs, bytes, hipMemcpyHostToDevice, c->stream));
         src = c->src_stage;
     }
-    uint8_t* dst = (uint8_t*)c->bufs[c->buf_in].p;
+    uint8_t* dst = (uint8_t*)c->bufs[c->buf_resized].p;
     HIPCHK(c, launch_resize_u8(c->stream, src, dst, B, h, w, c->H, c->W));
     int r = launch_all_ops(c, dst, CF_IN_U8_HWC_BGR, B);
     if (r) return r;
@@ -779,7 +799,7 @@ int cf_forward_resized(cf_ctx* c, const void* imgs, int in_on_device, int B, int
 
 int cf_get_resized_input(cf_ctx* c, void* out_u8, int B) {
     if (!c || !out_u8 || B < 1 || B > c->max_batch) return CF_EINVAL;
-    HIPCHK(c, hipMemcpyAsync(out_u8, c->bufs[c->buf_in].p, (size_t)B * c->H * c->W * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_u8, c->bufs[c->buf_resized].p, (size_t)B * c->H * c->W * 3, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CF_OK;
 }
@@ -873,17 +893,24 @@ int cf_detect_topk(cf_ctx* c, const void* in, int in_format, int in_on_device, i
     return cf_decode_topk(c, K, 1, dets, lms, inds, out_on_device);
 }
 
-static int ensure_thresh_ws(cf_ctx* c, int max_out) {
-    const int HW = (c->H / 4) * (c->W / 4);
-    const int cap = HW < 4096 ? ((HW + 63) / 64 * 64) : 4096;
-    if (!c->t_cand) {
+static int ensure_thresh_ws(cf_ctx* c, int max_out, int cap) {
+    if (c->t_cap < cap) {
+        for (void* p : {(void*)c->t_cand, (void*)c->t_count, (void*)c->t_order, (void*)c->t_mask, (void*)c->t_counts, (void*)c->t_overflow})
+            if (p) hipFree(p);
+        c->t_cand = nullptr; c->t_count = nullptr; c->t_order = nullptr; c->t_mask = nullptr; c->t_counts = nullptr; c->t_overflow = nullptr;
+        c->t_cap = 0;
         const size_t mb = c->max_batch, words = (cap + 63) / 64;
-        HIPCHK(c, hipMalloc((void**)&c->t_cand, mb * cap * 16 * sizeof(float)));
-        HIPCHK(c, hipMalloc((void**)&c->t_count, mb * sizeof(int)));
-        HIPCHK(c, hipMalloc((void**)&c->t_order, mb * cap * sizeof(int)));
-        HIPCHK(c, hipMalloc((void**)&c->t_mask, mb * cap * words * sizeof(unsigned long long)));
-        HIPCHK(c, hipMalloc((void**)&c->t_counts, mb * sizeof(int)));
-        HIPCHK(c, hipMalloc((void**)&c->t_overflow, sizeof(int)));
+        hipError_t e = hipMalloc((void**)&c->t_cand, mb * cap * 16 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->t_count, mb * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->t_order, mb * cap * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->t_mask, mb * cap * words * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->t_counts, mb * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->t_overflow, sizeof(int));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return c->fail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "threshold-decode workspace for %d candidates per image x %d images: %s",
+                           cap, c->max_batch, hipGetErrorString(e));
+        }
         c->t_cap = cap;
     }
     if (c->t_maxout < max_out) {
@@ -904,25 +931,40 @@ int cf_decode_threshold(cf_ctx* c, float score_thresh, float nms_thresh, int max
 
 int cf_decode_threshold_ex(cf_ctx* c, int mode, float score_thresh, float nms_thresh, int max_out,
                            float* dets, float* lms, int32_t* counts) {
-    if (!c || !dets || !counts || max_out < 1 || (mode != 0 && mode != 1)) return CF_EINVAL;
+    if (!c) return CF_EINVAL;
+    return cf_decode_threshold_sized(c, mode, score_thresh, nms_thresh, c->H, c->W, max_out, dets, lms, counts);
+}
+
+int cf_decode_threshold_sized(cf_ctx* c, int mode, float score_thresh, float nms_thresh, int img_h, int img_w, int max_out,
+                              float* dets, float* lms, int32_t* counts) {
+    if (!c || !dets || !counts || max_out < 1 || (mode != 0 && mode != 1) || img_h < 1 || img_w < 1) return CF_EINVAL;
     if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_decode_threshold before cf_forward");
     HIPCHK(c, hipSetDevice(c->device));
-    int r = ensure_thresh_ws(c, max_out); if (r) return r;
-    const int B = c->last_B;
-    ThreshParams p{};
-    p.heads = (const float*)c->bufs[c->buf_heads].p; p.B = B; p.h = c->H / 4; p.w = c->W / 4;
-    p.img_h = c->H; p.img_w = c->W; p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = c->t_cap; p.mode = mode;
-    p.cand = c->t_cand; p.cand_count = c->t_count; p.order = c->t_order; p.mask = c->t_mask;
-    p.max_out = max_out; p.dets = c->t_dets; p.lms = c->t_lms; p.counts = c->t_counts; p.overflow = c->t_overflow;
-    HIPCHK(c, hipMemsetAsync(c->t_overflow, 0, sizeof(int), c->stream));
-    HIPCHK(c, launch_decode_threshold(c->stream, p));
-    int overflow = 0;
+    const int B = c->last_B, HW = (c->H / 4) * (c->W / 4);
+    // candidate capacity starts at 4096 per image and grows to the largest count seen (the reference's decode takes
+    // any number of cells above the threshold, centerface.py:78-79): on overflow the collect kernel reports the
+    // count, the workspace is reallocated and the decode reruns
+    int cap = c->t_cap > 0 ? c->t_cap : (HW < 4096 ? (HW + 63) / 64 * 64 : 4096);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int r = ensure_thresh_ws(c, max_out, cap); if (r) return r;
+        ThreshParams p{};
+        p.heads = (const float*)c->bufs[c->buf_heads].p; p.B = B; p.h = c->H / 4; p.w = c->W / 4;
+        p.img_h = img_h; p.img_w = img_w; p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = c->t_cap; p.mode = mode;
+        p.cand = c->t_cand; p.cand_count = c->t_count; p.order = c->t_order; p.mask = c->t_mask;
+        p.max_out = max_out; p.dets = c->t_dets; p.lms = c->t_lms; p.counts = c->t_counts; p.overflow = c->t_overflow;
+        HIPCHK(c, hipMemsetAsync(c->t_overflow, 0, sizeof(int), c->stream));
+        HIPCHK(c, launch_decode_threshold(c->stream, p));
+        int overflow = 0;
+        HIPCHK(c, hipMemcpyAsync(&overflow, c->t_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (overflow > c->t_cap && attempt == 0) { cap = (std::min(overflow, HW) + 63) / 64 * 64; continue; }
+        if (overflow > c->t_cap) return c->fail(CF_EOVERFLOW, "more than %d cells above the score threshold in one image", c->t_cap);
+        break;
+    }
     HIPCHK(c, hipMemcpyAsync(dets, c->t_dets, (size_t)B * max_out * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (lms) HIPCHK(c, hipMemcpyAsync(lms, c->t_lms, (size_t)B * max_out * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(counts, c->t_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&overflow, c->t_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (overflow) return c->fail(CF_EOVERFLOW, "more than %d cells above the score threshold in one image", c->t_cap);
     return CF_OK;
 }
 
@@ -993,6 +1035,51 @@ int cf_profile_forward(cf_ctx* c, const void* in, int in_format, int in_on_devic
     }
     for (auto& e : ev) hipEventDestroy(e);
     *n_out = i;
+    return CF_OK;
+}
+
+int cf_plan_size(cf_ctx* c, int* n) {
+    if (!c || !n) return CF_EINVAL;
+    *n = (int)c->ops.size();
+    return CF_OK;
+}
+
+int cf_plan_op(cf_ctx* c, int i, cf_op_info* out) {
+    if (!c || !out || i < 0 || i >= (int)c->ops.size()) return CF_EINVAL;
+    const Op& op = c->ops[i];
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
+    snprintf(out->kind, sizeof out->kind, "%s", kKindName[op.kind]);
+    out->C = op.kind == OP_HEAD ? 16 : op.Cout; out->H = op.Hout; out->W = op.Wout;
+    out->fused_away = op.fused_away ? 1 : 0;
+    return CF_OK;
+}
+
+int cf_forward_trace(cf_ctx* c, const void* in, int in_format, int in_on_device, int B, int op_index, float* out_nchw) {
+    if (!c || !out_nchw) return CF_EINVAL;
+    if (op_index < 0 || op_index >= (int)c->ops.size()) return c->fail(CF_EINVAL, "cf_forward_trace: op_index %d outside the plan", op_index);
+    if (c->ops[op_index].fused_away) return c->fail(CF_EINVAL, "cf_forward_trace: plan entry %d is fused into the next one", op_index);
+    const void* net_in = nullptr;
+    int r = stage_input(c, in, in_format, in_on_device, B, &net_in);
+    if (r) return r;
+    if (c->dec_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dec, 0)); c->dec_pending = false; }
+    for (int i = 0; i <= op_index; ++i) HIPCHK(c, launch_op(c, c->ops[i], net_in, in_format, B));
+    if (c->in_slot_used >= 0) {
+        HIPCHK(c, hipEventRecord(c->ev_slot_free[c->in_slot_used], c->stream));
+        c->slot_busy[c->in_slot_used] = true; c->in_slot_used = -1;
+    }
+    const Op& op = c->ops[op_index];
+    const bool head = op.kind == OP_HEAD;
+    const int C = head ? 16 : op.Cout;
+    const size_t n = (size_t)B * C * op.Hout * op.Wout;
+    float* tmp = nullptr;
+    HIPCHK(c, hipMalloc((void**)&tmp, n * sizeof(float)));
+    hipError_t e = launch_nhwc_to_nchw(c->stream, head ? CF_F32 : c->dtype, c->bufs[op.out].p, tmp, B, C, op.Hout, op.Wout);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_nchw, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return c->fail(CF_EHIP, "cf_forward_trace: %s", hipGetErrorString(e));
+    c->last_B = op_index + 1 == (int)c->ops.size() ? B : 0;      // heads are only valid after the whole plan ran
     return CF_OK;
 }
 

@@ -5,8 +5,10 @@ Tolerances (BASELINE.json north_star): top-k indices bit-exact, box/score fp32 w
   * fp32 mode (CF_F32: fp32 storage + exact-fp32 MFMA) is the parity mode: 1e-3 abs/rel end to end,
     ~1e-5 per op.  Decode kernels are integer/selection work on given fp32 maps: bit-exact.
   * bf16 mode (CF_BF16) is the throughput mode; its error is bf16 rounding of every stored
-    activation (the reference itself run in bf16 shows head error mean 0.026), so it is
-    checked per op against bf16-rounded inputs at 2^-7 relative and end to end statistically.
+    activation (the reference itself run in bf16 shows head error mean 0.026).  It is checked
+    against the bf16-EMULATING oracle (oracle/bf16_emulation.py, pinned to a hooked run of the reference) at
+    one bf16 ulp + flip noise per kernel; the production instances and the engine layer by layer are in
+    tests/test_bf16_parity.py.
 """
 import numpy as np
 import pytest
@@ -14,12 +16,21 @@ import torch
 
 import centerface_amd as cfa
 from centerface_amd import ops
+from oracle import bf16_emulation as E
 from oracle import centerface_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 F32 = dict(rtol=2e-5, atol=2e-5)
-BF16 = dict(rtol=2.5e-2, atol=2.5e-2)
+BF16 = dict(rtol=2.5e-2, atol=2.5e-2)      # only for bf16 flavours of ops that are NOT on the engine's bf16 path (unfused stem, two-stage heads)
+
+
+def _emu_close(got, ref, what, bf16_output=True):
+    """bf16 kernels against the bf16-emulating oracle: one bf16 ulp + flip noise (oracle/bf16_emulation.py)."""
+    ref = ref.numpy() if hasattr(ref, "numpy") else np.asarray(ref)
+    r = np.abs(np.asarray(got, np.float64) - ref.astype(np.float64)) / E.tolerance(ref)
+    stat = (float(r.max()), float((r > 1).mean()), float((r > 0.5).mean()), float((r > 0).mean()), int(r.size))
+    assert E.accept(stat, bf16_output), (what, stat)
 
 
 def _tol(dtype):
@@ -48,9 +59,15 @@ def test_conv_swish_flavours_vs_reference(golden, dtype):
     for i in range(1, 5):
         cin, cout, k, s, groups = (int(v) for v in g["cr%d_cfg" % i])
         y = ops.conv_dw(g["cr%d_x" % i], g["cr%d_w" % i], k, s, dtype=dtype)
-        np.testing.assert_allclose(y, g["cr%d_y" % i], **_tol(dtype), err_msg="cr%d" % i)
+        if dtype == "bf16":
+            _emu_close(y, E.dw_op(g["cr%d_x" % i], g["cr%d_w" % i], k, s), "cr%d" % i)
+        else:
+            np.testing.assert_allclose(y, g["cr%d_y" % i], **_tol(dtype), err_msg="cr%d" % i)
     y = ops.conv_pw(g["cr5_x"], g["cr5_w"], act="swish", dtype=dtype)
-    np.testing.assert_allclose(y, g["cr5_y"], **_tol(dtype))
+    if dtype == "bf16":
+        _emu_close(y, E.pw_op(g["cr5_x"], g["cr5_w"], act="swish"), "cr5")
+    else:
+        np.testing.assert_allclose(y, g["cr5_y"], **_tol(dtype))
 
 
 def _mbconv_gpu(x, sd, cin, cout, t, k, s, dtype):
@@ -68,9 +85,15 @@ def test_mbconv_blocks_vs_reference(golden, dtype):
     g = golden("ops")
     for i in range(9):
         cin, cout, t, k, s = (int(v) for v in g["mb%d_cfg" % i])
-        y = _mbconv_gpu(g["mb%d_x" % i], _sub(g, "mb%d_w_" % i), cin, cout, t, k, s, dtype)
-        tol = dict(rtol=1e-4, atol=1e-4) if dtype == "fp32" else dict(rtol=6e-2, atol=6e-2)
-        np.testing.assert_allclose(y, g["mb%d_y" % i], **tol, err_msg="mb%d" % i)
+        sd = _sub(g, "mb%d_w_" % i)
+        y = _mbconv_gpu(g["mb%d_x" % i], sd, cin, cout, t, k, s, dtype)
+        if dtype == "fp32":
+            np.testing.assert_allclose(y, g["mb%d_y" % i], rtol=1e-4, atol=1e-4, err_msg="mb%d" % i)
+        else:       # three bf16 kernels: every intermediate is an HBM tensor
+            j = 0 if t == 1 else 1
+            emu = E.mbconv_unfused(E.q_bf16(torch.from_numpy(g["mb%d_x" % i])), sd["conv.0.1.weight"] if t != 1 else None,
+                                   sd["conv.%d.1.weight" % j], sd["conv.%d.weight" % (j + 1)], k, s, cin == cout and s == 1)
+            _emu_close(y, emu, "mb%d" % i)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -85,8 +108,13 @@ def test_fused_mbconv_vs_reference(golden, dtype):
             continue
         sd = _sub(g, "mb%d_w_" % i)
         y = ops.mbconv(g["mb%d_x" % i], sd["conv.0.1.weight"], sd["conv.1.1.weight"], sd["conv.2.weight"], k, s, dtype=dtype)
-        tol = dict(rtol=1e-4, atol=1e-4) if dtype == "fp32" else dict(rtol=6e-2, atol=6e-2)
-        np.testing.assert_allclose(y, g["mb%d_y" % i], **tol, err_msg="mb%d" % i)
+        if dtype == "fp32":
+            np.testing.assert_allclose(y, g["mb%d_y" % i], rtol=1e-4, atol=1e-4, err_msg="mb%d" % i)
+        else:
+            we, wp = sd["conv.0.1.weight"], sd["conv.2.weight"]
+            emu = E.mbconv_fused(E.q_bf16(torch.from_numpy(g["mb%d_x" % i])), we.reshape(we.shape[0], -1), sd["conv.1.1.weight"],
+                                 wp.reshape(wp.shape[0], -1), k, s, cin == cout and s == 1)
+            _emu_close(y, emu, "mb%d" % i)
         done += 1
     assert done == 6
 
@@ -106,7 +134,9 @@ def test_fused_mbconv_multi_tile_vs_oracle(cfg):
     y = ops.mbconv(x, sd["b.conv.0.1.weight"], sd["b.conv.1.1.weight"], sd["b.conv.2.weight"], k, s, dtype="fp32")
     np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
     yb = ops.mbconv(x, sd["b.conv.0.1.weight"], sd["b.conv.1.1.weight"], sd["b.conv.2.weight"], k, s, dtype="bf16")
-    assert np.abs(yb - ref).max() < 0.15 and np.abs(yb - ref).mean() < 0.02
+    emu = E.mbconv_fused(E.q_bf16(torch.from_numpy(x)), sd["b.conv.0.1.weight"].reshape(hid, cin), sd["b.conv.1.1.weight"],
+                         sd["b.conv.2.weight"].reshape(cout, hid), k, s, cin == cout and s == 1)
+    _emu_close(yb, emu, cfg)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -117,14 +147,26 @@ def test_conv1x1bn_idaup_heads_vs_reference(golden, dtype):
     w = (sd["conv_last.0.weight"].reshape(24, 320) * sc[:, None]).astype(np.float32)
     b = (sd["conv_last.1.bias"] - sd["conv_last.1.running_mean"] * sc).astype(np.float32)
     y = ops.conv_pw(g["c1bn_x"], w, act="swish", bias=b, dtype=dtype)
-    np.testing.assert_allclose(y, g["c1bn_y"], **(dict(rtol=1e-4, atol=1e-4) if dtype == "fp32" else BF16))
+    if dtype == "fp32":
+        np.testing.assert_allclose(y, g["c1bn_y"], rtol=1e-4, atol=1e-4)
+    else:
+        _emu_close(y, E.conv_last(E.q_bf16(torch.from_numpy(g["c1bn_x"])), O.to_torch_sd(sd)), "conv_1x1_bn")
     for i in range(3):
         y = ops.idaup(g["ida%d_lo" % i], g["ida%d_skip" % i], _sub(g, "ida%d_w_" % i), "up", dtype=dtype)
-        np.testing.assert_allclose(y, g["ida%d_y" % i], **(dict(rtol=1e-4, atol=1e-4) if dtype == "fp32" else BF16))
+        if dtype == "fp32":
+            np.testing.assert_allclose(y, g["ida%d_y" % i], rtol=1e-4, atol=1e-4)
+        else:
+            _emu_close(y, E.idaup(E.q_bf16(torch.from_numpy(g["ida%d_lo" % i])), E.q_bf16(torch.from_numpy(g["ida%d_skip" % i])),
+                                  O.to_torch_sd(_sub(g, "ida%d_w_" % i)), "up"), "ida%d" % i)
     full = cfa.weights.synthetic_state_dict(0)
     for collapse in (False, True):
         out = ops.heads(g["head_x"], full, collapse=collapse, dtype=dtype)
-        np.testing.assert_allclose(out["lm"], g["head_y"], **(dict(rtol=1e-4, atol=1e-4) if dtype == "fp32" else BF16))
+        if dtype == "bf16" and collapse:            # the engine's bf16 flavour: collapsed 3x3 24 -> 15, fp32 out
+            emu = E.heads(E.q_bf16(torch.from_numpy(g["head_x"])), O.to_torch_sd(full))
+            for k in ("hm", "wh", "lm", "reg"):
+                _emu_close(out[k], emu[k], "head." + k, bf16_output=False)
+        else:
+            np.testing.assert_allclose(out["lm"], g["head_y"], **(dict(rtol=1e-4, atol=1e-4) if dtype == "fp32" else BF16))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -209,18 +251,30 @@ def test_uint8_image_path_fp32(golden):
     eng.close()
 
 
-def test_network_bf16_statistical(golden):
-    """bf16 storage mode against the fp32 reference goldens: bounded, unbiased error."""
-    g = golden("net")
-    x = g["x_b"]
-    eng = cfa.Engine(64, 96, max_batch=2, dtype="bf16")
-    out = eng.forward(x)
+def test_network_bf16_vs_hooked_reference(golden):
+    """bf16 engine against the REFERENCE run with the engine's roundings inserted by hooks (net_bf16emu.npz):
+    the 32x32 case end to end (no rounding flip on so small a map: agreement to 2e-3 of a map whose rms is 1.4-4.3),
+    the larger cases block by block on the golden's... no: on the ENGINE's own block inputs (teacher forcing, see
+    tests/test_bf16_parity.py), with the golden as the independent end-to-end cross-check at drift level."""
+    g = golden("net_bf16emu")
+    sd = cfa.weights.synthetic_state_dict(0)
+    eng = cfa.Engine(32, 32, max_batch=1, dtype="bf16")
+    out = eng.forward(g["x_a"])
     for h in ("hm", "wh", "lm", "reg"):
-        ref = g["%s_b" % h]
-        err = np.abs(out[h] - ref)
-        assert err.mean() < 0.05 and err.max() < 0.8, (h, err.mean(), err.max())
-        assert abs((out[h] - ref).mean()) < 0.02
+        np.testing.assert_allclose(out[h], g[h + "_a"], rtol=0, atol=2e-3, err_msg=h)
     eng.close()
+    for tag in "bc":
+        x = g["x_" + tag]
+        eng = cfa.Engine(x.shape[2], x.shape[3], max_batch=1, dtype="bf16")
+        out = eng.forward(x)
+        for h in ("hm", "wh", "lm", "reg"):
+            ref = g["%s_%s" % (h, tag)]
+            d = np.abs(out[h] - ref)
+            rms = float(np.sqrt((ref ** 2).mean()))
+            assert d.mean() <= 0.006 * rms and d.max() <= 0.12 * rms, (tag, h, float(d.mean()) / rms, float(d.max()) / rms)
+        # first block: bit-level agreement with the hooked reference (nothing upstream to drift)
+        _emu_close(eng.trace(x, 0), E.from_bf16_bits(g["layer0.0_" + tag]), "layer0.0_" + tag)
+        eng.close()
 
 
 def test_forward_errors_are_loud():
@@ -362,13 +416,15 @@ def test_decode_d2_and_get_detections(golden):
     rng = np.random.default_rng(31)
     x = rng.standard_normal((3, 3, 64, 96)).astype(np.float32)
     eng = cfa.Engine(64, 96, max_batch=2, dtype="fp32")
-    dets = ew.get_detections({"input": x}, eng, threshold=0.2)
-    assert len(dets) == 3
+    dets = ew.get_detections({"input": x}, eng, threshold=0.2)                  # clamps to the reference's hard-coded (640, 640), :88
+    dets_own = ew.get_detections({"input": x}, eng, threshold=0.2, size=None)   # clamps to the engine's input size
+    assert len(dets) == 3 and len(dets_own) == 3
     for i in range(3):
         eng.forward_enqueue(x[i:i + 1])
         hd = eng.heads(sigmoid_hm=True)
-        ref = O.decode_d2(hd["hm_sigmoid"][0], hd["wh"][0], hd["reg"][0], (64, 96), threshold=0.2)
-        assert np.array_equal(np.asarray(dets[i], np.float32).reshape(-1, 5), np.asarray(ref, np.float32).reshape(-1, 5))
+        for got, size in ((dets[i], (640, 640)), (dets_own[i], (64, 96))):
+            ref = O.decode_d2(hd["hm_sigmoid"][0], hd["wh"][0], hd["reg"][0], size, threshold=0.2)
+            assert np.array_equal(np.asarray(got, np.float32).reshape(-1, 5), np.asarray(ref, np.float32).reshape(-1, 5))
     eng.close()
 
 
@@ -561,12 +617,7 @@ def test_batch64_bf16_properties():
     assert (np.diff(d1[..., 4], axis=1) <= 0).all()
     assert i1.min() >= 0 and i1.max() < 160 * 160
     assert all(len(np.unique(row)) == 100 for row in i1[:4])
-    # against the fp32 oracle on one image: the detection SET overlaps strongly (98 %)
-    sd = cfa.weights.synthetic_state_dict(0)
-    ref = O.forward(O.to_torch_sd(sd), torch.from_numpy(O.preprocess(base[0])))
-    _, _, rinds = O.ctdet_decode(O.sigmoid_clamp(ref["hm"]).numpy(), ref["wh"].numpy(), ref["reg"].numpy(), 100)
-    overlap = len(set(i1[0].tolist()) & set(rinds[0].tolist()))
-    assert overlap >= 85, overlap
+    # accuracy of this batch against the bf16-emulating oracle: tests/test_bf16_parity.py::test_batch64_end_to_end_vs_emulation
     eng.close()
 
 
@@ -586,45 +637,34 @@ def test_expand_dw_kernel_vs_oracle(cfg):
     ref = O.conv_swish(O.conv_swish(t, torch.from_numpy(we), 1, 1), torch.from_numpy(wd), k, s, groups=hid).numpy()
     y = ops.expand_dw(x, we, wd, k, s, dtype="bf16")
     assert y.shape == ref.shape
-    d = np.abs(y - ref)
+    _emu_close(y, E.expand_dw(E.q_bf16(t), we.reshape(hid, cin), wd, k, s, out_scaled=False), cfg)
+    d = np.abs(y - ref)                                # and the fp32 oracle at the bf16 noise floor
     assert d.max() < 0.08 and d.mean() < 0.006, (float(d.max()), float(d.mean()))
     with pytest.raises(ValueError):
         ops.expand_dw(x, we, wd, k, s, dtype="fp32")           # bf16-only kernel: loud, no fallback
 
 
-@pytest.mark.parametrize("size", [(96, 128), (160, 224), (480, 640)])
-def test_bf16_engine_tracks_fp32_engine(size):
-    """The bf16 throughput path (second-generation fused kernels: fp16 pixel-pair tiles, dot2c depthwise,
-    pre-scaled Swish) against the fp32 parity path on map sizes that are not multiples of any tile, so
-    every kernel has edge tiles: a misplaced halo or a dropped edge pixel shows up as an O(1) error
-    at the border, far outside the bf16 noise floor asserted here."""
-    H, W = size
-    rng = np.random.default_rng(H * 7 + W)
-    x = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
-    e32 = cfa.Engine(H, W, max_batch=2, dtype="fp32")
-    e16 = cfa.Engine(H, W, max_batch=2, dtype="bf16")
-    e32.forward_enqueue(x); e16.forward_enqueue(x)
-    h32, h16 = e32.heads(), e16.heads()
-    for k in ("hm", "wh", "lm", "reg"):
-        d = np.abs(h16[k] - h32[k])
-        scale = np.abs(h32[k]).mean() + 1e-6
-        assert d.mean() / scale < 0.03, (k, d.mean() / scale)
-        assert d.max() < 0.25 * max(1.0, float(np.abs(h32[k]).max())), (k, float(d.max()))
-        # borders are as good as the interior
-        border = np.concatenate([d[..., :2, :].ravel(), d[..., -2:, :].ravel(), d[..., :, :2].ravel(), d[..., :, -2:].ravel()])
-        assert border.mean() < 3.0 * d.mean() + 1e-3, (k, float(border.mean()), float(d.mean()))
-    e32.close(); e16.close()
+# (bf16 engine on sizes that are not multiples of any tile / smaller than a tile: tests/test_bf16_parity.py,
+#  layer by layer against the emulating oracle -- it replaced the bf16-vs-fp32-engine noise-floor tests that stood here)
 
 
 def test_variable_size_buckets_match_per_shape_detectors():
     """BASELINE configs[3] (VGA-class images of different shapes in one batch): CenterFaceBuckets groups by
     network shape and must return, per image and in input order, exactly what CenterFace(h, w)(img) returns."""
     rng = np.random.default_rng(2024)
-    shapes = [(480, 640), (640, 480), (640, 640), (448, 640), (640, 416), (478, 720), (300, 500)]
-    imgs = [rng.integers(0, 256, shapes[i % len(shapes)] + (3,), dtype=np.uint8) for i in range(17)]
+    shapes = [(480, 640), (640, 480), (640, 640), (448, 640), (640, 416), (478, 720), (300, 500), (470, 730), (630, 470)]
+    imgs = [rng.integers(0, 256, shapes[i % len(shapes)] + (3,), dtype=np.uint8) for i in range(21)]
     pool = cfa.CenterFaceBuckets(dtype="fp32", max_batch=4, max_buckets=4)        # fewer contexts than shapes: eviction
     got = pool.detect(imgs)
     assert len(got) == len(imgs)
+    # raw sizes that round up to the same network shape share one context: (478,720)/(470,730) -> 480x736,
+    # (640,480)/(630,470) -> 640x480; 9 raw shapes = 7 network shapes
+    roomy = cfa.CenterFaceBuckets(dtype="fp32", max_batch=4, max_buckets=16)
+    got2 = roomy.detect(imgs)
+    assert roomy.created == 7
+    for a, b2 in zip(got, got2):
+        assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1])
+    roomy.close()
     for (h, w) in shapes:
         one = cfa.CenterFace(h, w, dtype="fp32")
         for i, im in enumerate(imgs):
@@ -653,28 +693,6 @@ def test_fused_up3_heads_bit_equal_to_two_kernels(size):
     df, d2 = ef.decode_topk(50), e2.decode_topk(50)
     assert np.array_equal(df[2], d2[2]) and np.array_equal(df[0], d2[0])
     ef.close(); e2.close()
-
-
-@pytest.mark.parametrize("size", [(32, 32), (64, 96), (32, 640)])
-def test_bf16_engine_on_maps_smaller_than_a_tile(size):
-    """Smallest legal inputs: the stride-32 map is 1 x 1, every fused kernel runs a single partly filled
-    tile (halo entirely in the zero padding).  bf16 path vs fp32 path: finite, close, same top peaks."""
-    H, W = size
-    rng = np.random.default_rng(H * 3 + W)
-    x = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
-    e32 = cfa.Engine(H, W, max_batch=2, dtype="fp32")
-    e16 = cfa.Engine(H, W, max_batch=2, dtype="bf16")
-    e32.forward_enqueue(x); e16.forward_enqueue(x)
-    h32, h16 = e32.heads(), e16.heads()
-    for k in ("hm", "wh", "lm", "reg"):
-        assert np.isfinite(h16[k]).all()
-        d = np.abs(h16[k] - h32[k])
-        assert d.mean() < 0.03 * (np.abs(h32[k]).mean() + 1e-6) + 2e-3, (k, float(d.mean()))
-        assert d.max() < 0.25 * max(1.0, float(np.abs(h32[k]).max())), (k, float(d.max()))
-    K = min(10, (H // 4) * (W // 4))
-    d16, d32 = e16.decode_topk(K), e32.decode_topk(K)
-    assert d16[0].shape == d32[0].shape and np.isfinite(d16[0]).all()
-    e32.close(); e16.close()
 
 
 # ----------------------------------------------------------------------------- N4: training-side pieces
