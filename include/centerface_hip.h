@@ -27,7 +27,7 @@ extern "C" {
 
 /* error codes */
 #define CF_OK             0
-#define CF_EINVAL        -1      /* bad argument (shape not multiple of 32, K too large, ...) */
+#define CF_EINVAL        -1      /* bad argument (shape not multiple of 32, K > h*w, ...) */
 #define CF_ENOMEM        -2
 #define CF_EHIP          -3      /* a HIP runtime call failed; see cf_last_error */
 #define CF_ESTATE        -4      /* call order violated (forward before load_weights, ...) */
@@ -114,7 +114,7 @@ int cf_get_heads(cf_ctx* ctx, float* hm, float* wh, float* lm, float* reg, float
  * same cells (may be NULL); inds [B,K] flat cell index y*w+x (may be NULL).  Equal scores are
  * ordered lower-index-first (torch.topk leaves it unspecified).  use_reg = 0 gives the +0.5
  * branch (centerface_ext.py:65-67).  out_on_device selects host or device destination buffers.
- * K <= 1024 and K <= h*w. */
+ * 1 <= K <= h*w, any map size (K > 1024 sorts through global memory: slower, same results). */
 int cf_decode_topk(cf_ctx* ctx, int K, int use_reg, float* dets, float* lms, int64_t* inds,
                    int out_on_device);
 
@@ -155,6 +155,23 @@ int cf_decode_threshold_sized(cf_ctx* ctx, int mode, float score_thresh, float n
 /* ---- fused convenience: forward + D3 decode in one enqueue (eval_widerface.py:76-90 shape) -- */
 int cf_detect_topk(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int K,
                    float* dets, float* lms, int64_t* inds, int out_on_device);
+
+/* ---- multi-GPU: one process (or thread) per GPU, batch sharded by rank, final boxes gathered over RCCL / xGMI -- */
+/* The only exchange of the data path (images are independent end to end): an all-gather of the fixed-size
+ * detection records.  The reference has no counterpart (train.py:11,17 import torch.distributed without using
+ * it).  librccl is loaded on first use.  Rendezvous is the caller's: rank 0 calls cf_comm_unique_id and ships the
+ * 128 bytes to the other ranks by any means (file, socket, MPI, torch.distributed store), then every rank calls
+ * cf_comm_create (collective: returns when all `world` ranks have joined). */
+#define CF_COMM_ID_BYTES 128
+typedef struct cf_comm cf_comm;
+int cf_comm_unique_id(void* id, int bytes);
+int cf_comm_create(cf_ctx* ctx, int rank, int world, const void* id, cf_comm** out);
+int cf_comm_destroy(cf_comm* comm);
+/* D3 decode of the last forward (as cf_decode_topk) followed by the all-gather: records [world * B, K, 16] =
+ * x1,y1,x2,y2,score,cls,lm0..lm9 per detection, rank-major = exactly the batch order of the unsharded run (every
+ * rank must pass the same B and K).  Runs on the decode stream underneath the next forward.  out_on_device = 1:
+ * `records` is a device buffer, the call is asynchronous (cf_synchronize before reading it); 0: host buffer, blocking. */
+int cf_gather_topk(cf_ctx* ctx, cf_comm* comm, int K, int use_reg, float* records, int out_on_device);
 
 /* ---- stream / timing plumbing -------------------------------------------------------------- */
 int cf_synchronize(cf_ctx* ctx);

@@ -1,16 +1,25 @@
 // Peak decode on the GPU.
 //
-// D3 (peak_topk_kernel) replaces ctdet_decode and its helpers (centerface_ext.py:11-82):
+// D3 (peak_collect_kernel + topk_select_kernel) replaces ctdet_decode and its helpers (centerface_ext.py:11-82):
 //   _nms   (:44-50)  3x3 max-pool equality mask            -> fused peak test, no pooled tensor
 //   _topk  (:11-27)  torch.topk over H*W, index -> (y, x)   -> exact radix select + bitonic sort
 //   _transpose_and_gather_feat (:28-42) full NCHW->NHWC permute + gather -> K 64-byte row reads
 //   box assembly (:60-82)
-// One workgroup (1024 threads, 16 waves) per image.  Scores are made totally ordered by the
-// composite 64-bit key (orderable(score) << 32) | ~index, so "equal scores: lower index first" is
-// part of the key and the selected set is exact and deterministic (torch leaves ties unspecified).
-// The K-th largest key is found by MSB-first radix select (LDS histograms, suffix scans with wave
-// shuffles); the K survivors are sorted descending by a bitonic network that exchanges through
-// __shfl_xor inside a wave and through LDS across waves.
+// Scores are made totally ordered by the composite 64-bit key (orderable(score) << 32) | ~index, so "equal
+// scores: lower index first" is part of the key and the selected set is exact and deterministic (torch leaves
+// ties unspecified).
+//
+// Two kernels.  After `heat * (hmax == heat)` every cell that is not a 3x3 peak scores exactly +0.0, and those are
+// ~8/9 of a map: they need no key at all -- among themselves they are ordered by index.  So
+//   1. peak_collect_kernel, grid (cells / 4096, B): the peak test (all 9 loads of 4 cells per thread in flight) and a
+//      wave-aggregated append of the composite keys of the cells whose kept score is NOT +0.0 to a per-image list.
+//      Many workgroups per image: a 4-image 1280x1280 batch fills 100 CUs instead of 4.
+//   2. topk_select_kernel, grid (B): MSB-first radix select of the K-th largest key over the LIST (typically 11 %
+//      of the map; staged in LDS when it fits), compaction, bitonic sort (wave shuffles / LDS; global memory for
+//      K > 1024), then -- only when the list holds fewer than K positive scores -- the lowest-index zero cells in
+//      index order, then the gather and box assembly.
+// HBM traffic: the heat plane once (4 B/cell) + 8 B per listed cell + K records, against 8 B/cell written and
+// re-read up to four times by the one-kernel version this replaces.  No limit on K (<= H*W) or on the map size.
 //
 // D1 (threshold decode + greedy NMS) replaces CenterFace.decode / CenterFace.nms
 // (centerface.py:73-151) with the reference's arithmetic (float64 intermediates rounded to fp32,
@@ -30,6 +39,73 @@ __device__ __forceinline__ uint32_t orderable(float f) {
 __device__ __forceinline__ float from_orderable(uint32_t k) {
     uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
     return __uint_as_float(u);
+}
+constexpr uint32_t kZeroOk = 0x80000000u;              // orderable(+0.0f)
+
+// heat * keep for cell (y, x) of one image plane: keep = 1.0 where the 3x3 maximum equals the cell
+// (max_pool2d pads with -inf = clamped in-range duplicates), "+ 0.0f" canonicalises -0 to +0
+__device__ __forceinline__ float kept_score(const float* hm, int hs, int h, int w, int i) {
+    const int y = i / w, x = i - y * w;
+    const float v = hm[(size_t)i * hs];
+    float mx = v;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = min(max(y + dy, 0), h - 1), xx = min(max(x + dx, 0), w - 1);
+            mx = fmaxf(mx, hm[((size_t)yy * w + xx) * hs]);
+        }
+    return (mx == v) ? v : (v * 0.0f + 0.0f);
+}
+
+constexpr int kCollectCells = 4096;                    // cells per workgroup of peak_collect_kernel
+
+__global__ __launch_bounds__(256) void peak_collect_kernel(TopkParams p) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int HW = p.h * p.w;
+    const float* hm = p.hm_plane ? p.hm_plane + (size_t)b * HW : p.heads + (size_t)b * HW * 16;
+    const int hs = p.hm_plane ? 1 : 16;
+    u64* keys = p.scratch + (size_t)b * HW;
+    const int base = blockIdx.x * kCollectCells;
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+        float v[4], mx[4];
+        int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + (g * 4 + u) * 256 + tid;
+            idx[u] = i;
+            const int ic = i < HW ? i : HW - 1;
+            const int y = ic / p.w, x = ic - y * p.w;
+            v[u] = hm[(size_t)ic * hs];
+            mx[u] = v[u];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = min(max(y + dy, 0), p.h - 1), xx = min(max(x + dx, 0), p.w - 1);
+                    mx[u] = fmaxf(mx[u], hm[((size_t)yy * p.w + xx) * hs]);
+                }
+        }
+        uint32_t ok[4]; bool hit[4]; unsigned long long bal[4]; uint32_t tot = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float kept = (mx[u] == v[u]) ? v[u] : (v[u] * 0.0f + 0.0f);
+            ok[u] = orderable(kept);
+            hit[u] = idx[u] < HW && ok[u] != kZeroOk;
+            bal[u] = __ballot(hit[u]);
+            tot += (uint32_t)__popcll(bal[u]);
+        }
+        if (tot == 0) continue;                           // wave-uniform
+        uint32_t off = 0;
+        if (lane == 0) off = (uint32_t)atomicAdd(&p.count[b], (int)tot);   // one atomic per wave and group
+        off = __shfl(off, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (hit[u]) keys[off + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull))] = ((u64)ok[u] << 32) | (u64)(0xffffffffu - (uint32_t)idx[u]);
+            off += (uint32_t)__popcll(bal[u]);
+        }
+    }
 }
 
 // suffix-inclusive scan over NBINS LDS counters by wave 0; finds digit d with
@@ -64,163 +140,259 @@ __device__ __forceinline__ void find_digit(const uint32_t* hist, uint32_t kth, u
     }
 }
 
-__global__ __launch_bounds__(1024) void peak_topk_kernel(TopkParams p) {
+constexpr int kStageCap = 4096;                        // list entries staged in LDS (32 KB)
+
+// BIG = false: K <= 1024, survivors live in registers / LDS.  BIG = true: any K, survivors, sort and the final
+// order live in p.big (global; one workgroup per image, so __syncthreads orders its accesses).
+template <bool BIG>
+__global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t res[3];
-    __shared__ uint32_t nsel;
+    __shared__ uint32_t nsel, npos_s, zfound;
+    __shared__ uint32_t wave_cnt[16];
     __shared__ u64 sel[1024];
+    __shared__ u64 staged[kStageCap];
 
     const int b = blockIdx.x;
     const int HW = p.h * p.w;
-    const int tid = threadIdx.x;
-    // dense heat-map plane when the head kernel provided one (coalesced), else channel 0 of the records
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K;
     const float* hm = p.hm_plane ? p.hm_plane + (size_t)b * HW : p.heads + (size_t)b * HW * 16;
     const int hs = p.hm_plane ? 1 : 16;
-    u64* keys = p.scratch + (size_t)b * HW;
-
-    // ---- pass 0: peak test (_nms), composite keys, and the histogram of the top 11 score bits
+    const int L = p.count[b];
+    const u64* list = p.scratch + (size_t)b * HW;
+    if (L <= kStageCap) {                               // workgroup-uniform
+        for (int i = tid; i < L; i += 1024) staged[i] = list[i];
+        list = staged;
+    }
+    // ---- pass 0: histogram of the top 11 score bits over the list; positives = bins >= 1024 (the list never holds +0)
     for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+    if (tid == 0) npos_s = 0;
     __syncthreads();
-    // four cells per thread and iteration: all 4 x 9 loads are in flight before the first compare
-    for (int i0 = tid; i0 < HW; i0 += 4096) {
-        float v[4], mx[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 1024;
-            const int ic = i < HW ? i : HW - 1;
-            const int y = ic / p.w, x = ic - y * p.w;
-            v[u] = hm[(size_t)ic * hs];
-            mx[u] = v[u];
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int yy = min(max(y + dy, 0), p.h - 1), xx = min(max(x + dx, 0), p.w - 1);   // clamped = in-range duplicate
-                    mx[u] = fmaxf(mx[u], hm[((size_t)yy * p.w + xx) * hs]);
-                }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 1024;
-            if (i >= HW) break;
-            // heat * keep  (keep = 1.0 where hmax == heat else 0.0); "+ 0.0f" canonicalises -0 to +0
-            const float kept = (mx[u] == v[u]) ? v[u] : (v[u] * 0.0f + 0.0f);
-            const uint32_t ok = orderable(kept);
-            keys[i] = ((u64)ok << 32) | (u64)(0xffffffffu - (uint32_t)i);
+    {
+        uint32_t mypos = 0;
+        for (int i = tid; i < L; i += 1024) {
+            const uint32_t ok = (uint32_t)(list[i] >> 32);
             atomicAdd(&hist[ok >> 21], 1u);
+            mypos += ok > kZeroOk ? 1u : 0u;
         }
+        for (int off = 32; off > 0; off >>= 1) mypos += __shfl_xor(mypos, off);
+        if (lane == 0 && mypos) atomicAdd(&npos_s, mypos);
     }
     __syncthreads();
+    const uint32_t Ppos = npos_s;
+    const uint32_t Z = (uint32_t)(HW - L);              // cells whose kept score is exactly +0: ordered by index
+    // how many list entries the result holds (M), how many zero cells (nz): positives, then zeros, then negatives
+    uint32_t M, nz;
+    if (Ppos >= (uint32_t)K) { M = K; nz = 0; }
+    else { nz = min((uint32_t)K - Ppos, Z); M = (uint32_t)K - nz; }
+    const uint32_t lead = min(Ppos, M);                 // list entries that precede the zero cells in the output
 
-    // ---- radix select of the K-th largest composite key, MSB first: 11+11+10 score bits, then
-    //      17 index bits (9+8) which only matter when scores tie at the threshold
-    u64 prefix = 0, mask = 0;
-    uint32_t kth = (uint32_t)p.K;
-    const int shifts[5] = {53, 42, 32, 8, 0};
-    const int widths[5] = {11, 11, 10, 9, 8};
-    // the low 32 bits hold ~index: its top 15 bits are all ones for index < 2^17, include them in
-    // the prefix up front so that the two index passes cover bits [16:8] and [7:0]
-    for (int pass = 0; pass < 5; ++pass) {
-        if (pass == 3) { prefix |= 0xfffe0000ull; mask |= 0xfffe0000ull; }
-        const int sh = shifts[pass], wd = widths[pass];
-        if (pass > 0) {                                  // pass 0's histogram was built with the keys
-            for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
-            __syncthreads();
-            for (int i0 = tid; i0 < HW; i0 += 4096) {
-                u64 k[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) k[u] = keys[min(i0 + u * 1024, HW - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + u * 1024 < HW && (k[u] & mask) == prefix) atomicAdd(&hist[(uint32_t)(k[u] >> sh) & ((1u << wd) - 1u)], 1u);
+    // ---- radix select of the M-th largest composite key of the list, MSB first: 11+11+10 score bits, then the
+    //      index bits (only when scores tie at the threshold)
+    u64 thresh = 0;                                     // M == L: everything
+    if (M > 0 && M < (uint32_t)L) {
+        u64 prefix = 0, mask = 0;
+        uint32_t kth = M;
+        int ibits = 1;
+        while ((1ll << ibits) < (long long)HW) ++ibits;
+        bool done = false;
+        for (int pass = 0; pass < 3 && !done; ++pass) {
+            const int sh = pass == 0 ? 53 : (pass == 1 ? 42 : 32), wd = pass == 2 ? 10 : 11;
+            if (pass > 0) {                                  // pass 0's histogram is already there
+                for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+                __syncthreads();
+                for (int i = tid; i < L; i += 1024) {
+                    const u64 k = list[i];
+                    if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> sh) & ((1u << wd) - 1u)], 1u);
+                }
+                __syncthreads();
             }
+            find_digit<2048>(hist, kth, res);
             __syncthreads();
+            prefix |= (u64)res[0] << sh;
+            mask |= (u64)((1u << wd) - 1u) << sh;
+            kth -= res[1];
+            const uint32_t in_bin = res[2];
+            __syncthreads();
+            // every key that shares the fixed bits is needed: nothing left to break
+            if (kth == in_bin) done = true;
         }
-        find_digit<2048>(hist, kth, res);
-        __syncthreads();
-        prefix |= (u64)res[0] << sh;
-        mask |= (u64)((1u << wd) - 1u) << sh;
-        kth -= res[1];
-        const uint32_t in_bin = res[2];
-        __syncthreads();
-        // all 32 score bits fixed and every key with that score is needed: no tie to break by index
-        if (pass == 2 && kth == in_bin) break;
+        if (!done) {
+            // ~index occupies the low 32 bits; its bits above `ibits` are all ones for every key
+            const u64 hi_ones = (ibits < 32) ? ((0xffffffffull >> ibits) << ibits) : 0ull;
+            prefix |= hi_ones; mask |= hi_ones;
+            for (int rem = ibits; rem > 0 && !done;) {
+                const int wd = rem < 11 ? rem : 11, sh = rem - wd;
+                for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+                __syncthreads();
+                for (int i = tid; i < L; i += 1024) {
+                    const u64 k = list[i];
+                    if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> sh) & ((1u << wd) - 1u)], 1u);
+                }
+                __syncthreads();
+                find_digit<2048>(hist, kth, res);
+                __syncthreads();
+                prefix |= (u64)res[0] << sh;
+                mask |= (u64)((1u << wd) - 1u) << sh;
+                kth -= res[1];
+                const uint32_t in_bin = res[2];
+                __syncthreads();
+                if (kth == in_bin) done = true;
+                rem = sh;
+            }
+        }
+        thresh = prefix;                                // keys >= thresh (masked bits only) are exactly the M survivors
     }
-    const u64 thresh = prefix;          // exact K-th largest composite key (keys are distinct)
 
-    // ---- compaction of the K survivors (order irrelevant: sorted next)
-    if (tid == 0) nsel = 0;
-    __syncthreads();
-    for (int i0 = tid; i0 < HW; i0 += 4096) {
-        u64 k[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) k[u] = keys[min(i0 + u * 1024, HW - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i0 + u * 1024 < HW && k[u] >= thresh) { uint32_t pos = atomicAdd(&nsel, 1u); if (pos < 1024) sel[pos] = k[u]; }
-    }
-    __syncthreads();
-    u64 mine = (tid < p.K) ? sel[tid] : 0ull;
-    __syncthreads();
-
-    // ---- bitonic sort, descending, over the next power of two >= K elements (one per thread; the padding
-    //      keys are 0 and sink to the end)
+    // ---- compaction of the M survivors (order irrelevant: sorted next)
     int sortn = 64;
-    while (sortn < p.K) sortn <<= 1;
-    for (int k2 = 2; k2 <= sortn; k2 <<= 1) {
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            u64 other;
-            if (j >= 64) {
-                sel[tid] = mine;
-                __syncthreads();
-                other = sel[tid ^ j];
-                __syncthreads();
-            } else {
-                uint32_t lo = __shfl_xor((uint32_t)mine, j), hi = __shfl_xor((uint32_t)(mine >> 32), j);
-                other = ((u64)hi << 32) | lo;
+    while (sortn < (int)M) sortn <<= 1;
+    u64* gbuf = BIG ? p.big + (size_t)b * p.big_stride : nullptr;      // [sortn] sort buffer, then [K] final order
+    if (tid == 0) nsel = 0;
+    if constexpr (BIG) for (int i = tid; i < sortn; i += 1024) gbuf[i] = 0ull;
+    __syncthreads();
+    if (M > 0) {
+        for (int i = tid; i < L; i += 1024) {
+            const u64 k = list[i];
+            if (k >= thresh) {
+                const uint32_t pos = atomicAdd(&nsel, 1u);
+                if constexpr (BIG) gbuf[pos] = k; else if (pos < 1024) sel[pos] = k;
             }
-            const bool up = (tid & k2) == 0;            // descending block
-            const bool lower = (tid & j) == 0;
-            const bool take_max = (up == lower);
-            mine = take_max ? (mine > other ? mine : other) : (mine < other ? mine : other);
         }
     }
+    __syncthreads();
+
+    u64 mine = 0ull;
+    if constexpr (!BIG) {
+        mine = (tid < (int)M) ? sel[tid] : 0ull;
+        __syncthreads();
+        // bitonic sort, descending, one key per thread over the next power of two >= M (padding keys 0 sink to the end)
+        for (int k2 = 2; k2 <= sortn; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                u64 other;
+                if (j >= 64) {
+                    sel[tid] = mine;
+                    __syncthreads();
+                    other = sel[tid ^ j];
+                    __syncthreads();
+                } else {
+                    uint32_t lo = __shfl_xor((uint32_t)mine, j), hi = __shfl_xor((uint32_t)(mine >> 32), j);
+                    other = ((u64)hi << 32) | lo;
+                }
+                const bool up = (tid & k2) == 0;            // descending block
+                const bool lower = (tid & j) == 0;
+                const bool take_max = (up == lower);
+                mine = take_max ? (mine > other ? mine : other) : (mine < other ? mine : other);
+            }
+        }
+        __syncthreads();
+        // final order: list entries before the zero cells, the zero cells, the rest of the list entries
+        if (tid < (int)M) sel[(uint32_t)tid < lead ? tid : tid + nz] = mine;
+    } else {
+        for (int k2 = 2; k2 <= sortn; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < sortn / 2; t += 1024) {
+                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;       // the pair (lo, lo ^ j)
+                    const u64 a = gbuf[lo], c = gbuf[hi];
+                    const bool desc = (lo & k2) == 0;
+                    if (desc ? (a < c) : (a > c)) { gbuf[lo] = c; gbuf[hi] = a; }
+                }
+                __syncthreads();
+            }
+        u64* fin = gbuf + sortn;
+        for (int t = tid; t < (int)M; t += 1024) fin[(uint32_t)t < lead ? t : t + nz] = gbuf[t];
+    }
+
+    // ---- the zero cells (kept score exactly +0.0), lowest index first: ordered scan in rounds of 1024 cells
+    if (nz > 0) {
+        if (tid == 0) zfound = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < HW; i0 += 1024) {
+            const uint32_t have = zfound;                   // uniform (read after the barrier below / above)
+            if (have >= nz) break;
+            const int i = i0 + tid;
+            const bool hit = i < HW && orderable(kept_score(hm, hs, p.h, p.w, i)) == kZeroOk;
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t off = have, total = 0;
+            for (int w2 = 0; w2 < 16; ++w2) { if (w2 < wave) off += wave_cnt[w2]; total += wave_cnt[w2]; }
+            if (hit) {
+                const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < nz) {
+                    const u64 k = ((u64)kZeroOk << 32) | (u64)(0xffffffffu - (uint32_t)i);
+                    if constexpr (BIG) gbuf[sortn + lead + pos] = k; else sel[lead + pos] = k;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) zfound = have + total;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (tid == 0) p.count[b] = 0;                       // leave the list empty for the next launch
 
     // ---- gather + box assembly (centerface_ext.py:60-82)
-    if (tid < p.K) {
-        const uint32_t idx = 0xffffffffu - (uint32_t)mine;
-        const float score = from_orderable((uint32_t)(mine >> 32));
+    for (int t = tid; t < K; t += 1024) {
+        const u64 key = BIG ? gbuf[sortn + t] : sel[t];
+        const uint32_t idx = 0xffffffffu - (uint32_t)key;
+        const float score = from_orderable((uint32_t)(key >> 32));
         const float* rec = p.heads + ((size_t)b * HW + idx) * 16;
         float xs = (float)(int)(idx % (uint32_t)p.w);
         float ys = (float)(int)(idx / (uint32_t)p.w);
         if (p.use_reg) { xs = xs + rec[13]; ys = ys + rec[14]; }
         else { xs = xs + 0.5f; ys = ys + 0.5f; }
         const float hw0 = rec[1] / 2.0f, hw1 = rec[2] / 2.0f;
-        float* d = p.dets + ((size_t)b * p.K + tid) * 6;
         float bx1 = xs - hw0, by1 = ys - hw1, bx2 = xs + hw0, by2 = ys + hw1;
         if (p.trans) {
             // ctdet_post_process (utils/post_process.py:83-90): transform_preds on both corners with the
             // inverse affine of get_affine_transform (utils/image.py:19-66); float64 like np.dot(t, pt)
-            const double* t = p.trans + (size_t)b * 6;
-            const double ax1 = t[0] * (double)bx1 + t[1] * (double)by1 + t[2], ay1 = t[3] * (double)bx1 + t[4] * (double)by1 + t[5];
-            const double ax2 = t[0] * (double)bx2 + t[1] * (double)by2 + t[2], ay2 = t[3] * (double)bx2 + t[4] * (double)by2 + t[5];
+            const double* tr = p.trans + (size_t)b * 6;
+            const double ax1 = tr[0] * (double)bx1 + tr[1] * (double)by1 + tr[2], ay1 = tr[3] * (double)bx1 + tr[4] * (double)by1 + tr[5];
+            const double ax2 = tr[0] * (double)bx2 + tr[1] * (double)by2 + tr[2], ay2 = tr[3] * (double)bx2 + tr[4] * (double)by2 + tr[5];
             bx1 = (float)ax1; by1 = (float)ay1; bx2 = (float)ax2; by2 = (float)ay2;
         }
-        d[0] = bx1; d[1] = by1; d[2] = bx2; d[3] = by2; d[4] = score; d[5] = 0.0f;
+        const size_t o = (size_t)b * K + t;
+        if (p.dets) {
+            float* d = p.dets + o * 6;
+            d[0] = bx1; d[1] = by1; d[2] = bx2; d[3] = by2; d[4] = score; d[5] = 0.0f;
+        }
         if (p.lms) {
-            float* l = p.lms + ((size_t)b * p.K + tid) * 10;
+            float* l = p.lms + o * 10;
 #pragma unroll
             for (int j = 0; j < 10; ++j) l[j] = rec[3 + j];
         }
-        if (p.inds) p.inds[(size_t)b * p.K + tid] = (long long)idx;
+        if (p.inds) p.inds[o] = (long long)idx;
+        if (p.rec16) {                                     // the gather record: box, score, class, landmarks
+            float* r = p.rec16 + o * 16;
+            r[0] = bx1; r[1] = by1; r[2] = bx2; r[3] = by2; r[4] = score; r[5] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) r[6 + j] = rec[3 + j];
+        }
     }
+}
+
+size_t topk_big_stride(int K) {                           // u64 per image of TopkParams::big for K > 1024
+    size_t n = 64;
+    while (n < (size_t)K) n <<= 1;
+    return n + (size_t)K;
 }
 
 hipError_t launch_peak_topk(hipStream_t s, const TopkParams& p) {
     if (p.B <= 0) return hipSuccess;
-    if (p.K < 1 || p.K > 1024 || p.K > p.h * p.w || p.h * p.w > (1 << 17)) return hipErrorInvalidValue;
-    set_kernel_tag("cf::peak_topk_kernel(cf::TopkParams)");
-    hipLaunchKernelGGL(peak_topk_kernel, dim3(p.B), dim3(1024), 0, s, p);
+    const long long HW = (long long)p.h * p.w;
+    if (p.K < 1 || p.K > HW || HW >= (1ll << 31) || !p.scratch || !p.count) return hipErrorInvalidValue;
+    if (p.K > 1024 && (!p.big || p.big_stride < topk_big_stride(p.K))) return hipErrorInvalidValue;
+    set_kernel_tag("cf::peak_collect_kernel(cf::TopkParams)");
+    hipLaunchKernelGGL(peak_collect_kernel, dim3((unsigned)((HW + kCollectCells - 1) / kCollectCells), p.B), dim3(256), 0, s, p);
+    if (p.K <= 1024) {
+        set_kernel_tag("void cf::topk_select_kernel<false>(cf::TopkParams)");
+        hipLaunchKernelGGL(topk_select_kernel<false>, dim3(p.B), dim3(1024), 0, s, p);
+    } else {
+        set_kernel_tag("void cf::topk_select_kernel<true>(cf::TopkParams)");
+        hipLaunchKernelGGL(topk_select_kernel<true>, dim3(p.B), dim3(1024), 0, s, p);
+    }
     return hipGetLastError();
 }
 

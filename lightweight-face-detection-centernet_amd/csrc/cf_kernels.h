@@ -173,17 +173,23 @@ struct UpHeadParams {
 hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p);
 
 // ------------------------------------------------------------------ decode
-// D3: 3x3 peak test + top-K (radix select + bitonic sort) + gather, one workgroup per image.
+// D3: 3x3 peak test + top-K (radix select + bitonic sort) + gather: a multi-workgroup collect kernel + one select
+// workgroup per image (cf_decode.hip).
 struct TopkParams {
     const float* heads;   // [B][h*w][16]
     const float* hm_plane; // optional dense [B][h*w] heat map (else channel 0 of the records is used)
-    unsigned long long* scratch;   // [B][h*w] composite keys
+    unsigned long long* scratch;   // [B][h*w] composite keys of the cells whose kept score is not +0 (the peak list)
+    int* count;           // [B] list lengths: zero before the launch, zero again after it
+    unsigned long long* big;       // K > 1024 only: [B][big_stride] sort buffer + final order (topk_big_stride(K))
+    size_t big_stride;
     int B, h, w, K, use_reg;
-    float* dets;          // [B][K][6]
+    float* dets;          // [B][K][6] or nullptr
     float* lms;           // [B][K][10] or nullptr
     long long* inds;      // [B][K] or nullptr
+    float* rec16;         // [B][K][16] or nullptr: x1,y1,x2,y2,score,cls,lm0..9 -- the record the multi-GPU gather ships
     const double* trans;  // optional [B][6]: row-major 2x3 affine (heat-map -> source image) applied to both box corners
 };
+size_t topk_big_stride(int K);
 hipError_t launch_peak_topk(hipStream_t s, const TopkParams& p);
 
 // D1: threshold compaction (row-major) + box/landmark arithmetic + greedy NMS

@@ -305,12 +305,14 @@ int cf_op_heads(int device, int dtype, const float* x, const float* w0, const fl
 
 int cf_op_ctdet_decode(int device, const float* heat, const float* wh, const float* reg, const float* lm,
                        int B, int h, int w, int K, float* dets, float* lms, int64_t* inds) {
-    if (!heat || !wh || !dets || B < 1 || K < 1 || K > 1024 || K > h * w || h * w > (1 << 17)) return CF_EINVAL;
+    if (!heat || !wh || !dets || B < 1 || K < 1 || (long long)K > (long long)h * w) return CF_EINVAL;
     Scope sc(device);
     std::vector<float> rec = make_records(heat, wh, reg, lm, B, h, w);
     TopkParams p{};
     p.heads = sc.upv(rec);
     p.scratch = (unsigned long long*)sc.alloc((size_t)B * h * w * 8);
+    p.count = (int*)sc.alloc((size_t)B * 4);                                  // zero-initialised by Scope::alloc
+    if (K > 1024) { p.big_stride = topk_big_stride(K); p.big = (unsigned long long*)sc.alloc((size_t)B * p.big_stride * 8); }
     p.B = B; p.h = h; p.w = w; p.K = K; p.use_reg = reg ? 1 : 0;
     p.dets = (float*)sc.alloc((size_t)B * K * 6 * 4);
     p.lms = (lms && lm) ? (float*)sc.alloc((size_t)B * K * 10 * 4) : nullptr;

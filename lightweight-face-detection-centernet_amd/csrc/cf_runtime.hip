@@ -9,6 +9,8 @@
 // reused HBM buffers (ping/pong + expanded + depthwise) so the working set of a batch stays small
 // and L2 / Infinity-Cache resident between producer and consumer where it fits.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -81,7 +83,9 @@ struct cf_ctx {
     std::string err;
     hipEvent_t events[64] = {};
     // decode workspaces (lazy)
-    unsigned long long* keys = nullptr; float* hm_plane = nullptr; double* d_trans = nullptr; uint8_t* src_stage = nullptr; size_t src_stage_bytes = 0;
+    unsigned long long* keys = nullptr; int* key_count = nullptr; unsigned long long* big = nullptr; size_t big_stride = 0; float* d_rec = nullptr;
+    hipEvent_t ev_main_dec = nullptr; bool main_dec_pending = false;
+    float* hm_plane = nullptr; double* d_trans = nullptr; uint8_t* src_stage = nullptr; size_t src_stage_bytes = 0;
     float* d_dets = nullptr; float* d_lms = nullptr; long long* d_inds = nullptr; int decK = 0;
     float* t_cand = nullptr; int* t_count = nullptr; int* t_order = nullptr; unsigned long long* t_mask = nullptr;
     float* t_dets = nullptr; float* t_lms = nullptr; int* t_counts = nullptr; int* t_overflow = nullptr;
@@ -326,7 +330,6 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
         g_create_error = "cf_create: H and W must be positive multiples of 32, max_batch >= 1, dtype CF_F32|CF_BF16";
         return CF_EINVAL;
     }
-    if ((long long)(H / 4) * (W / 4) > (1 << 17)) { g_create_error = "cf_create: heat map larger than 2^17 cells"; return CF_EINVAL; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return CF_EHIP; }
     cf_ctx* c = new cf_ctx();
@@ -345,6 +348,7 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
         if ((e = hipEventCreateWithFlags(&c->ev_slot_free[i], hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
     }
     if ((e = hipEventCreateWithFlags(&c->ev_dec, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_main_dec, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
     for (auto& ev : c->events) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
     build_plan(c);
     // input staging: the larger of u8 HWC and f32 NCHW
@@ -376,9 +380,10 @@ int cf_destroy(cf_ctx* c) {
     if (c->stream_in) { hipStreamSynchronize(c->stream_in); hipStreamDestroy(c->stream_in); }
     for (int i = 0; i < 2; ++i) { if (c->ev_copy[i]) hipEventDestroy(c->ev_copy[i]); if (c->ev_slot_free[i]) hipEventDestroy(c->ev_slot_free[i]); }
     if (c->ev_dec) hipEventDestroy(c->ev_dec);
+    if (c->ev_main_dec) hipEventDestroy(c->ev_main_dec);
     for (auto& b : c->bufs) if (b.p) hipFree(b.p);
     for (void* p : c->owned) hipFree(p);
-    for (void* p : {(void*)c->src_stage, (void*)c->d_trans, (void*)c->hm_plane, (void*)c->keys, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
+    for (void* p : {(void*)c->src_stage, (void*)c->d_trans, (void*)c->hm_plane, (void*)c->keys, (void*)c->key_count, (void*)c->big, (void*)c->d_rec, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
                     (void*)c->t_order, (void*)c->t_mask, (void*)c->t_dets, (void*)c->t_lms, (void*)c->t_counts, (void*)c->t_overflow})
         if (p) hipFree(p);
     for (auto& ev : c->events) if (ev) hipEventDestroy(ev);
@@ -678,25 +683,47 @@ void inverse_affine(float cx, float cy, float sw, int out_w, int out_h, double t
 int ensure_topk_ws(cf_ctx* c, int K) {
     const size_t HW = (size_t)(c->H / 4) * (c->W / 4);
     if (!c->keys) HIPCHK(c, hipMalloc((void**)&c->keys, HW * c->max_batch * sizeof(unsigned long long)));
+    if (!c->key_count) {
+        HIPCHK(c, hipMalloc((void**)&c->key_count, (size_t)c->max_batch * sizeof(int)));
+        HIPCHK(c, hipMemset(c->key_count, 0, (size_t)c->max_batch * sizeof(int)));       // the select kernel leaves it zero
+    }
     if (c->decK < K) {
-        for (void* p : {(void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds}) if (p) hipFree(p);
-        c->d_dets = nullptr; c->d_lms = nullptr; c->d_inds = nullptr;
+        HIPCHK(c, hipStreamSynchronize(c->stream));           // a decode in flight may still write the old buffers
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        for (void* p : {(void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->d_rec, (void*)c->big}) if (p) hipFree(p);
+        c->d_dets = nullptr; c->d_lms = nullptr; c->d_inds = nullptr; c->d_rec = nullptr; c->big = nullptr; c->big_stride = 0;
         HIPCHK(c, hipMalloc((void**)&c->d_dets, (size_t)c->max_batch * K * 6 * sizeof(float)));
         HIPCHK(c, hipMalloc((void**)&c->d_lms, (size_t)c->max_batch * K * 10 * sizeof(float)));
         HIPCHK(c, hipMalloc((void**)&c->d_inds, (size_t)c->max_batch * K * sizeof(long long)));
+        HIPCHK(c, hipMalloc((void**)&c->d_rec, (size_t)c->max_batch * K * 16 * sizeof(float)));
+        if (K > 1024) {
+            c->big_stride = topk_big_stride(K);
+            HIPCHK(c, hipMalloc((void**)&c->big, (size_t)c->max_batch * c->big_stride * sizeof(unsigned long long)));
+        }
         c->decK = K;
     }
     return CF_OK;
 }
 
+// One scratch list serves both streams: a decode on the main stream waits for an overlapped decode still running on
+// the decode stream and vice versa (events, no host sync).
 int enqueue_topk(cf_ctx* c, int B, int K, int use_reg, float* dets, float* lms, long long* inds, const double* trans = nullptr,
-                 hipStream_t on = nullptr) {
+                 hipStream_t on = nullptr, float* rec16 = nullptr) {
     TopkParams p{};
     p.trans = trans;
-    p.heads = (const float*)c->bufs[c->buf_heads].p; p.hm_plane = c->hm_plane; p.scratch = c->keys;
+    p.heads = (const float*)c->bufs[c->buf_heads].p; p.hm_plane = c->hm_plane; p.scratch = c->keys; p.count = c->key_count;
+    p.big = c->big; p.big_stride = c->big_stride;
     p.B = B; p.h = c->H / 4; p.w = c->W / 4; p.K = K; p.use_reg = use_reg;
-    p.dets = dets; p.lms = lms; p.inds = inds;
-    HIPCHK(c, launch_peak_topk(on ? on : c->stream, p));
+    p.dets = dets; p.lms = lms; p.inds = inds; p.rec16 = rec16;
+    const bool on_main = (on == nullptr || on == c->stream);
+    if (on_main) {
+        if (c->dec_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dec, 0));
+    } else if (c->main_dec_pending) {
+        HIPCHK(c, hipStreamWaitEvent(on, c->ev_main_dec, 0));
+        c->main_dec_pending = false;
+    }
+    HIPCHK(c, launch_peak_topk(on_main ? c->stream : on, p));
+    if (on_main) { HIPCHK(c, hipEventRecord(c->ev_main_dec, c->stream)); c->main_dec_pending = true; }
     return CF_OK;
 }
 
@@ -835,7 +862,7 @@ int cf_decode_topk(cf_ctx* c, int K, int use_reg, float* dets, float* lms, int64
     if (!c || !dets) return CF_EINVAL;
     if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_decode_topk before cf_forward");
     const int B = c->last_B, HW = (c->H / 4) * (c->W / 4);
-    if (K < 1 || K > 1024 || K > HW) return c->fail(CF_EINVAL, "K=%d must be in [1, min(1024, %d)]", K, HW);
+    if (K < 1 || K > HW) return c->fail(CF_EINVAL, "K=%d must be in [1, %d]", K, HW);
     HIPCHK(c, hipSetDevice(c->device));
     int r = ensure_topk_ws(c, K); if (r) return r;
     if (out_on_device) {
@@ -862,7 +889,7 @@ int cf_decode_topk_post(cf_ctx* c, int K, int use_reg, const float* centers, con
     if (!c || !dets || !centers || !scales) return CF_EINVAL;
     if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_decode_topk_post before cf_forward");
     const int B = c->last_B, HW = (c->H / 4) * (c->W / 4);
-    if (K < 1 || K > 1024 || K > HW) return c->fail(CF_EINVAL, "K=%d must be in [1, min(1024, %d)]", K, HW);
+    if (K < 1 || K > HW) return c->fail(CF_EINVAL, "K=%d must be in [1, %d]", K, HW);
     HIPCHK(c, hipSetDevice(c->device));
     int r = ensure_topk_ws(c, K); if (r) return r;
     if (!c->d_trans) HIPCHK(c, hipMalloc((void**)&c->d_trans, (size_t)c->max_batch * 6 * sizeof(double)));
@@ -1005,7 +1032,7 @@ int cf_profile_forward(cf_ctx* c, const void* in, int in_format, int in_on_devic
     c->last_B = B;
     if (K > 0) {
         r = enqueue_topk(c, B, K, 1, c->d_dets, c->d_lms, c->d_inds); if (r) return r;
-        tags.push_back(last_kernel_tag());
+        tags.push_back("cf::peak_collect_kernel(cf::TopkParams) + cf::topk_select_kernel");
         HIPCHK(c, hipEventRecord(ev[++i], c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1162,6 +1189,124 @@ int cf_memcpy_d2h(cf_ctx* c, void* dst, const void* src, uint64_t bytes) {
     if (!c) return CF_EINVAL;
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CF_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- multi-GPU: gather of the final boxes over RCCL
+// One process per GPU, images sharded across ranks, nothing exchanged on the data path except the fixed-size
+// detection records [B, K, 16] after the decode (the reference has no counterpart: its
+// torch.distributed imports at train.py:11,17 are unused).  RCCL is loaded with dlopen on first use, so a
+// process that never creates a communicator carries no dependency on librccl.
+struct cf_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    float* recv = nullptr; size_t recv_elems = 0;       // staging for host destinations
+};
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+RcclApi* rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return &api;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) { api.err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found"); return &api; }
+    auto sym = [&](const char* n) { void* p = dlsym(api.handle, n); if (!p && api.err.empty()) api.err = std::string("librccl lacks ") + n; return p; };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    return &api;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cf_comm_unique_id(void* id, int bytes) {
+    if (!id || bytes < (int)sizeof(ncclUniqueId)) { g_create_error = "cf_comm_unique_id: need a 128-byte buffer"; return CF_EINVAL; }
+    RcclApi* r = rccl();
+    if (!r->err.empty()) { g_create_error = r->err; return CF_EHIP; }
+    ncclUniqueId u;
+    ncclResult_t e = r->GetUniqueId(&u);
+    if (e != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + r->GetErrorString(e); return CF_EHIP; }
+    memcpy(id, &u, sizeof u);
+    return CF_OK;
+}
+
+int cf_comm_create(cf_ctx* c, int rank, int world, const void* id, cf_comm** out) {
+    if (!c || !id || !out || world < 1 || rank < 0 || rank >= world) return CF_EINVAL;
+    *out = nullptr;
+    RcclApi* r = rccl();
+    if (!r->err.empty()) return c->fail(CF_EHIP, "%s", r->err.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    cf_comm* m = new cf_comm();
+    m->rank = rank; m->world = world; m->device = c->device;
+    ncclResult_t e = r->CommInitRank(&m->comm, world, u, rank);
+    if (e != ncclSuccess) { delete m; return c->fail(CF_EHIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, r->GetErrorString(e)); }
+    *out = m;
+    return CF_OK;
+}
+
+int cf_comm_destroy(cf_comm* m) {
+    if (!m) return CF_OK;
+    hipSetDevice(m->device);
+    if (m->recv) hipFree(m->recv);
+    if (m->comm) rccl()->CommDestroy(m->comm);
+    delete m;
+    return CF_OK;
+}
+
+int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, int out_on_device) {
+    if (!c || !m || !records) return CF_EINVAL;
+    if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_gather_topk before cf_forward");
+    if (m->device != c->device) return c->fail(CF_EINVAL, "communicator was created for device %d, context runs on %d", m->device, c->device);
+    const int B = c->last_B, HW = (c->H / 4) * (c->W / 4);
+    if (K < 1 || K > HW) return c->fail(CF_EINVAL, "K=%d must be in [1, %d]", K, HW);
+    HIPCHK(c, hipSetDevice(c->device));
+    int r = ensure_topk_ws(c, K); if (r) return r;
+    const size_t n = (size_t)B * K * 16;
+    float* dst = records;
+    if (!out_on_device) {
+        if (m->recv_elems < n * m->world) {
+            if (m->recv) HIPCHK(c, hipFree(m->recv));
+            m->recv = nullptr; m->recv_elems = 0;
+            HIPCHK(c, hipMalloc((void**)&m->recv, n * m->world * sizeof(float)));
+            m->recv_elems = n * m->world;
+        }
+        dst = m->recv;
+    }
+    // decode stream: [wait forward] decode -> records -> [event: heads / scratch free again] -> all-gather (-> D2H)
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
+    r = enqueue_topk(c, B, K, use_reg, nullptr, nullptr, nullptr, nullptr, c->stream2, c->d_rec);
+    if (r) return r;
+    HIPCHK(c, hipEventRecord(c->ev_dec, c->stream2));
+    c->dec_pending = true;
+    ncclResult_t e = rccl()->AllGather(c->d_rec, dst, n, ncclFloat, m->comm, c->stream2);
+    if (e != ncclSuccess) return c->fail(CF_EHIP, "ncclAllGather: %s", rccl()->GetErrorString(e));
+    if (!out_on_device) {
+        HIPCHK(c, hipMemcpyAsync(records, dst, n * m->world * sizeof(float), hipMemcpyDeviceToHost, c->stream2));
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+    }
     return CF_OK;
 }
 

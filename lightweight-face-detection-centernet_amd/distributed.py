@@ -2,11 +2,22 @@
 
 Images are independent end to end (eval-mode BN, per-image decode -- SURVEY.md section 8e), so the
 only exchange is the gather of the fixed-size detection records after decode.  The reference has no
-counterpart (its torch.distributed imports at train.py:11,17 are unused).  The collective goes
-through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
-tests); payloads are a few hundred KB per rank, so it is latency- not bandwidth-bound.
+counterpart (its torch.distributed imports at train.py:11,17 are unused).  Two equivalent gathers:
+
+* ``Comm`` / ``Comm.gather_topk``: the C ABI's ``cf_gather_topk`` -- decode + ``ncclAllGather`` (RCCL over xGMI)
+  enqueued on the context's decode stream, no Python or torch on the data path; what a C / cgo / JNI host uses too.
+  The 128-byte RCCL id is shipped by the caller (``unique_id`` / ``broadcast_unique_id`` over torch.distributed's
+  store, or any other channel).
+* ``gather_records``: ``torch.distributed.all_gather_into_tensor`` (backend "nccl" = RCCL on the GPU box, "gloo"
+  in the CPU tests) on records packed by ``pack_records``.
+
+Payloads are a few hundred KB per rank, so the gather is latency- not bandwidth-bound.
 """
+import ctypes as C
+
 import numpy as np
+
+from . import _lib
 
 
 def shard_range(n_items, rank, world):
@@ -42,3 +53,56 @@ def gather_records(local, group=None):
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     return out
+
+
+COMM_ID_BYTES = 128
+
+
+def unique_id():
+    """A fresh RCCL unique id (bytes, 128) -- call on ONE rank and ship it to the others."""
+    buf = (C.c_char * COMM_ID_BYTES)()
+    _lib.check(_lib.lib().cf_comm_unique_id(buf, COMM_ID_BYTES))
+    return bytes(buf.raw)
+
+
+def broadcast_unique_id(src=0, group=None):
+    """Rank ``src`` creates the id, every rank of the (initialised) torch.distributed group receives it."""
+    import torch.distributed as dist
+    obj = [unique_id() if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(obj, src=src, group=group)
+    return obj[0]
+
+
+class Comm(object):
+    """RCCL communicator bound to one Engine (one GPU): ``cf_comm_create`` / ``cf_gather_topk``."""
+
+    def __init__(self, engine, rank, world, uid):
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError("RCCL unique id must be %d bytes" % COMM_ID_BYTES)
+        self.engine, self.rank, self.world = engine, int(rank), int(world)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().cf_comm_create(engine._h, self.rank, self.world, C.c_char_p(uid), C.byref(h)), engine._h)
+        self._h = h
+
+    def gather_topk(self, K=100, use_reg=True):
+        """Decode the engine's last forward and all-gather: float32 [world * B, K, 16] (host, blocking)."""
+        B = self.engine.last_B
+        out = np.empty((self.world * B, int(K), REC), np.float32)
+        _lib.check(_lib.lib().cf_gather_topk(self.engine._h, self._h, int(K), 1 if use_reg else 0, _lib.ptr(out), 0), self.engine._h)
+        return out
+
+    def gather_topk_device(self, K, records_ptr, use_reg=True):
+        """Same into a caller-owned DEVICE buffer [world * B, K, 16] (asynchronous, decode stream)."""
+        _lib.check(_lib.lib().cf_gather_topk(self.engine._h, self._h, int(K), 1 if use_reg else 0, C.c_void_p(int(records_ptr)), 1),
+                   self.engine._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cf_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

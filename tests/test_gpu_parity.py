@@ -347,6 +347,53 @@ def test_ctdet_decode_large_crowd_map():
     assert (np.diff(d[..., 4], axis=1) <= 0).all()
 
 
+@pytest.mark.parametrize("case", ["k_equals_hw", "constant_map", "negative_scores", "zeros_fill", "k2000_big_path",
+                                  "map_over_2p17_cells", "map_over_2p17_k3000", "sparse_positive"])
+def test_ctdet_decode_no_limits_and_zero_fill(case):
+    """The collect + select decode beyond the one-kernel version's limits (K <= 1024, h*w <= 2^17) and through its
+    rare branches, bit-exact against the oracle's ctdet_decode (centerface_ext.py:11-82): K = h*w, a constant map
+    (every cell is a peak: the list is the whole map), negative scores (they rank BELOW the +0 of suppressed cells),
+    fewer positive peaks than K (the lowest-index suppressed cells fill in, in index order), K > 1024 (global-memory
+    sort), maps of more than 2^17 cells."""
+    rng = np.random.default_rng(sum(ord(c) for c in case))
+    B, h, w, K = 2, 24, 40, 100
+    heat = rng.uniform(1e-4, 0.9999, (B, 1, h, w)).astype(np.float32)
+    if case == "k_equals_hw":
+        K = h * w
+    elif case == "constant_map":
+        heat[:] = 0.25; h, w = 80, 96; heat = np.full((B, 1, h, w), 0.25, np.float32); K = 300
+    elif case == "negative_scores":
+        heat = rng.standard_normal((B, 1, h, w)).astype(np.float32); K = 700
+    elif case == "zeros_fill":
+        heat = np.zeros((B, 1, h, w), np.float32)
+        for b in range(B):
+            for _ in range(30):
+                heat[b, 0, rng.integers(h), rng.integers(w)] = rng.uniform(0.3, 0.9)
+        K = 200
+    elif case == "k2000_big_path":
+        h, w, K = 96, 96, 2000
+        heat = rng.uniform(1e-4, 0.9999, (B, 1, h, w)).astype(np.float32)
+    elif case == "map_over_2p17_cells":
+        B, h, w, K = 1, 400, 400, 100
+        heat = rng.uniform(1e-4, 0.9999, (B, 1, h, w)).astype(np.float32)
+    elif case == "map_over_2p17_k3000":
+        B, h, w, K = 1, 384, 512, 3000
+        heat = rng.uniform(1e-4, 0.9999, (B, 1, h, w)).astype(np.float32)
+    elif case == "sparse_positive":
+        heat = (rng.uniform(0, 1, (B, 1, h, w)) > 0.97).astype(np.float32) * rng.uniform(0.2, 0.9, (B, 1, h, w)).astype(np.float32)
+        heat -= 0.05 * (rng.uniform(0, 1, (B, 1, h, w)) > 0.99)                      # a few negative cells as well
+        heat = heat.astype(np.float32); K = 960
+    wh = rng.uniform(1, 20, (B, 2, h, w)).astype(np.float32)
+    reg = rng.uniform(0, 1, (B, 2, h, w)).astype(np.float32)
+    lm = rng.standard_normal((B, 10, h, w)).astype(np.float32)
+    dets, lms, inds = ops.ctdet_decode(heat, wh, reg, K, lm)
+    rd, rl, ri = O.ctdet_decode(heat, wh, reg, K, lm)
+    assert np.array_equal(inds, ri), case
+    assert np.array_equal(dets, rd) and np.array_equal(lms, rl), case
+    with pytest.raises(ValueError):
+        ops.ctdet_decode(heat, wh, reg, h * w + 1, lm)
+
+
 def test_ctdet_post_process_vs_oracle():
     """utils/post_process.py:83-100 on the GPU: standalone on explicit dets and fused into the top-K
     decode epilogue, against the oracle restatement (float64 matrices agree to rounding)."""

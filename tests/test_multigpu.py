@@ -1,0 +1,96 @@
+"""The N > 1 path before the driver runs it on 8 GPUs: the exact `step()` of bench.py on one GPU (C-ABI RCCL
+gather at world 1 and the torch.distributed variant), and a world-size-2 run (two processes, both on GPU 0, gloo
+rendezvous, each with its own Engine on its shard) whose gathered result must equal the unsharded result BITWISE
+(SURVEY.md section 8e).  RCCL itself refuses two ranks on one device, so the 2-rank run gathers through gloo; the
+RCCL collective is exercised at world 1 (communicator creation, decode-stream all-gather, record layout)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import centerface_amd as cfa
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _records(eng, K):
+    d, l, _ = eng.decode_topk(K)
+    return cfa.distributed.pack_records(d, l)
+
+
+@pytest.mark.parametrize("gather", ["cf", "torch"])
+def test_bench_multi_gpu_step_on_one_gpu(gather):
+    import torch
+    import bench
+    B, S, K = 8, 160, 50
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    imgs = rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    d_in = torch.from_numpy(imgs).to(dev)
+    out = {"dets": torch.empty((B, K, 6), dtype=torch.float32, device=dev), "lms": torch.empty((B, K, 10), dtype=torch.float32, device=dev),
+           "inds": torch.empty((B, K), dtype=torch.int64, device=dev), "all": torch.zeros((B, K, 16), dtype=torch.float32, device=dev)}
+    eng = cfa.Engine(S, S, max_batch=B, dtype="bf16")
+    comm = cfa.distributed.Comm(eng, 0, 1, cfa.distributed.unique_id()) if gather == "cf" else None
+    step = bench.make_step(cfa, eng, d_in.data_ptr(), B, K, out, gather, comm)
+    for _ in range(4):                                   # eager, capture, replay, replay: gathers overlap the next forward
+        got = step()
+    eng.synchronize(); torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    eng.forward_enqueue(imgs)
+    assert np.array_equal(got, _records(eng, K))
+    if comm is not None:                                 # host-destination variant of the same entry point
+        assert np.array_equal(comm.gather_topk(K), got)
+        comm.close()
+    eng.close()
+
+
+WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(repo)r)
+import centerface_amd as cfa
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B, S, K = 6, 128, 40
+imgs = np.random.default_rng(3).integers(0, 256, (B, S, S, 3), dtype=np.uint8)      # the same full batch on every rank
+lo, hi = cfa.distributed.shard_range(B, rank, world)
+eng = cfa.Engine(S, S, max_batch=B, dtype=%(dtype)r, device=0)
+eng.forward_enqueue(imgs[lo:hi])
+d, l, _ = eng.decode_topk(K)
+rec = torch.from_numpy(cfa.distributed.pack_records(d, l))
+allrec = cfa.distributed.gather_records(rec).numpy()
+assert allrec.shape == (B, K, 16), allrec.shape
+eng.forward_enqueue(imgs)                                                           # unsharded run on this rank
+d, l, _ = eng.decode_topk(K)
+full = cfa.distributed.pack_records(d, l)
+assert np.array_equal(allrec, full), "sharded != unsharded"
+eng.close()
+dist.barrier()
+dist.destroy_process_group()
+print("rank %%d ok" %% rank)
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_world2_sharded_equals_unsharded_bitwise(tmp_path, dtype):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"repo": REPO, "dtype": dtype})
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert "rank %d ok" % r in o
