@@ -97,8 +97,9 @@ int cf_ctdet_loss(cf_ctx* ctx, const float* gt_hm, const uint8_t* reg_mask, cons
  * enqueueing. */
 int cf_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B);
 /* cv2.resize + forward in one enqueue (centerface.py:30-41): imgs uint8 [B,h,w,3] BGR of ANY size are
- * stretch-resized on the device to the ctx's (H, W) (bilinear, half-pixel centres, float32, round to
- * nearest) and fed to the network.  Bit parity with cv2's fixed-point INTER_LINEAR is unpinned. */
+ * stretch-resized on the device to the ctx's (H, W) with OpenCV's fixed-point INTER_LINEAR arithmetic for uint8
+ * (11-bit coefficients, int32 passes; csrc/cf_util.hip restates it) and fed to the network.  Pinned to the
+ * published algorithm, not to a particular cv2 binary (cv2 is not installable where this was built). */
 int cf_forward_resized(cf_ctx* ctx, const void* imgs_u8, int in_on_device, int B, int h, int w);
 /* the resized uint8 [B,H,W,3] batch of the last cf_forward_resized (tests) */
 int cf_get_resized_input(cf_ctx* ctx, void* out_u8, int B);
@@ -253,6 +254,16 @@ int cf_op_ctdet_loss(int device, const float* hm_raw, const float* wh, const flo
 int cf_op_encode_targets(int device, const float* boxes, const float* lms, const int32_t* counts, int B, int h, int w,
                          int max_objs, float* hm, float* wh, float* reg, int64_t* ind, uint8_t* reg_mask,
                          float* landmarks, int64_t* lm_ind, uint8_t* lm_mask);
+/* ShuffleV2Block.forward in eval mode (model/blocks.py:4-62) as ONE entry point: x [B, 2*inp, H, W] (stride 1) or
+ * [B, inp, H, W] (stride 2) -> y [B, oup, Ho, Wo].  Weights as the reference's state_dict holds them: m_w0
+ * [mid, inp] (branch_main.0), m_wdw [mid,1,k,k] (.3), m_w5 [oup-inp, mid] (.5); p_wdw [inp,1,k,k] (branch_proj.0),
+ * p_w2 [inp, inp] (.2) for stride 2 (NULL otherwise); every *_bn* is 4 rows [C]: weight, bias, running_mean,
+ * running_var (eps 1e-5), folded here.  The channel shuffle (:56-62) and the concat (:50,54) are channel
+ * addressing inside the kernels.  inp, mid, oup-inp multiples of 8. */
+int cf_op_shufflev2(int device, int dtype, const float* x, float* y, int B, int inp, int oup, int mid, int H, int W,
+                    int ksize, int stride, const float* m_w0, const float* m_bn1, const float* m_wdw, const float* m_bn4,
+                    const float* m_w5, const float* m_bn6, const float* p_wdw, const float* p_bn1, const float* p_w2,
+                    const float* p_bn3);
 /* stem: ConvReLU(3,32,3,stride 2) on a normalised float NCHW tensor or a uint8 HWC BGR image
  * (model/centernet.py:224 ; centerface.py:32-37). y [B,32,H/2,W/2] */
 int cf_op_stem(int device, int dtype, const void* x, int in_format, const float* w, float* y,

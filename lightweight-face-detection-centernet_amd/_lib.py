@@ -22,7 +22,7 @@ EXPORTS = (
     "cf_load_weights", "cf_forward", "cf_forward_resized", "cf_get_resized_input", "cf_get_heads", "cf_decode_topk", "cf_decode_topk_post", "cf_affine_from_center_scale", "cf_decode_threshold", "cf_decode_threshold_ex", "cf_decode_threshold_sized",
     "cf_detect_topk", "cf_synchronize", "cf_event_record", "cf_event_elapsed_ms",
     "cf_profile_forward", "cf_plan_size", "cf_plan_op", "cf_forward_trace", "cf_graph_stats", "cf_get_streams", "cf_ctdet_loss", "cf_comm_unique_id", "cf_comm_create", "cf_comm_destroy", "cf_gather_topk", "cf_device_alloc", "cf_device_free", "cf_memcpy_h2d", "cf_memcpy_d2h",
-    "cf_op_last_error", "cf_op_mbconv", "cf_op_expand_dw", "cf_op_ctdet_loss", "cf_op_encode_targets", "cf_op_dwconv", "cf_op_pwconv", "cf_op_stem", "cf_op_idaup", "cf_op_heads",
+    "cf_op_last_error", "cf_op_shufflev2", "cf_op_mbconv", "cf_op_expand_dw", "cf_op_ctdet_loss", "cf_op_encode_targets", "cf_op_dwconv", "cf_op_pwconv", "cf_op_stem", "cf_op_idaup", "cf_op_heads",
     "cf_op_ctdet_decode", "cf_op_ctdet_post_process", "cf_op_decode_threshold", "cf_op_decode_threshold_ex", "cf_op_nms",
 )
 
@@ -114,6 +114,7 @@ def lib():
         L.cf_op_dwconv.argtypes = [i, i, fp, fp, fp, fp] + [i] * 9
         L.cf_op_pwconv.argtypes = [i, i, fp, fp, fp, fp, fp] + [i] * 6
         L.cf_op_stem.argtypes = [i, i, vp, i, fp, fp, i, i, i]
+        L.cf_op_shufflev2.argtypes = [i, i, fp, fp] + [i] * 8 + [fp] * 10
         L.cf_op_mbconv.argtypes = [i, i, fp, fp, fp, fp, fp] + [i] * 8
         L.cf_op_expand_dw.argtypes = [i, i, fp, fp, fp, fp] + [i] * 7
         L.cf_op_idaup.argtypes = [i, i, fp, fp, fp, fp, fp, fp, C.c_float, fp] + [i] * 5

@@ -31,7 +31,13 @@ struct PwParams {
     const float* upw;     // [4][N]  deconv tap * BN scale
     const float* upb;     // [N]     BN shift
     int Ho, Wo;           // spatial dims of y (only for the IDAUp fusion)
+    // channel-addressed output (ShuffleV2 concat, model/blocks.py:47-54): y rows have ldy elements and this conv
+    // writes channels [yoff, yoff + N) of them; ldy = 0 means a dense [M][N] output.  Plain pw_kernel only.
+    int ldy, yoff;
 };
+// out[m][c] = x[m][2 c + phase], c < C: the pass-through half of channel_shuffle (model/blocks.py:56-62) written
+// straight into its slice of the block output (rows of ldy elements, channel offset yoff)
+hipError_t launch_shuffle_copy(hipStream_t s, int dtype, const void* x, void* y, long long M, int C, int phase, int ldy, int yoff);
 size_t pw_packed_bytes(int dtype, int K, int N);
 void pw_pack_weights(int dtype, const float* w /*[N][K]*/, int K, int N, void* out_host);
 hipError_t launch_pw(hipStream_t s, int dtype, const PwParams& p);

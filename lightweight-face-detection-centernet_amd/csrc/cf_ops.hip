@@ -303,6 +303,78 @@ int cf_op_heads(int device, int dtype, const float* x, const float* w0, const fl
     return CF_OK;
 }
 
+// ShuffleV2Block.forward, eval mode (model/blocks.py:47-62).  BatchNorm is folded here (float64) into the conv
+// weights + an fp32 bias; the channel shuffle is ADDRESSING, not data movement on the host: the first 1x1 conv of
+// branch_main reads the odd input channels through a zero-interleaved weight matrix over all 2*inp channels (exact:
+// the even channels meet zero weights), the pass-through half is copied by a strided-channel kernel straight into
+// channels [0, inp) of the block output, and both final 1x1 convs write their slice of the output rows
+// (PwParams::ldy / yoff) -- the torch.cat of the reference never materialises.
+int cf_op_shufflev2(int device, int dtype, const float* x, float* y, int B, int inp, int oup, int mid, int H, int W,
+                    int ksize, int stride, const float* m_w0, const float* m_bn1, const float* m_wdw, const float* m_bn4,
+                    const float* m_w5, const float* m_bn6, const float* p_wdw, const float* p_bn1, const float* p_w2,
+                    const float* p_bn3) {
+    const int outputs = oup - inp;
+    if (bad_dtype(dtype) || !x || !y || B < 1 || (ksize != 3 && ksize != 5) || (stride != 1 && stride != 2) || outputs < 8 ||
+        (inp % 8) || (mid % 8) || (outputs % 8) || !m_w0 || !m_bn1 || !m_wdw || !m_bn4 || !m_w5 || !m_bn6) return CF_EINVAL;
+    if (stride == 2 && (!p_wdw || !p_bn1 || !p_w2 || !p_bn3)) return CF_EINVAL;
+    const int Cin = stride == 1 ? 2 * inp : inp, pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const float eps = 1e-5f;                                             // nn.BatchNorm2d default (blocks.py:23,29,32)
+    Scope sc(device);
+    void* xd = sc.to_nhwc(dtype, x, B, Cin, H, W);
+    void* out = sc.alloc((size_t)B * Ho * Wo * oup * elem_size(dtype));
+    const long long Min = (long long)B * H * W, Mout = (long long)B * Ho * Wo;
+
+    auto pw = [&](const void* src, long long M, int K, int N, const float* w /*[N][Kw]*/, int Kw, bool interleave, const float* bn,
+                  void* dst, int ldy, int yoff) {
+        std::vector<double> s1, h1;
+        fold(bn, N, eps, s1, h1);
+        std::vector<float> wf((size_t)N * K, 0.0f), bias(N);
+        for (int n = 0; n < N; ++n) {
+            for (int k = 0; k < Kw; ++k) wf[(size_t)n * K + (interleave ? 2 * k + 1 : k)] = (float)((double)w[(size_t)n * Kw + k] * s1[n]);
+            bias[n] = (float)h1[n];
+        }
+        std::vector<char> packed(pw_packed_bytes(dtype, K, N));
+        pw_pack_weights(dtype, wf.data(), K, N, packed.data());
+        PwParams p{};
+        p.x = src; p.wp = sc.up(packed.data(), packed.size()); p.bias = sc.upv(bias); p.y = dst;
+        p.M = M; p.K = K; p.N = N; p.act = 2; p.ldy = ldy; p.yoff = yoff;
+        if (sc.err == hipSuccess) sc.chk(launch_pw(sc.s, dtype, p));
+    };
+    auto dw = [&](const void* src, int C, const float* w /*[C][1][k][k]*/, const float* bn) -> void* {
+        std::vector<double> s1, h1;
+        fold(bn, C, eps, s1, h1);
+        std::vector<float> wf((size_t)C * ksize * ksize), wp((size_t)C * ksize * ksize), bias(C);
+        for (int c = 0; c < C; ++c) {
+            for (int t = 0; t < ksize * ksize; ++t) wf[(size_t)c * ksize * ksize + t] = (float)((double)w[(size_t)c * ksize * ksize + t] * s1[c]);
+            bias[c] = (float)h1[c];
+        }
+        dw_pack_weights(wf.data(), C, ksize, wp.data());
+        DwParams p{};
+        p.x = src; p.w = sc.upv(wp); p.bias = sc.upv(bias);
+        p.y = sc.alloc((size_t)Mout * C * elem_size(dtype));
+        p.B = B; p.C = C; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.k = ksize; p.s = stride; p.pad_lo = pad; p.act = 0;
+        if (sc.err == hipSuccess) sc.chk(launch_dw(sc.s, dtype, p));
+        return p.y;
+    };
+
+    // branch_main (:20-34): pw + BN + ReLU -> dw + BN -> pw + BN + ReLU, into channels [inp, oup)
+    void* t1 = sc.alloc((size_t)Min * mid * elem_size(dtype));
+    pw(xd, Min, Cin, mid, m_w0, inp, stride == 1, m_bn1, t1, 0, 0);
+    void* t2 = dw(t1, mid, m_wdw, m_bn4);
+    pw(t2, Mout, mid, outputs, m_w5, mid, false, m_bn6, out, oup, inp);
+    if (stride == 1) {
+        // x_proj = the even channels (:56-62), passed through into channels [0, inp)
+        if (sc.err == hipSuccess) sc.chk(launch_shuffle_copy(sc.s, dtype, xd, out, Min, inp, 0, oup, 0));
+    } else {
+        // branch_proj (:36-45): dw + BN -> pw + BN + ReLU, into channels [0, inp)
+        void* p1 = dw(xd, inp, p_wdw, p_bn1);
+        pw(p1, Mout, inp, inp, p_w2, inp, false, p_bn3, out, oup, 0);
+    }
+    sc.to_host_nchw(dtype, out, y, B, oup, Ho, Wo);
+    return sc.result("cf_op_shufflev2");
+}
+
 int cf_op_ctdet_decode(int device, const float* heat, const float* wh, const float* reg, const float* lm,
                        int B, int h, int w, int K, float* dets, float* lms, int64_t* inds) {
     if (!heat || !wh || !dets || B < 1 || K < 1 || (long long)K > (long long)h * w) return CF_EINVAL;

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
                 for (int e = 0; e < P; ++e)
                     v[e] += relu_f(r[e] * p.upw[tap * p.N + ch + e] + p.upb[ch + e]);
             }
-            st16((char*)p.y + ((size_t)m * p.N + ch) * sizeof(T), pack16<T>(v));
+            const size_t ld = p.ldy ? (size_t)p.ldy : (size_t)p.N;
+            st16((char*)p.y + ((size_t)m * ld + p.yoff + ch) * sizeof(T), pack16<T>(v));
         }
     }
 }
@@ -334,7 +335,7 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
     const long long gx = (p.M + 127) / 128;
     // GEMM-heavy layers (no bias / IDAUp epilogue): share weight fragments through LDS
     static const int wl_env = getenv("CF_PW_WLDS") ? atoi(getenv("CF_PW_WLDS")) : -1;     // A/B: 0 off, N = force NBW
-    if (wl_env != 0 && !p.bias && !p.low && p.K >= 64 && NB >= 4 && (p.act == 1 || p.act == 0)) {
+    if (wl_env != 0 && !p.bias && !p.low && !p.ldy && p.K >= 64 && NB >= 4 && (p.act == 1 || p.act == 0)) {
         (void)wl_env;                          // NBW = 4 measured best of {4,5,6,8} on every late layer
         static const int nst_env = getenv("CF_PW_NST") ? atoi(getenv("CF_PW_NST")) : 0;       // A/B: ring depth 2..4
         static const int nbw_env = getenv("CF_PW_NBW") ? atoi(getenv("CF_PW_NBW")) : 0;
@@ -366,9 +367,26 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
     }
 }
 
+template <typename T>
+__global__ void shuffle_copy_kernel(const T* x, T* y, long long M, int C, int phase, int ldy, int yoff) {
+    const long long n = M * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C; const int c = (int)(i - m * C);
+        y[m * ldy + yoff + c] = x[m * (2 * C) + 2 * c + phase];
+    }
+}
+hipError_t launch_shuffle_copy(hipStream_t s, int dtype, const void* x, void* y, long long M, int C, int phase, int ldy, int yoff) {
+    if (M <= 0 || C <= 0) return hipSuccess;
+    long long g = (M * C + 255) / 256; if (g > 16384) g = 16384;
+    if (dtype == 0) hipLaunchKernelGGL(shuffle_copy_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, M, C, phase, ldy, yoff);
+    else hipLaunchKernelGGL(shuffle_copy_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, M, C, phase, ldy, yoff);
+    return hipGetLastError();
+}
+
 hipError_t launch_pw(hipStream_t s, int dtype, const PwParams& p) {
     if (p.M <= 0) return hipSuccess;
     if (p.K % 8 || p.N % 8) return hipErrorInvalidValue;
+    if (p.ldy && ((p.ldy * (int)elem_size(dtype)) % 16 || (p.yoff * (int)elem_size(dtype)) % 16 || p.yoff + p.N > p.ldy)) return hipErrorInvalidValue;
     return dtype == 0 ? dispatch_nbw<float>(s, p) : dispatch_nbw<bf16_t>(s, p);
 }
 

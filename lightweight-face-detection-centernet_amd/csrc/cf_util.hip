@@ -14,21 +14,44 @@ void set_kernel_tag(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------- bilinear resize (centerface.py:30)
-// dst(Y, X) samples src at ((Y + 0.5) * h / H - 0.5, (X + 0.5) * w / W - 0.5), clamped to the image,
-// float32 arithmetic, round-to-nearest-even.  cv2's INTER_LINEAR uses 11-bit fixed-point weights for
-// uint8; cv2 is not installable here, so bit parity with it is UNPINNED (documented in DESIGN.md).
+// cv2.resize(img, (W, H)) with the default INTER_LINEAR on uint8 is FIXED-POINT in OpenCV (third-party code, not
+// under /root/reference and not installable here; algorithm restated from OpenCV 4.x modules/imgproc/src/resize.cpp,
+// the generic path all SIMD paths are bit-exact with):
+//   * per destination column: fx = (float)((dx + 0.5) * scale_x - 0.5) with scale_x = 1.0 / ((double)W / w),
+//     sx = floor(fx), fx -= sx; sx < 0 -> (sx, fx) = (0, 0); sx >= w - 1 -> (w - 1, 0);
+//     coefficients as shorts with 11 fractional bits: a0 = cvRound((1.f - fx) * 2048), a1 = cvRound(fx * 2048);
+//   * rows likewise (fy, sy, b0, b1), except that out-of-range rows are CLAMPED (sy + k -> [0, h - 1]) and the
+//     coefficients kept;
+//   * horizontal pass in int32: r = S[sx] * a0 + S[sx + 1] * a1;
+//   * vertical pass (VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>>):
+//     dst = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
+// cvRound = round-half-to-even (rintf).  Parity with an actual cv2 build is UNPINNED (no cv2 anywhere we can run);
+// the oracle restates the same published algorithm and the known answers in the tests (identity, exact 2x
+// patterns) are derived by hand from it.
+__device__ __forceinline__ void cv_linear_coeffs(int d, int src, int dst, bool clamp_coeff, int& s0, int& s1, int& c0, int& c1) {
+    const double scale = 1.0 / ((double)dst / (double)src);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (clamp_coeff) {                                   // columns: coefficient reset at the borders
+        if (si < 0) { f = 0.0f; si = 0; }
+        if (si >= src - 1) { f = 0.0f; si = src - 1; }
+        s0 = si; s1 = min(si + 1, src - 1);
+    } else {                                             // rows: indices clamped, coefficients kept
+        s0 = min(max(si, 0), src - 1); s1 = min(max(si + 1, 0), src - 1);
+    }
+    c0 = (int)rintf((1.0f - f) * 2048.0f);
+    c1 = (int)rintf(f * 2048.0f);
+}
 __global__ void resize_u8_kernel(const uint8_t* src, uint8_t* dst, int B, int h, int w, int H, int W) {
     const long long n = (long long)B * H * W;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int X = (int)(i % W); const long long t = i / W;
     const int Y = (int)(t % H); const int b = (int)(t / H);
-    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    float fy = ((float)Y + 0.5f) * sy - 0.5f, fx = ((float)X + 0.5f) * sx - 0.5f;
-    fy = fminf(fmaxf(fy, 0.0f), (float)(h - 1)); fx = fminf(fmaxf(fx, 0.0f), (float)(w - 1));
-    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
-    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    cv_linear_coeffs(X, w, W, true, x0, x1, a0, a1);
+    cv_linear_coeffs(Y, h, H, false, y0, y1, b0, b1);
     const uint8_t* p00 = src + (((size_t)b * h + y0) * w + x0) * 3;
     const uint8_t* p01 = src + (((size_t)b * h + y0) * w + x1) * 3;
     const uint8_t* p10 = src + (((size_t)b * h + y1) * w + x0) * 3;
@@ -36,10 +59,10 @@ __global__ void resize_u8_kernel(const uint8_t* src, uint8_t* dst, int B, int h,
     uint8_t* d = dst + (size_t)i * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float top = (float)p00[c] * (1.0f - wx) + (float)p01[c] * wx;
-        const float bot = (float)p10[c] * (1.0f - wx) + (float)p11[c] * wx;
-        const float v = top * (1.0f - wy) + bot * wy;
-        d[c] = (uint8_t)fminf(fmaxf(rintf(v), 0.0f), 255.0f);
+        const int r0 = (int)p00[c] * a0 + (int)p01[c] * a1;
+        const int r1 = (int)p10[c] * a0 + (int)p11[c] * a1;
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        d[c] = (uint8_t)min(max(v, 0), 255);
     }
 }
 hipError_t launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int B, int h, int w, int H, int W) {

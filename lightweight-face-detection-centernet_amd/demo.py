@@ -1,6 +1,27 @@
-"""The evaluator-facing pieces of the reference's ``demo.py``: the WIDER-FACE result-file format
-(``demo.py:81-87``) and a batched dump loop.  GUI/webcam/``cv2.imshow`` parts are out of scope."""
+"""The evaluator-facing pieces of the reference's ``demo.py``: image files in (``cv2.imread`` at demo.py:31,74 ->
+PIL here), the WIDER-FACE result-file format (``demo.py:81-87``) and a batched dump loop.  GUI/webcam/``cv2.imshow``
+parts are out of scope."""
 import os
+
+import numpy as np
+
+
+def imread(path):
+    """``cv2.imread(path)`` (demo.py:31,74): uint8 [H, W, 3] in BGR channel order.  Decoded with PIL (cv2 is not
+    a dependency); both sit on libjpeg, bit parity of the DECODER with a cv2 build is unpinned."""
+    from PIL import Image
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def detect_file(detector, path, threshold=0.3):
+    """demo.py:30-38 (``test_image``): read one image file and run ``CenterFace.__call__`` on it.  ``detector`` must
+    have been built for the image's (h, w) -- or be a ``CenterFaceBuckets``, which takes any size."""
+    frame = imread(path)
+    if hasattr(detector, "detect"):
+        return detector.detect([frame], threshold)[0]
+    return detector(frame, threshold)
 
 
 def format_wider_result(rel_name, dets):

@@ -121,6 +121,29 @@ def heads(x, sd, collapse=False, dtype="fp32", device=0):
     return {"hm": out[:, 0:1], "wh": out[:, 1:3], "lm": out[:, 3:13], "reg": out[:, 13:15]}
 
 
+def shuffle_v2_block(x, sd, inp, oup, mid, ksize, stride, prefix="", dtype="fp32", device=0):
+    """ShuffleV2Block(inp, oup, mid, ksize=, stride=).forward in eval mode (model/blocks.py:4-62) from a
+    state_dict slice with the reference's key names (branch_main.0/1/3/4/5/6, branch_proj.0/1/2/3): ONE C-ABI call;
+    BN fold, channel shuffle and concat all happen behind it."""
+    x = f32(x)
+    B, _, H, W = x.shape
+    pad = ksize // 2
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    y = np.empty((B, oup, Ho, Wo), np.float32)
+
+    def w(key):
+        return f32(np.asarray(sd[prefix + key + ".weight"]))
+    args = [w("branch_main.0"), _bn4(sd, prefix + "branch_main.1"), w("branch_main.3"), _bn4(sd, prefix + "branch_main.4"),
+            w("branch_main.5"), _bn4(sd, prefix + "branch_main.6")]
+    if stride == 2:
+        args += [w("branch_proj.0"), _bn4(sd, prefix + "branch_proj.1"), w("branch_proj.2"), _bn4(sd, prefix + "branch_proj.3")]
+    else:
+        args += [None, None, None, None]
+    _lib.check(_lib.lib().cf_op_shufflev2(device, _DT[dtype], ptr(x), ptr(y), B, int(inp), int(oup), int(mid), H, W,
+                                          int(ksize), int(stride), *[ptr(a) for a in args]), op=True)
+    return y
+
+
 def ctdet_decode(heat, wh, reg=None, K=100, lm=None, device=0):
     """ctdet_decode (centerface_ext.py:52-82): (dets [B,K,6], lms [B,K,10]|None, inds [B,K] int64)."""
     heat, wh, reg, lm = f32(heat), f32(wh), f32(reg), f32(lm)

@@ -353,3 +353,30 @@ def accept(stat, bf16_output=True, n=None):
     if n:
         lim1, limd = max(lim1, 2.0 / n), max(limd, 8.0 / n)
     return mx <= 2.0 and f1 <= lim1 and (fd <= limd or not bf16_output)
+
+
+def shuffle_v2_block(x, sd, inp, oup, mid, ksize, stride, prefix=""):
+    """ShuffleV2Block.forward (model/blocks.py:47-62) as cf_op_shufflev2 computes it on bf16 storage: BN folded in
+    float64 into bf16 1x1 weights / fp32 depthwise taps + fp32 bias, every intermediate a bf16 HBM tensor."""
+    sd = O.to_torch_sd(sd)
+    x = q_bf16(_t(x).float())
+    pad = (ksize // 2, ksize // 2)
+
+    def fold(conv, bn):
+        scale, shift = bn_fold(sd, prefix + bn, 1e-5)
+        w = sd[prefix + conv + ".weight"].double()
+        return (w * scale.reshape(-1, 1, 1, 1)).float(), shift.float()
+
+    def main(v):
+        w, b = fold("branch_main.0", "branch_main.1")
+        v = pw_op(v, w, b, "relu")
+        w, b = fold("branch_main.3", "branch_main.4")
+        v = dw_op(v, w, ksize, stride, pad, "none", b)
+        w, b = fold("branch_main.5", "branch_main.6")
+        return pw_op(v, w, b, "relu")
+    if stride == 1:
+        return torch.cat((x[:, 0::2], main(x[:, 1::2])), 1)
+    w, b = fold("branch_proj.0", "branch_proj.1")
+    p = dw_op(x, w, ksize, stride, pad, "none", b)
+    w, b = fold("branch_proj.2", "branch_proj.3")
+    return torch.cat((pw_op(p, w, b, "relu"), main(x)), 1)

@@ -7,8 +7,9 @@ Parity status: PINNED.  The reference ships no tests or golden vectors (SURVEY.m
 the pins are outputs of the reference itself, imported in the build container by
 ``tools/gen_goldens.py`` (inference path) and ``tools/gen_goldens_train.py`` (loss / target encoder) and
 committed under ``tests/golden/``; ``tests/test_oracle_vs_golden.py``
-checks every function here against them.  Unpinned: ``cv2.resize`` (centerface.py:30) -- cv2 is not
-installed anywhere we can run, so only the identity-resize case (H, W multiples of 32) is covered.
+checks every function here against them.  ``cv2.resize`` (centerface.py:30): cv2 is not installed anywhere we
+can run, so the resize is pinned to OpenCV's PUBLISHED fixed-point INTER_LINEAR algorithm (restated in
+``resize_bilinear_u8``, known answers derived by hand) and not to a cv2 binary.
 
 Third-party arithmetic: the reference's convolutions, batch-norm, max-pool and top-k are
 PyTorch calls (README.md:8 names torch 1.0.1, no lockfile).  The network restatement below calls
@@ -158,21 +159,41 @@ def transform(h, w):
     return h_new, w_new, h_new / h, w_new / w
 
 
+def _cv_linear_coeffs(dst, src, clamp_coeff):
+    """OpenCV 4.x modules/imgproc/src/resize.cpp, INTER_LINEAR tables for 8-bit images (third-party code: not under
+    /root/reference, version unpinned by the reference -- README.md names no OpenCV version; restated from the
+    published source): index pair and 11-bit fixed-point coefficient pair per destination coordinate."""
+    scale = 1.0 / (float(dst) / float(src))                       # double
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    si = np.floor(f).astype(np.int64)
+    f = f - si.astype(np.float32)
+    if clamp_coeff:                                               # columns: xmin / xmax rule
+        lo, hi = si < 0, si >= src - 1
+        f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
+        si = np.where(lo, 0, np.where(hi, src - 1, si))
+        s0, s1 = si, np.minimum(si + 1, src - 1)
+    else:                                                         # rows: clip(sy + k, 0, h)
+        s0, s1 = np.clip(si, 0, src - 1), np.clip(si + 1, 0, src - 1)
+    c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)       # cvRound: half to even
+    c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    return s0, s1, c0, c1
+
+
 def resize_bilinear_u8(img, new_h, new_w):
-    """Stand-in for cv2.resize(img, (w, h)) (centerface.py:30): bilinear, half-pixel centres, clamped,
-    float32 arithmetic, round-to-nearest-even -- the formula the device kernel implements.  cv2 is not
-    installable here, so parity with cv2's fixed-point INTER_LINEAR is UNPINNED."""
+    """cv2.resize(img, (new_w, new_h)) (centerface.py:30; default INTER_LINEAR) as OpenCV computes it for uint8:
+    fixed point, 11-bit coefficients, int32 horizontal pass, then
+    ``(((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2``.  cv2 is not installable here, so this is pinned
+    to OpenCV's published algorithm, NOT to a cv2 binary (parity with a particular cv2 build: unpinned)."""
     h, w = img.shape[:2]
-    f = np.float32
-    fy = np.clip((np.arange(new_h, dtype=f) + f(0.5)) * (f(h) / f(new_h)) - f(0.5), f(0), f(h - 1)).astype(f)
-    fx = np.clip((np.arange(new_w, dtype=f) + f(0.5)) * (f(w) / f(new_w)) - f(0.5), f(0), f(w - 1)).astype(f)
-    y0 = np.floor(fy).astype(np.int64); x0 = np.floor(fx).astype(np.int64)
-    y1 = np.minimum(y0 + 1, h - 1); x1 = np.minimum(x0 + 1, w - 1)
-    wy = (fy - y0.astype(f))[:, None, None]; wx = (fx - x0.astype(f))[None, :, None]
-    im = img.astype(f)
-    top = im[y0][:, x0] * (f(1) - wx) + im[y0][:, x1] * wx
-    bot = im[y1][:, x0] * (f(1) - wx) + im[y1][:, x1] * wx
-    return np.clip(np.rint(top * (f(1) - wy) + bot * wy), 0, 255).astype(np.uint8)
+    x0, x1, a0, a1 = _cv_linear_coeffs(new_w, w, True)
+    y0, y1, b0, b1 = _cv_linear_coeffs(new_h, h, False)
+    im = img.astype(np.int64)
+    a0, a1 = a0[None, :, None], a1[None, :, None]
+    r0 = im[y0][:, x0] * a0 + im[y0][:, x1] * a1
+    r1 = im[y1][:, x0] * a0 + im[y1][:, x1] * a1
+    b0, b1 = b0[:, None, None], b1[:, None, None]
+    v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
 
 
 def preprocess(img_bgr_u8):

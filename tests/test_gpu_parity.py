@@ -171,37 +171,23 @@ def test_conv1x1bn_idaup_heads_vs_reference(golden, dtype):
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_shufflev2_block_vs_reference(golden, dtype):
-    """ShuffleV2Block (model/blocks.py:4-62) composed from the same dw/pw kernels: BN folded into
-    weight scale + bias, channel shuffle = even/odd channel addressing."""
+    """ShuffleV2Block (model/blocks.py:4-62) through ONE product entry point (cf_op_shufflev2): BN fold in the
+    runtime, channel shuffle and concat as channel addressing inside the kernels -- against the reference's goldens
+    (stride 1 / 2, 3x3 / 5x5; fp32) and the bf16-emulating oracle (bf16)."""
     g = golden("ops")
-
-    def fold(sd, conv, bn):
-        sc = sd[bn + ".weight"].astype(np.float64) / np.sqrt(sd[bn + ".running_var"].astype(np.float64) + 1e-5)
-        w = sd[conv + ".weight"]
-        wf = (w.astype(np.float64) * sc.reshape(-1, 1, 1, 1)).astype(np.float32)
-        return wf, (sd[bn + ".bias"] - sd[bn + ".running_mean"] * sc).astype(np.float32)
-
     for i in range(4):
         inp, oup, mid, k, s = (int(v) for v in g["sh%d_cfg" % i])
         sd, x = _sub(g, "sh%d_w_" % i), g["sh%d_x" % i]
-
-        def main(v):
-            w, b = fold(sd, "branch_main.0", "branch_main.1")
-            v = ops.conv_pw(v, w, act="relu", bias=b, dtype=dtype)
-            w, b = fold(sd, "branch_main.3", "branch_main.4")
-            v = ops.conv_dw(v, w, k, s, pad=(k // 2, k // 2), act="none", bias=b, dtype=dtype)
-            w, b = fold(sd, "branch_main.5", "branch_main.6")
-            return ops.conv_pw(v, w, act="relu", bias=b, dtype=dtype)
-        if s == 1:
-            y = np.concatenate([x[:, 0::2], main(np.ascontiguousarray(x[:, 1::2]))], 1)
+        y = ops.shuffle_v2_block(x, sd, inp, oup, mid, k, s, dtype=dtype)
+        assert y.shape == g["sh%d_y" % i].shape
+        if dtype == "fp32":
+            np.testing.assert_allclose(y, g["sh%d_y" % i], rtol=1e-4, atol=1e-4, err_msg="sh%d" % i)
+            if s == 1:                                   # the pass-through half is a copy: bit-exact
+                assert np.array_equal(y[:, :inp], x[:, 0::2])
         else:
-            w, b = fold(sd, "branch_proj.0", "branch_proj.1")
-            p = ops.conv_dw(x, w, k, s, pad=(k // 2, k // 2), act="none", bias=b, dtype=dtype)
-            w, b = fold(sd, "branch_proj.2", "branch_proj.3")
-            p = ops.conv_pw(p, w, act="relu", bias=b, dtype=dtype)
-            y = np.concatenate([p, main(x)], 1)
-        tol = dict(rtol=1e-4, atol=1e-4) if dtype == "fp32" else dict(rtol=6e-2, atol=6e-2)
-        np.testing.assert_allclose(y, g["sh%d_y" % i], **tol, err_msg="sh%d" % i)
+            _emu_close(y, E.shuffle_v2_block(x, sd, inp, oup, mid, k, s), "sh%d" % i)
+    with pytest.raises(ValueError):
+        ops.shuffle_v2_block(g["sh0_x"], _sub(g, "sh0_w_"), 24, 48, 20, 3, 1)         # mid not a multiple of 8: loud
 
 
 # ------------------------------------------------------------------------------- whole network
@@ -475,26 +461,49 @@ def test_decode_d2_and_get_detections(golden):
     eng.close()
 
 
-def test_device_resize_and_non32_sizes():
-    """centerface.py:30 on the device: bilinear stretch to the next multiple of 32, against the numpy
-    restatement of the same formula (cv2 parity is unpinned), then the full __call__ on a 478x720 image
-    (imgs/1.jpg's size, BASELINE config 1 geometry)."""
+def test_device_resize_and_non32_sizes(tmp_path):
+    """centerface.py:30 on the device: cv2.resize's fixed-point INTER_LINEAR (integer arithmetic: BIT-EXACT against
+    the oracle's restatement of OpenCV's published algorithm; parity with a cv2 binary is unpinned), up- and
+    down-scaling, then the full __call__ on a 478x720 image (imgs/1.jpg's size, BASELINE configs[0] geometry) --
+    from a JPEG file through the PIL loader as well, and detections equal the oracle's detect() on the same pixels."""
     rng = np.random.default_rng(12)
     sd = cfa.weights.synthetic_state_dict(0)
-    for (h, w) in ((50, 70), (478, 720)):
+    for (h, w) in ((50, 70), (33, 97), (478, 720)):
         img = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
         face = cfa.CenterFace(h, w, weights=sd, max_batch=2)
         assert (face.img_h_new, face.img_w_new) == (O.transform(h, w)[:2])
         face.engine.forward_resized_enqueue(img)
         got = face.engine.resized_input()
         want = np.stack([O.resize_bilinear_u8(im, face.img_h_new, face.img_w_new) for im in img])
-        diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
-        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+        assert np.array_equal(got, want), (h, w)
+        if (h, w) != (478, 720):
+            face.close()
+    # a 2.3x DOWN-scale through the same kernel (any source size -> the context's size)
+    big = rng.integers(0, 256, (1, 150, 223, 3), dtype=np.uint8)
+    small = cfa.Engine(64, 96, max_batch=1, weights=sd)
+    small.forward_resized_enqueue(big)
+    assert np.array_equal(small.resized_input()[0], O.resize_bilinear_u8(big[0], 64, 96))
+    small.close()
     res = face.detect_batch(list(img))
     assert len(res) == 2
-    rd, rl = O.detect(O.to_torch_sd(sd), img[0])
-    dets, lms = res[0]
-    assert dets.shape[1] == 5 and lms.shape[1] == 10 and abs(len(dets) - len(rd)) <= max(2, len(rd) // 50)
+    for b in range(2):
+        rd, rl = O.detect(O.to_torch_sd(sd), img[b])
+        dets, lms = res[b]
+        assert dets.shape == rd.shape and lms.shape == rl.shape
+        # same pixels in, fp32 engine within 1e-3 of the oracle's heads: same candidates up to threshold-crossers
+        assert np.abs(dets - rd).max() <= 1.0 if len(rd) else True
+    # configs[0]: a 720x478 JPEG from disk (PIL decode -> BGR) through CenterFace.__call__
+    from PIL import Image
+    from centerface_amd import demo
+    path = str(tmp_path / "1.jpg")
+    Image.fromarray(img[0][:, :, ::-1]).save(path, quality=95)
+    frame = demo.imread(path)
+    assert frame.shape == (478, 720, 3) and frame.dtype == np.uint8
+    assert np.array_equal(frame, np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    dets, lms = demo.detect_file(face, path)
+    d2, l2 = face(frame)
+    assert np.array_equal(dets, d2) and np.array_equal(lms, l2)
+    face.close()
 
 
 def test_centerface_call_matches_oracle():

@@ -252,3 +252,24 @@ def test_f16_round_toward_zero_helper():
     assert torch.equal(r, exp), (r, exp)
     # round-to-nearest saturating (tap packer)
     assert torch.equal(E.q_f16_rne_sat(torch.tensor([7e4, 65519.0, 1.00048828125])), torch.tensor([65504.0, 65504.0, 1.0]))
+
+
+def test_cv2_fixed_point_resize_known_answers():
+    """resize_bilinear_u8 = OpenCV's fixed-point INTER_LINEAR for uint8 (resize.cpp; cv2 itself is not installable
+    here).  Known answers derived by hand from the published algorithm: identity, a 2x horizontal up-sample of
+    [0, 255] (column coefficients (2048,0), (1536,512), (512,1536), (2048,0) -> r = 0, 130560, 391680, 522240 ->
+    ((2048 * (r >> 4)) >> 16) + 2 >> 2 = 0, 64, 191, 255), a 2x vertical one, and monotonic / range properties."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(O.resize_bilinear_u8(img, 37, 53), img)
+    two = np.array([[[0, 0, 0], [255, 255, 255]]], np.uint8)                   # 1 x 2
+    assert O.resize_bilinear_u8(two, 1, 4)[0, :, 0].tolist() == [0, 64, 191, 255]
+    col = two.transpose(1, 0, 2)                                              # 2 x 1: rows are clamped, coefficients kept
+    # dy=0: fy=-0.25 -> sy=-1 (both rows clamp to 0) ; dy=1: (1536, 512) ; dy=2: (512, 1536) ; dy=3: sy=1, rows (1, 1)
+    assert O.resize_bilinear_u8(col, 4, 1)[:, 0, 0].tolist() == [0, 64, 191, 255]
+    flat = np.full((9, 11, 3), 137, np.uint8)
+    assert (O.resize_bilinear_u8(flat, 32, 32) == 137).all()                  # constants survive (coefficients sum to 2048)
+    up = O.resize_bilinear_u8(img, 64, 64)
+    assert up.min() >= img.min() and up.max() <= img.max()
+    # transform() + resize: the geometry of BASELINE configs[0] (imgs/1.jpg is 720 x 478 -> 736 x 480)
+    assert O.transform(478, 720)[:2] == (480, 736)
