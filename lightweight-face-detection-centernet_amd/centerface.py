@@ -35,10 +35,10 @@ class Engine(object):
         self.h, self.w = self.H // 4, self.W // 4
         self.dtype = dtype
         if collapse_heads is None:
-            # the head pair conv3x3+b -> conv1x1+b is linear (model/centernet.py:249-256): folding it
-            # into one 3x3 24->15 conv is exact algebra; default on in the throughput mode, off in
-            # the fp32 parity mode so that mode keeps the reference's operation order
-            collapse_heads = (dtype not in ("fp32", "float32", "f32"))
+            # the head pair conv3x3+b -> conv1x1+b is linear (model/centernet.py:249-256): folding it (in float64)
+            # into one 3x3 24->15 conv is exact algebra and 6x fewer flops -- the default in both modes; pass
+            # collapse_heads=False for the two-stage kernel that keeps the reference's operation order
+            collapse_heads = True
         flags = ((_lib.CF_FLAG_COLLAPSE_HEADS if collapse_heads else 0) | (0 if fuse else _lib.CF_FLAG_NO_FUSE)
                  | (0 if graph else _lib.CF_FLAG_NO_GRAPH) | (0 if uphead else _lib.CF_FLAG_NO_UPHEAD))
         handle = C.c_void_p()

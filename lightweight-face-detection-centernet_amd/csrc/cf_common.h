@@ -98,6 +98,17 @@ __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 __device__ __forceinline__ u32x4 zero16() { u32x4 z; z.x = z.y = z.z = z.w = 0u; return z; }
 
+// XCD-aware tile order.  The hardware deals consecutive workgroup ids round-robin onto the 8 XCDs (observed, for
+// speed only -- not a contract; MI355X_MICROARCH.md), so spatially adjacent tiles land on different L2s and every
+// halo row / shared cache line is fetched once per XCD that touches it.  This remaps the linear workgroup id so that
+// each XCD walks a CONTIGUOUS range of tiles (x fastest, then y, then batch): neighbours share an L2.
+__device__ __forceinline__ void xcd_tile_order(unsigned& bx, unsigned& by, unsigned& bz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    unsigned l = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if ((n & 7u) == 0u) l = (l & 7u) * (n >> 3) + (l >> 3);
+    bx = l % gx; l /= gx; by = l % gy; bz = l / gy;
+}
+
 // host-side fp32 -> bf16 (RNE), identical rounding to the device instruction for finite values
 static inline uint16_t host_f32_to_bf16(float f) {
     uint32_t u; __builtin_memcpy(&u, &f, 4);

@@ -58,8 +58,10 @@ __device__ __forceinline__ float kept_score(const float* hm, int hs, int h, int 
     return (mx == v) ? v : (v * 0.0f + 0.0f);
 }
 
-constexpr int kCollectCells = 4096;                    // cells per workgroup of peak_collect_kernel
+constexpr int kCollectCells = 1024;                    // cells per workgroup of peak_collect_kernel: 4 per thread
 
+// One group of four cells per thread: the chain loads -> ballot -> reserve -> stores is walked once, and a
+// 64 x 640x640 batch is 1600 workgroups (6 waves per SIMD in flight).
 __global__ __launch_bounds__(256) void peak_collect_kernel(TopkParams p) {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int HW = p.h * p.w;
@@ -67,44 +69,52 @@ __global__ __launch_bounds__(256) void peak_collect_kernel(TopkParams p) {
     const int hs = p.hm_plane ? 1 : 16;
     u64* keys = p.scratch + (size_t)b * HW;
     const int base = blockIdx.x * kCollectCells;
-#pragma unroll 1
-    for (int g = 0; g < 4; ++g) {
-        float v[4], mx[4];
-        int idx[4];
+    float v[4], mx[4];
+    int idx[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base + (g * 4 + u) * 256 + tid;
-            idx[u] = i;
-            const int ic = i < HW ? i : HW - 1;
-            const int y = ic / p.w, x = ic - y * p.w;
-            v[u] = hm[(size_t)ic * hs];
-            mx[u] = v[u];
+    for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + tid;
+        idx[u] = i;
+        const int ic = i < HW ? i : HW - 1;
+        const int y = ic / p.w, x = ic - y * p.w;
+        v[u] = hm[(size_t)ic * hs];
+        mx[u] = v[u];
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+        for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int yy = min(max(y + dy, 0), p.h - 1), xx = min(max(x + dx, 0), p.w - 1);
-                    mx[u] = fmaxf(mx[u], hm[((size_t)yy * p.w + xx) * hs]);
-                }
-        }
-        uint32_t ok[4]; bool hit[4]; unsigned long long bal[4]; uint32_t tot = 0;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = min(max(y + dy, 0), p.h - 1), xx = min(max(x + dx, 0), p.w - 1);
+                mx[u] = fmaxf(mx[u], hm[((size_t)yy * p.w + xx) * hs]);
+            }
+    }
+    uint32_t ok[4]; bool hit[4]; unsigned long long bal[4]; uint32_t tot = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float kept = (mx[u] == v[u]) ? v[u] : (v[u] * 0.0f + 0.0f);
-            ok[u] = orderable(kept);
-            hit[u] = idx[u] < HW && ok[u] != kZeroOk;
-            bal[u] = __ballot(hit[u]);
-            tot += (uint32_t)__popcll(bal[u]);
-        }
-        if (tot == 0) continue;                           // wave-uniform
-        uint32_t off = 0;
-        if (lane == 0) off = (uint32_t)atomicAdd(&p.count[b], (int)tot);   // one atomic per wave and group
-        off = __shfl(off, 0);
+    for (int u = 0; u < 4; ++u) {
+        const float kept = (mx[u] == v[u]) ? v[u] : (v[u] * 0.0f + 0.0f);
+        ok[u] = orderable(kept);
+        hit[u] = idx[u] < HW && ok[u] != kZeroOk;
+        bal[u] = __ballot(hit[u]);
+        tot += (uint32_t)__popcll(bal[u]);
+    }
+    // one returning atomic per WORKGROUP, on a counter that owns its cache line (kTopkCountStride): returning atomics
+    // on one line serialise in the L2 (~8 ns each) -- per-wave atomics on 64 adjacent counters made this kernel 36-52 us
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t wbase;
+    const int wave = tid >> 6;
+    if (lane == 0) wtot[wave] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t all = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        wbase = all ? (uint32_t)atomicAdd(&p.count[(size_t)b * kTopkCountStride], (int)all) : 0u;
+    }
+    __syncthreads();
+    if (tot == 0) return;                               // wave-uniform
+    uint32_t off = wbase;
+    for (int w2 = 0; w2 < wave; ++w2) off += wtot[w2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (hit[u]) keys[off + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull))] = ((u64)ok[u] << 32) | (u64)(0xffffffffu - (uint32_t)idx[u]);
-            off += (uint32_t)__popcll(bal[u]);
-        }
+    for (int u = 0; u < 4; ++u) {
+        if (hit[u]) keys[off + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull))] = ((u64)ok[u] << 32) | (u64)(0xffffffffu - (uint32_t)idx[u]);
+        off += (uint32_t)__popcll(bal[u]);
     }
 }
 
@@ -142,15 +152,16 @@ __device__ __forceinline__ void find_digit(const uint32_t* hist, uint32_t kth, u
 
 constexpr int kStageCap = 4096;                        // list entries staged in LDS (32 KB)
 
-// BIG = false: K <= 1024, survivors live in registers / LDS.  BIG = true: any K, survivors, sort and the final
-// order live in p.big (global; one workgroup per image, so __syncthreads orders its accesses).
-template <bool BIG>
-__global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
-    __shared__ uint32_t hist[2048];
+// BIG = false: K <= NT, survivors live in registers / LDS.  BIG = true: any K, survivors, sort and the final
+// order live in p.big (global; one workgroup per image, so __syncthreads orders its accesses).  NT = 256 threads
+// for K <= 256 (the usual top-100: four waves make every barrier cheap), 1024 otherwise.
+template <int NT, bool BIG>
+__global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
+    __shared__ uint32_t hist3[3][2048];                 // one histogram per score pass, zeroed once up front
     __shared__ uint32_t res[3];
     __shared__ uint32_t nsel, npos_s, zfound;
-    __shared__ uint32_t wave_cnt[16];
-    __shared__ u64 sel[1024];
+    __shared__ uint32_t wave_cnt[NT / 64];
+    __shared__ u64 sel[BIG ? 64 : NT];
     __shared__ u64 staged[kStageCap];
 
     const int b = blockIdx.x;
@@ -159,21 +170,21 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
     const int K = p.K;
     const float* hm = p.hm_plane ? p.hm_plane + (size_t)b * HW : p.heads + (size_t)b * HW * 16;
     const int hs = p.hm_plane ? 1 : 16;
-    const int L = p.count[b];
+    const int L = p.count[(size_t)b * kTopkCountStride];
     const u64* list = p.scratch + (size_t)b * HW;
+    for (int i = tid; i < 3 * 2048; i += NT) (&hist3[0][0])[i] = 0;
+    if (tid == 0) npos_s = 0;
     if (L <= kStageCap) {                               // workgroup-uniform
-        for (int i = tid; i < L; i += 1024) staged[i] = list[i];
+        for (int i = tid; i < L; i += NT) staged[i] = list[i];
         list = staged;
     }
-    // ---- pass 0: histogram of the top 11 score bits over the list; positives = bins >= 1024 (the list never holds +0)
-    for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
-    if (tid == 0) npos_s = 0;
     __syncthreads();
+    // ---- pass 0: histogram of the top 11 score bits over the list; positives = bins >= 1024 (the list never holds +0)
     {
         uint32_t mypos = 0;
-        for (int i = tid; i < L; i += 1024) {
+        for (int i = tid; i < L; i += NT) {
             const uint32_t ok = (uint32_t)(list[i] >> 32);
-            atomicAdd(&hist[ok >> 21], 1u);
+            atomicAdd(&hist3[0][ok >> 21], 1u);
             mypos += ok > kZeroOk ? 1u : 0u;
         }
         for (int off = 32; off > 0; off >>= 1) mypos += __shfl_xor(mypos, off);
@@ -199,10 +210,9 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
         bool done = false;
         for (int pass = 0; pass < 3 && !done; ++pass) {
             const int sh = pass == 0 ? 53 : (pass == 1 ? 42 : 32), wd = pass == 2 ? 10 : 11;
+            uint32_t* hist = hist3[pass];
             if (pass > 0) {                                  // pass 0's histogram is already there
-                for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
-                __syncthreads();
-                for (int i = tid; i < L; i += 1024) {
+                for (int i = tid; i < L; i += NT) {
                     const u64 k = list[i];
                     if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> sh) & ((1u << wd) - 1u)], 1u);
                 }
@@ -213,20 +223,20 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
             prefix |= (u64)res[0] << sh;
             mask |= (u64)((1u << wd) - 1u) << sh;
             kth -= res[1];
-            const uint32_t in_bin = res[2];
-            __syncthreads();
             // every key that shares the fixed bits is needed: nothing left to break
-            if (kth == in_bin) done = true;
+            if (kth == res[2]) done = true;
         }
         if (!done) {
             // ~index occupies the low 32 bits; its bits above `ibits` are all ones for every key
             const u64 hi_ones = (ibits < 32) ? ((0xffffffffull >> ibits) << ibits) : 0ull;
             prefix |= hi_ones; mask |= hi_ones;
+            uint32_t* hist = hist3[0];
             for (int rem = ibits; rem > 0 && !done;) {
                 const int wd = rem < 11 ? rem : 11, sh = rem - wd;
-                for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+                __syncthreads();                             // everyone has read res / the previous histogram
+                for (int i = tid; i < 2048; i += NT) hist[i] = 0;
                 __syncthreads();
-                for (int i = tid; i < L; i += 1024) {
+                for (int i = tid; i < L; i += NT) {
                     const u64 k = list[i];
                     if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> sh) & ((1u << wd) - 1u)], 1u);
                 }
@@ -236,9 +246,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
                 prefix |= (u64)res[0] << sh;
                 mask |= (u64)((1u << wd) - 1u) << sh;
                 kth -= res[1];
-                const uint32_t in_bin = res[2];
-                __syncthreads();
-                if (kth == in_bin) done = true;
+                if (kth == res[2]) done = true;
                 rem = sh;
             }
         }
@@ -250,14 +258,14 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
     while (sortn < (int)M) sortn <<= 1;
     u64* gbuf = BIG ? p.big + (size_t)b * p.big_stride : nullptr;      // [sortn] sort buffer, then [K] final order
     if (tid == 0) nsel = 0;
-    if constexpr (BIG) for (int i = tid; i < sortn; i += 1024) gbuf[i] = 0ull;
+    if constexpr (BIG) for (int i = tid; i < sortn; i += NT) gbuf[i] = 0ull;
     __syncthreads();
     if (M > 0) {
-        for (int i = tid; i < L; i += 1024) {
+        for (int i = tid; i < L; i += NT) {
             const u64 k = list[i];
             if (k >= thresh) {
                 const uint32_t pos = atomicAdd(&nsel, 1u);
-                if constexpr (BIG) gbuf[pos] = k; else if (pos < 1024) sel[pos] = k;
+                if constexpr (BIG) gbuf[pos] = k; else if (pos < (uint32_t)NT) sel[pos] = k;
             }
         }
     }
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
     } else {
         for (int k2 = 2; k2 <= sortn; k2 <<= 1)
             for (int j = k2 >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < sortn / 2; t += 1024) {
+                for (int t = tid; t < sortn / 2; t += NT) {
                     const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;       // the pair (lo, lo ^ j)
                     const u64 a = gbuf[lo], c = gbuf[hi];
                     const bool desc = (lo & k2) == 0;
@@ -301,14 +309,14 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
                 __syncthreads();
             }
         u64* fin = gbuf + sortn;
-        for (int t = tid; t < (int)M; t += 1024) fin[(uint32_t)t < lead ? t : t + nz] = gbuf[t];
+        for (int t = tid; t < (int)M; t += NT) fin[(uint32_t)t < lead ? t : t + nz] = gbuf[t];
     }
 
-    // ---- the zero cells (kept score exactly +0.0), lowest index first: ordered scan in rounds of 1024 cells
+    // ---- the zero cells (kept score exactly +0.0), lowest index first: ordered scan in rounds of NT cells
     if (nz > 0) {
         if (tid == 0) zfound = 0;
         __syncthreads();
-        for (int i0 = 0; i0 < HW; i0 += 1024) {
+        for (int i0 = 0; i0 < HW; i0 += NT) {
             const uint32_t have = zfound;                   // uniform (read after the barrier below / above)
             if (have >= nz) break;
             const int i = i0 + tid;
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
             if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
             __syncthreads();
             uint32_t off = have, total = 0;
-            for (int w2 = 0; w2 < 16; ++w2) { if (w2 < wave) off += wave_cnt[w2]; total += wave_cnt[w2]; }
+            for (int w2 = 0; w2 < NT / 64; ++w2) { if (w2 < wave) off += wave_cnt[w2]; total += wave_cnt[w2]; }
             if (hit) {
                 const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                 if (pos < nz) {
@@ -331,10 +339,10 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(TopkParams p) {
         }
     }
     __syncthreads();
-    if (tid == 0) p.count[b] = 0;                       // leave the list empty for the next launch
+    if (tid == 0) p.count[(size_t)b * kTopkCountStride] = 0;     // leave the list empty for the next launch
 
     // ---- gather + box assembly (centerface_ext.py:60-82)
-    for (int t = tid; t < K; t += 1024) {
+    for (int t = tid; t < K; t += NT) {
         const u64 key = BIG ? gbuf[sortn + t] : sel[t];
         const uint32_t idx = 0xffffffffu - (uint32_t)key;
         const float score = from_orderable((uint32_t)(key >> 32));
@@ -386,12 +394,15 @@ hipError_t launch_peak_topk(hipStream_t s, const TopkParams& p) {
     if (p.K > 1024 && (!p.big || p.big_stride < topk_big_stride(p.K))) return hipErrorInvalidValue;
     set_kernel_tag("cf::peak_collect_kernel(cf::TopkParams)");
     hipLaunchKernelGGL(peak_collect_kernel, dim3((unsigned)((HW + kCollectCells - 1) / kCollectCells), p.B), dim3(256), 0, s, p);
-    if (p.K <= 1024) {
-        set_kernel_tag("void cf::topk_select_kernel<false>(cf::TopkParams)");
-        hipLaunchKernelGGL(topk_select_kernel<false>, dim3(p.B), dim3(1024), 0, s, p);
+    if (p.K <= 256) {
+        set_kernel_tag("void cf::topk_select_kernel<256, false>(cf::TopkParams)");
+        hipLaunchKernelGGL((topk_select_kernel<256, false>), dim3(p.B), dim3(256), 0, s, p);
+    } else if (p.K <= 1024) {
+        set_kernel_tag("void cf::topk_select_kernel<1024, false>(cf::TopkParams)");
+        hipLaunchKernelGGL((topk_select_kernel<1024, false>), dim3(p.B), dim3(1024), 0, s, p);
     } else {
-        set_kernel_tag("void cf::topk_select_kernel<true>(cf::TopkParams)");
-        hipLaunchKernelGGL(topk_select_kernel<true>, dim3(p.B), dim3(1024), 0, s, p);
+        set_kernel_tag("void cf::topk_select_kernel<1024, true>(cf::TopkParams)");
+        hipLaunchKernelGGL((topk_select_kernel<1024, true>), dim3(p.B), dim3(1024), 0, s, p);
     }
     return hipGetLastError();
 }

@@ -75,7 +75,7 @@ struct MbParams {
     int k, s, pad_lo, residual;
     int HC, nq, NBE, JX, HALF, rowb;
     size_t lds_bytes;
-    int nw;               // unused
+    int nw;               // mbconv_px_kernel: 1 = XCD-aware tile order (set by the launcher)
     int kind;             // MbGeom::kind
 };
 hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p);
@@ -175,6 +175,7 @@ struct UpHeadParams {
     float* heads;         // [B][h][w][16] fp32
     float* hm_plane;      // [B][h][w] or nullptr
     int B, h, w;
+    int xcd;              // 1 = XCD-aware tile order (set by the launcher)
 };
 hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p);
 
@@ -185,7 +186,7 @@ struct TopkParams {
     const float* heads;   // [B][h*w][16]
     const float* hm_plane; // optional dense [B][h*w] heat map (else channel 0 of the records is used)
     unsigned long long* scratch;   // [B][h*w] composite keys of the cells whose kept score is not +0 (the peak list)
-    int* count;           // [B] list lengths: zero before the launch, zero again after it
+    int* count;           // [B * kTopkCountStride] list lengths, one per 128-byte line: zero before the launch, zero again after it
     unsigned long long* big;       // K > 1024 only: [B][big_stride] sort buffer + final order (topk_big_stride(K))
     size_t big_stride;
     int B, h, w, K, use_reg;
@@ -195,6 +196,7 @@ struct TopkParams {
     float* rec16;         // [B][K][16] or nullptr: x1,y1,x2,y2,score,cls,lm0..9 -- the record the multi-GPU gather ships
     const double* trans;  // optional [B][6]: row-major 2x3 affine (heat-map -> source image) applied to both box corners
 };
+constexpr int kTopkCountStride = 32;   // ints between two images' list counters (each on its own cache line)
 size_t topk_big_stride(int K);
 hipError_t launch_peak_topk(hipStream_t s, const TopkParams& p);
 

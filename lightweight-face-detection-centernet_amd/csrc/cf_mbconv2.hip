@@ -120,7 +120,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 31, h = lane >> 5;
-    const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH, b = blockIdx.z;
+    unsigned tbx = blockIdx.x, tby = blockIdx.y, tbz = blockIdx.z;
+    if (p.nw) xcd_tile_order(tbx, tby, tbz);        // neighbouring tiles (shared halo rows / cache lines) on one XCD's L2
+    const int ox0 = tbx * TOW, oy0 = tby * TOH, b = tbz;
     const int nq = p.nq;
     const int pp = wave % NPP, jg = wave / NPP;
 
@@ -681,8 +683,13 @@ static hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
         configured = true;
     }
     dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
+    // XCD-aware tile order: measured neutral-to-slower on these VALU-bound kernels (layer1.0 0.234 -> 0.237-0.244 ms; their
+    // PMC traffic is already 1.0-1.13x algorithmic), so it stays off here (CF_XCD_ORDER=2 switches it on for A/B runs);
+    // the stem and the up3+heads kernel, whose halo re-fetches across XCDs tripled the input traffic, use it
+    static const bool xcd_on = getenv("CF_XCD_ORDER") && atoi(getenv("CF_XCD_ORDER")) == 2;
+    MbParams q = p; q.nw = xcd_on ? 1 : 0;
     set_kernel_tag("void cf::mbconv_px_kernel<%d, %d, %d, %s, %d, %d, %d, %d, %d>(cf::MbParams)", KS, S, NBO, RESID ? "true" : "false", NW, JX, HC, TOH, TOW);
-    hipLaunchKernelGGL(kfn, grid, blk, LDS, s, p);
+    hipLaunchKernelGGL(kfn, grid, blk, LDS, s, q);
     return hipGetLastError();
 }
 

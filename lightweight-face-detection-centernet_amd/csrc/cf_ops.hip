@@ -383,7 +383,7 @@ int cf_op_ctdet_decode(int device, const float* heat, const float* wh, const flo
     TopkParams p{};
     p.heads = sc.upv(rec);
     p.scratch = (unsigned long long*)sc.alloc((size_t)B * h * w * 8);
-    p.count = (int*)sc.alloc((size_t)B * 4);                                  // zero-initialised by Scope::alloc
+    p.count = (int*)sc.alloc((size_t)B * kTopkCountStride * 4);               // zero-initialised by Scope::alloc
     if (K > 1024) { p.big_stride = topk_big_stride(K); p.big = (unsigned long long*)sc.alloc((size_t)B * p.big_stride * 8); }
     p.B = B; p.h = h; p.w = w; p.K = K; p.use_reg = reg ? 1 : 0;
     p.dets = (float*)sc.alloc((size_t)B * K * 6 * 4);

@@ -475,7 +475,8 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
         } else if (op.kind == OP_STEM0) {
             static const bool px_off = getenv("CF_STEM0_KIND") && atoi(getenv("CF_STEM0_KIND")) == 0;
             const bool px = dt == CF_BF16 && !px_off;                 // second-generation kernel (cf_stem0.hip)
-            op.geo.kind = px ? 1 : 0;
+            static const bool swz_off = getenv("CF_XCD_ORDER") && atoi(getenv("CF_XCD_ORDER")) == 0;
+            op.geo.kind = px ? (swz_off ? 1 : 3) : 0;                 // bit 1: XCD-aware tile order
             std::vector<char> w(px ? stem0px_wstem_bytes() : stem_packed_bytes(dt)), wp(stem0_proj_bytes(dt));
             std::vector<float> wd(px ? stem0px_wdw_dwords() : 9 * 32), lut(768);
             if (px) {
@@ -684,8 +685,8 @@ int ensure_topk_ws(cf_ctx* c, int K) {
     const size_t HW = (size_t)(c->H / 4) * (c->W / 4);
     if (!c->keys) HIPCHK(c, hipMalloc((void**)&c->keys, HW * c->max_batch * sizeof(unsigned long long)));
     if (!c->key_count) {
-        HIPCHK(c, hipMalloc((void**)&c->key_count, (size_t)c->max_batch * sizeof(int)));
-        HIPCHK(c, hipMemset(c->key_count, 0, (size_t)c->max_batch * sizeof(int)));       // the select kernel leaves it zero
+        HIPCHK(c, hipMalloc((void**)&c->key_count, (size_t)c->max_batch * kTopkCountStride * sizeof(int)));
+        HIPCHK(c, hipMemset(c->key_count, 0, (size_t)c->max_batch * kTopkCountStride * sizeof(int)));       // the select kernel leaves it zero
     }
     if (c->decK < K) {
         HIPCHK(c, hipStreamSynchronize(c->stream));           // a decode in flight may still write the old buffers

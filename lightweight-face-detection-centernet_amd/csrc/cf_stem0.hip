@@ -367,7 +367,9 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 31, h = lane >> 5;
     const int Ho = p.H >> 1, Wo = p.W >> 1;
-    const int ox0 = blockIdx.x * S0_TOW, oy0 = blockIdx.y * S0_TOH, b = blockIdx.z;
+    unsigned tbx = blockIdx.x, tby = blockIdx.y, tbz = blockIdx.z;
+    if (p.kind & 2) xcd_tile_order(tbx, tby, tbz);
+    const int ox0 = tbx * S0_TOW, oy0 = tby * S0_TOH, b = tbz;
 
     // ---- stage the normalised image patch
     const int iy0 = 2 * (oy0 - 1), ix0 = 2 * (ox0 - 1);
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
 hipError_t launch_stem0(hipStream_t s, int dtype, const Stem0Params& p) {
     if (p.B <= 0) return hipSuccess;
     const int Ho = p.H / 2, Wo = p.W / 2;
-    if (p.kind == 1) {
+    if (p.kind & 1) {
         if (dtype != 1) return hipErrorInvalidValue;
         dim3 grid((Wo + S0_TOW - 1) / S0_TOW, (Ho + S0_TOH - 1) / S0_TOH, p.B), blk(S0P_NT);
         set_kernel_tag("void cf::stem0_px_kernel<%d>(cf::Stem0Params)", p.in_format);

@@ -12,6 +12,7 @@
 // to the two-kernel path.
 #include "cf_common.h"
 #include "cf_kernels.h"
+#include <cstdlib>
 
 namespace cf {
 
@@ -31,7 +32,9 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
     __shared__ __attribute__((aligned(16))) char Wh[UH_WHB];                   // head weight fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
-    const int ox0 = blockIdx.x * UH_TW, oy0 = blockIdx.y * UH_TH, b = blockIdx.z;
+    unsigned tbx = blockIdx.x, tby = blockIdx.y, tbz = blockIdx.z;
+    if (p.xcd) xcd_tile_order(tbx, tby, tbz);       // the 3x3 halo rows and the half-resolution `low` rows are shared by neighbours
+    const int ox0 = tbx * UH_TW, oy0 = tby * UH_TH, b = tbz;
 
     // head weights -> LDS by DMA; lands under phase A, fenced by the barrier
     for (int c = wave; c < UH_WHB / 1024; c += 4)
@@ -134,7 +137,9 @@ hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p) {
     if (p.B <= 0) return hipSuccess;
     dim3 grid((p.w + UH_TW - 1) / UH_TW, (p.h + UH_TH - 1) / UH_TH, p.B), blk(256);
     set_kernel_tag("cf::uphead_kernel(cf::UpHeadParams)");
-    hipLaunchKernelGGL(uphead_kernel, grid, blk, 0, s, p);
+    static const bool xcd_off = getenv("CF_XCD_ORDER") && atoi(getenv("CF_XCD_ORDER")) == 0;
+    UpHeadParams q = p; q.xcd = xcd_off ? 0 : 1;
+    hipLaunchKernelGGL(uphead_kernel, grid, blk, 0, s, q);
     return hipGetLastError();
 }
 
