@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
         float a8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) a8[i] = 0.0f;
-        const CF_AS4 u32x8* wq = wtab + (size_t)(((q * NPARW + par) * (HC / 8) + c) * KS) * NT;
+        const CF_AS4 u32x8* wq = wtab + ((p.nw & 2) ? (size_t)0 : (size_t)(((q * NPARW + par) * (HC / 8) + c) * KS) * NT);   // bit 1: timing experiment (one hot table row)
         const char* eb = E + e_pix + c * 32;
         if constexpr (KS == 3) {
         // 3x3: all six tap-pair vectors of the chunk (48 SGPRs) in ONE batch.  Tap pairs (s_load) and tile
@@ -621,6 +621,12 @@ static const XdEntry kXdTable[] = {
     XD(0, 5, 2, 6, 32, 10, 20),     // 5.0   96 -> 576, 40x40 -> 20x20
     XD(0, 5, 1, 10, 32, 10, 20),    // 5.1  160 -> 960, 20x20
     XD(0, 3, 1, 10, 32, 10, 20),    // 6.0  160 -> 960, 20x20
+    XD(0, 5, 1, 4, 32, 10, 40),     // 4.0   64 -> 384, 40x40: full-width tiles (10x20 0.071, 20x20 0.067, 10x40 0.066, 20x40 0.083 ms)
+    XD(0, 5, 1, 6, 32, 10, 40),     // 4.1   96 -> 576, 40x40   (0.106 / 0.098 / 0.096 / 0.129)
+    XD(1, 5, 1, 4, 32, 20, 20),
+    XD(1, 5, 1, 6, 32, 20, 20),
+    XD(2, 5, 1, 4, 32, 10, 20),
+    XD(2, 5, 1, 6, 32, 10, 20),
     XD(1, 5, 2, 6, 32, 5, 20),
     XD(1, 5, 1, 10, 64, 10, 20),
     XD(1, 3, 1, 10, 64, 10, 20),
@@ -687,7 +693,8 @@ static hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
     // PMC traffic is already 1.0-1.13x algorithmic), so it stays off here (CF_XCD_ORDER=2 switches it on for A/B runs);
     // the stem and the up3+heads kernel, whose halo re-fetches across XCDs tripled the input traffic, use it
     static const bool xcd_on = getenv("CF_XCD_ORDER") && atoi(getenv("CF_XCD_ORDER")) == 2;
-    MbParams q = p; q.nw = xcd_on ? 1 : 0;
+    static const bool whack = getenv("CF_DW_WHACK") && atoi(getenv("CF_DW_WHACK")) == 1;     // timing experiment only: results invalid
+    MbParams q = p; q.nw = (xcd_on ? 1 : 0) | (whack ? 2 : 0);
     set_kernel_tag("void cf::mbconv_px_kernel<%d, %d, %d, %s, %d, %d, %d, %d, %d>(cf::MbParams)", KS, S, NBO, RESID ? "true" : "false", NW, JX, HC, TOH, TOW);
     hipLaunchKernelGGL(kfn, grid, blk, LDS, s, q);
     return hipGetLastError();

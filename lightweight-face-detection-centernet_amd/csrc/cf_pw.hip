@@ -335,16 +335,17 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
     const long long gx = (p.M + 127) / 128;
     // GEMM-heavy layers (no bias / IDAUp epilogue): share weight fragments through LDS
     static const int wl_env = getenv("CF_PW_WLDS") ? atoi(getenv("CF_PW_WLDS")) : -1;     // A/B: 0 off, N = force NBW
-    if (wl_env != 0 && !p.bias && !p.low && !p.ldy && p.K >= 64 && NB >= 4 && (p.act == 1 || p.act == 0)) {
+    if (wl_env != 0 && !p.bias && !p.low && !p.ldy && p.K >= 64 && NB >= 3 && (p.act == 1 || p.act == 0)) {
         (void)wl_env;                          // NBW = 4 measured best of {4,5,6,8} on every late layer
         static const int nst_env = getenv("CF_PW_NST") ? atoi(getenv("CF_PW_NST")) : 0;       // A/B: ring depth 2..4
         static const int nbw_env = getenv("CF_PW_NBW") ? atoi(getenv("CF_PW_NBW")) : 0;
-        const int nbw = nbw_env ? nbw_env : (NB % 5 == 0 ? 5 : 4);      // N = 160 / 320: five n-blocks per wave, activations read once / twice
+        const int nbw = nbw_env ? nbw_env : (NB == 3 ? 3 : (NB % 5 == 0 ? 5 : 4));      // N = 160 / 320: five n-blocks per wave, activations read once / twice; N = 96: three
         dim3 grid((unsigned)gx, (unsigned)((NB + nbw - 1) / nbw));
         // ring depth: 3-4 stages (<= 64 KB of LDS) when the grid is at most half a workgroup per CU (small batches: the
         // K chain's latency is the kernel time), 2 stages (more workgroups per CU) otherwise -- measured
         const int nst = nst_env ? nst_env : ((long long)grid.x * grid.y <= 128 ? (nbw == 5 ? 3 : 4) : 2);
         if (nbw == 5) return nst == 2 ? dispatch_wlds<T, 5, 2>(s, p, grid) : dispatch_wlds<T, 5, 3>(s, p, grid);
+        if (nbw == 3) return nst == 2 ? dispatch_wlds<T, 3, 2>(s, p, grid) : dispatch_wlds<T, 3, 4>(s, p, grid);
         switch (nst) {
             case 2: return dispatch_wlds<T, 4, 2>(s, p, grid);
             case 3: return dispatch_wlds<T, 4, 3>(s, p, grid);

@@ -159,6 +159,12 @@ void build_plan(cf_ctx* c) {
             if (li == 2 && i == n - 1) dst = S2;                 // x2 (:267)
             if (li == 4 && i == n - 1) dst = S4;                 // x4 (:269)
             MbGeom geo = mb_geometry(c->dtype, cin, hid, cout, k, s);
+            // Cout = 96 (layer4.0 / 4.1): three project accumulator blocks leave the fully fused kernel 2 waves per SIMD at
+            // 246 VGPRs and it runs at 0.47 of its own instruction-issue bound (profiles/r02b_valu_bound.md); expand + depthwise
+            // in one kernel (no accumulators: 6 waves per SIMD) + the LDS-weight GEMM for the project conv is faster although
+            // the depthwise output makes a round trip through HBM: 0.111 -> 0.095 ms and 0.166 -> 0.141 ms.  CF_SPLIT_WIDE=0: A/B.
+            static const bool fuse_wide = getenv("CF_SPLIT_WIDE") && atoi(getenv("CF_SPLIT_WIDE")) == 0;
+            if (!fuse_wide && c->dtype == CF_BF16 && cout > 64 && geo.kind == 1) geo.ok = false;
             if (t != 1 && geo.ok && !(c->flags & CF_FLAG_NO_FUSE)) {
                 // fused expand -> dw -> project (cf_mbconv.hip): one launch, expanded tensor stays in LDS
                 Op m; m.kind = OP_MB; m.name = std::string(pre) + ".mbconv"; m.in = cur; m.out = dst;

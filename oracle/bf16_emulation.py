@@ -19,7 +19,7 @@ What it is: the fp32 oracle of ``centerface_oracle.py`` (the reference's network
   depthwise accumulate                   fp32 (``v_dot2c_f32_f16``)
   project operand (fused blocks)         bf16 of  d / (1 + 2^d)  (d = pre-scaled depthwise sum)
   project weights (fused blocks)         bf16(-ln(2) * w)
-  layer5.0-6.0 depthwise output (HBM)    bf16 of  (d / (1 + 2^d)) * -ln(2); project weights plain bf16(w)
+  layer4.0-6.0 depthwise output (HBM)    bf16 of  (d / (1 + 2^d)) * -ln(2); project weights plain bf16(w)
   conv_last / IDAUp 1x1 weights          bf16(float(w * bn_scale)), bn_scale and shift folded in float64
   IDAUp deconv taps, all biases          fp32
   head weights                           collapsed (W = w1 . w0 in float64) -> float -> bf16; bias fp32
@@ -132,7 +132,7 @@ def dw_only(e_scaled, wd, k, s):
 
 
 def mbconv_fused(x, we, wd, wp, k, s, residual):
-    """MBConvBlock.forward (model/centernet.py:89-140), fused kernel mbconv_px_kernel (layer1.0-4.1)."""
+    """MBConvBlock.forward (model/centernet.py:89-140), fused kernel mbconv_px_kernel (layer1.0-3.1)."""
     y = expand_dw(x, we, wd, k, s, out_scaled=True)
     wpq = q_bf16(_f32mul(NEG_LN2, wp)).reshape(wp.shape[0], -1, 1, 1)
     o = F.conv2d(y, wpq)
@@ -142,7 +142,7 @@ def mbconv_fused(x, we, wd, wp, k, s, residual):
 
 
 def mbconv_split(x, we, wd, wp, k, s, residual):
-    """Same block as expdw_px_kernel + pw_wlds_kernel (layer5.0, 5.1, 6.0): depthwise output in HBM."""
+    """Same block as expdw_px_kernel + pw_wlds_kernel (layer4.0 - 6.0): depthwise output in HBM."""
     y = expand_dw(x, we, wd, k, s, out_scaled=False)
     wpq = q_bf16(_t(wp).to(torch.float32)).reshape(wp.shape[0], -1, 1, 1)
     o = F.conv2d(y, wpq)
@@ -217,7 +217,7 @@ def heads(x, sd):
     return OrderedDict((("hm", out[:, 0:1]), ("wh", out[:, 1:3]), ("lm", out[:, 3:13]), ("reg", out[:, 13:15])))
 
 
-SPLIT_BLOCKS = ("layer5.0", "layer5.1", "layer6.0")
+SPLIT_BLOCKS = ("layer4.0", "layer4.1", "layer5.0", "layer5.1", "layer6.0")   # expand+dw kernel + project GEMM in the engine
 
 
 @torch.no_grad()

@@ -77,7 +77,7 @@ def _w(prefix):
 def test_production_mbconv_instances_vs_emulation(blk):
     """Every MBConv template instance the bf16 engine launches at 640x640 (the op-level entry points go through
     the same geometry tables as the engine: ``mbconv_px_kernel<3,2,1,false,4,1,32,8,16>`` for layer1.0, ...,
-    ``expdw_px_kernel`` + ``pw_wlds_kernel`` for layer5.0-6.0), at its production map size with the production
+    ``expdw_px_kernel`` + ``pw_wlds_kernel`` for layer4.0-6.0), at its production map size with the production
     weights, B = 2, against the emulation at one bf16 ulp + flip noise."""
     prefix, cin, cout, k, s, h = blk
     rng = np.random.default_rng(sum(ord(ch) for ch in prefix))
@@ -98,7 +98,7 @@ def test_production_mbconv_instances_vs_emulation(blk):
 @pytest.mark.parametrize("prefix", E.SPLIT_BLOCKS)
 def test_production_project_gemm_at_batch64(prefix):
     """``pw_wlds_kernel`` picks its LDS ring depth from the grid size, so the B = 64 instance (2 stages) differs
-    from the B = 2 one (3-4 stages): the late project GEMMs at the benchmark's batch, 20x20 maps."""
+    from the B = 2 one (3-4 stages): the late project GEMMs at the benchmark's batch, 40x40 / 20x20 maps."""
     _, cin, cout, k, s, h = [b for b in BLOCKS if b[0] == prefix][0]
     ho = h // s
     rng = np.random.default_rng(cout)
@@ -155,7 +155,8 @@ def test_bf16_engine_layer_by_layer_teacher_forced(size, B):
     for prefix in E.SPLIT_BLOCKS:
         _, cin, cout, k, s, _ = [b for b in BLOCKS if b[0] == prefix][0]
         we, wd, wp = _w(prefix)
-        prev = "layer4.1" if prefix == "layer5.0" else ("layer5.0" if prefix == "layer5.1" else "layer5.1")
+        names = [b[0] for b in BLOCKS]
+        prev = names[names.index(prefix) - 1]
         emu = E.expand_dw(torch.from_numpy(g[prev]), we, wd, k, s, out_scaled=False)
         _assert_close(rec[prefix + ".expand+dw"], emu, prefix + ".expand+dw")
     # and the full forward (graph replay path) reproduces the traced heads bit for bit

@@ -15,14 +15,25 @@ if [ "${SKIP_TESTS:-0}" != 1 ]; then
 fi
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 600 "$OUT/bench.json"
 timeout 300 python tools/profile_ops.py --json "$OUT/ops.json" > "$OUT/ops.txt" 2>&1
-timeout 300 python tools/profile_ops.py --dtype fp32 --batch 16 > "$OUT/ops_fp32_b16.txt" 2>&1
+timeout 300 python tools/profile_ops.py --dtype fp32 --batch 64 > "$OUT/ops_fp32_b64.txt" 2>&1
+# BASELINE configs[4] per-GPU shards (1280x1280, top-1000) and the configs[3] VGA bucket mix
+timeout 300 python tools/profile_ops.py --size 1280 --topk 1000 --batch 4 --json "$OUT/ops_1280_b4.json" > "$OUT/ops_1280_b4.txt" 2>&1
+timeout 300 python tools/profile_ops.py --size 1280 --topk 1000 --batch 32 --json "$OUT/ops_1280_b32.json" > "$OUT/ops_1280_b32.txt" 2>&1
+timeout 300 python bench.py --size 1280 --topk 1000 --batch 4 --no-cpu-baseline --no-extras > "$OUT/bench_1280_b4.json" 2>> "$OUT/bench.err"
+timeout 300 python bench.py --size 1280 --topk 1000 --batch 32 --no-cpu-baseline --no-extras > "$OUT/bench_1280_b32.json" 2>> "$OUT/bench.err"
+timeout 300 python tools/vga_buckets_bench.py > "$OUT/vga_buckets.json" 2>> "$OUT/bench.err"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k" -o k -- \
-    python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/prof_k.log" 2>&1
+    python "$ROOT/bench.py" --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras > "$OUT/prof_k.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k1280" -o k -- \
+    python "$ROOT/bench.py" --size 1280 --topk 1000 --batch 4 --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras > "$OUT/prof_k1280.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch" -o f -- \
     python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/prof_write" -o w -- \
     python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_write.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAVES \
+    --kernel-trace --output-format csv -d "$OUT/prof_inst" -o i -- \
+    python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_inst.log" 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM \
     --kernel-trace --output-format csv -d "$OUT/prof_sq" -o s -- \
     python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_sq.log" 2>&1
