@@ -58,6 +58,26 @@ int main(int argc, char** argv) {
     for (int b = 0; b < B; ++b)
         printf("image %d: best score %.4f at cell %lld, box [%.2f %.2f %.2f %.2f] (map units)\n", b, dets[(b * K) * 6 + 4],
                (long long)inds[b * K], dets[(b * K) * 6], dets[(b * K) * 6 + 1], dets[(b * K) * 6 + 2], dets[(b * K) * 6 + 3]);
+    /* Multi-GPU (one process or thread per GPU, batch sharded by rank): the only exchange is the all-gather of the final
+     * records.  Rank 0 creates the 128-byte id and ships it to the other ranks by any channel (file, socket, MPI ...);
+     * every rank then calls cf_comm_create(ctx, rank, world, id, &comm) and, after each cf_forward on its shard,
+     * cf_gather_topk, which returns the records of ALL ranks in rank-major (= unsharded batch) order.  Shown here with
+     * world = 1 (`./detect weights.bin H W batch gather`). */
+    if (argc > 5 && strcmp(argv[5], "gather") == 0) {
+        char id[CF_COMM_ID_BYTES];
+        cf_comm* comm = NULL;
+        const int world = 1, rank = 0;
+        float* rec = (float*)malloc((size_t)world * B * K * 16 * sizeof(float));
+        CHECK(NULL, cf_comm_unique_id(id, (int)sizeof id));
+        CHECK(ctx, cf_comm_create(ctx, rank, world, id, &comm));
+        CHECK(ctx, cf_forward(ctx, img, CF_IN_U8_HWC_BGR, 0, B));
+        CHECK(ctx, cf_gather_topk(ctx, comm, K, 1, rec, 0));
+        for (int b = 0; b < world * B; ++b)
+            if (rec[(size_t)b * K * 16 + 4] != dets[(size_t)b * K * 6 + 4]) { fprintf(stderr, "gathered record differs\n"); return 1; }
+        printf("gathered %d x %d records over RCCL (world %d)\n", world * B, K, world);
+        CHECK(ctx, cf_comm_destroy(comm));
+        free(rec);
+    }
     CHECK(ctx, cf_destroy(ctx));
     return 0;
 }
