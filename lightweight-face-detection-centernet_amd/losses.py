@@ -1,6 +1,7 @@
 """Training-side pieces that share the detector's tensors: forward evaluation of the
 CenterNet detection loss and the target encoder, on the GPU through the C ABI.
 
+    to_output_map(boxes, lms, c, s, out_w, out_h, ...)      dataset/dataset.py:146,160-179: flip + affine into the output map
     encode_targets(boxes, lms, counts, h, w, max_objs)      dataset/dataset.py:160-217 + utils/image.py:95-141
     ctdet_loss(heads, batch, ...)                           model/losses.py:347-374 on explicit head maps
     Engine-level: ctdet_loss_last_forward(engine, batch)    the same on the head maps of the last forward
@@ -27,6 +28,32 @@ def _targets(batch, B):
     if t["ind"].shape != (B, M) or t["wh"].shape != (B, M, 2) or t["reg"].shape != (B, M, 2) or t["lm"].shape != (B, M, 10):
         raise ValueError("target shapes must be [B,M], [B,M,2], [B,M,2], [B,M,10]")
     return t, M
+
+
+def to_output_map(boxes, lms, center, scale, output_w, output_h, rot=0, flipped=False, width=None):
+    """The per-object coordinate step in front of the target encoder (dataset/dataset.py:146,160-179): optional
+    horizontal flip (:164-172, incl. the left/right landmark swap), then ``affine_transform`` of both box corners and
+    the five landmark points with ``get_affine_transform(c, s, rot, [output_w, output_h])``.  boxes [n,4], lms [n,10]
+    (lms[k][0] < 0 = no landmarks) in source-image pixels -> float32 copies in output-map coordinates, ready for
+    ``encode_targets``.  Host numpy (dataset preparation, as in the reference)."""
+    from .post_process import get_affine_transform, affine_transform
+    t = get_affine_transform(center, scale, rot, [output_w, output_h])
+    boxes = np.array(boxes, np.float32).reshape(-1, 4).copy()
+    lms = np.array(lms, np.float32).reshape(-1, 10).copy()
+    for k in range(len(boxes)):
+        bbox, lm = boxes[k], lms[k]
+        if flipped:
+            bbox[[0, 2]] = width - bbox[[2, 0]] - 1
+            if lm[0] >= 0:
+                lm[0::2] = width - lm[0::2] - 1
+                tmp = lm.copy()
+                lm[0:2], lm[2:4], lm[6:8], lm[8:10] = tmp[2:4], tmp[0:2], tmp[8:10], tmp[6:8]
+        bbox[:2] = affine_transform(bbox[:2], t)
+        bbox[2:] = affine_transform(bbox[2:], t)
+        if lm[0] >= 0:
+            for j in range(5):
+                lm[2 * j:2 * j + 2] = affine_transform(lm[2 * j:2 * j + 2], t)
+    return boxes, lms
 
 
 def encode_targets(boxes, lms, counts, h, w, device=0):

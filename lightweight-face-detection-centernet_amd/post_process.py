@@ -15,21 +15,43 @@ import numpy as np
 from . import _lib
 
 
+def _affine_general(center, scale, rot, output_size, shift, inv):
+    """utils/image.py:27-60 in full (rotation, shift): the three point pairs are built in float32 exactly as the
+    reference's numpy code does, the 2x3 map is solved in float64 where the reference calls cv2.getAffineTransform."""
+    scale = np.asarray(scale, np.float32)
+    src_w, (dst_w, dst_h) = scale[0], output_size
+    rot_rad = np.pi * rot / 180
+    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
+    sp = [0, src_w * -0.5]
+    src_dir = [sp[0] * cs - sp[1] * sn, sp[0] * sn + sp[1] * cs]                 # get_dir, :74-81
+    dst_dir = np.array([0, dst_w * -0.5], np.float32)
+    src, dst = np.zeros((3, 2), np.float32), np.zeros((3, 2), np.float32)
+    src[0, :] = center + scale * shift
+    src[1, :] = center + src_dir + scale * shift
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + dst_dir
+    for pts in (src, dst):                                                        # get_3rd_point, :69-71
+        d = pts[0] - pts[1]
+        pts[2] = pts[1] + np.array([-d[1], d[0]], np.float32)
+    a, b = (dst, src) if inv else (src, dst)
+    A = np.concatenate([a.astype(np.float64), np.ones((3, 1))], axis=1)
+    return np.linalg.solve(A, b.astype(np.float64)).T
+
+
 def get_affine_transform(center, scale, rot, output_size, shift=None, inv=0):
-    """Same signature as utils/image.py:27-60.  Only rot == 0, shift == 0 (all the detection path
-    uses) is supported; returns the 2x3 float64 matrix."""
-    if rot != 0 or (shift is not None and np.any(np.asarray(shift) != 0)):
-        raise NotImplementedError("only rot=0, shift=0 is on the detection path")
+    """Same signature as utils/image.py:27-60; returns the 2x3 float64 matrix.  rot == 0, shift == 0, inv == 1 (all the
+    detection path uses, utils/post_process.py:83-90) comes from the library -- the very matrix the decode kernel
+    applies; rotation / shift / the forward direction (dataset side, dataset/dataset.py:146) are host float64."""
     if not isinstance(scale, (np.ndarray, list, tuple)):
         scale = np.array([scale, scale], dtype=np.float32)
-    t = np.empty(6, np.float64)
-    _lib.check(_lib.lib().cf_affine_from_center_scale(float(center[0]), float(center[1]), float(scale[0]),
-                                                      int(output_size[0]), int(output_size[1]), _lib.ptr(t)))
-    m = t.reshape(2, 3)
-    if inv:
-        return m
-    full = np.vstack([m, [0.0, 0.0, 1.0]])
-    return np.linalg.inv(full)[:2]
+    shift0 = shift is None or not np.any(np.asarray(shift) != 0)
+    if rot == 0 and shift0 and inv:
+        t = np.empty(6, np.float64)
+        _lib.check(_lib.lib().cf_affine_from_center_scale(float(center[0]), float(center[1]), float(scale[0]),
+                                                          int(output_size[0]), int(output_size[1]), _lib.ptr(t)))
+        return t.reshape(2, 3)
+    shift = np.zeros(2, np.float32) if shift is None else np.asarray(shift, np.float32)
+    return _affine_general(np.asarray(center, np.float32), scale, rot, output_size, shift, inv)
 
 
 def affine_transform(pt, t):

@@ -520,6 +520,35 @@ def encode_targets(boxes, lms, output_h, output_w, max_objs):
     return dict(hm=hm, wh=wh, reg=reg, ind=ind, reg_mask=reg_mask, landmarks=landmarks, lm_ind=lm_ind, lm_mask=lm_mask)
 
 
+def dataset_to_output_map(bboxes, lms, c, s, output_w, output_h, flipped=False, width=None):
+    """dataset/dataset.py:146,160-179 restated: flip (:164-172), then affine_transform of the box corners and the five
+    landmark points with get_affine_transform(c, s, 0, [output_w, output_h]) (cv2.getAffineTransform -> float64 solve)."""
+    trans_output = get_affine_transform(c, s, 0, [output_w, output_h])
+    out_b, out_l = [], []
+    for k in range(len(bboxes)):
+        bbox = np.array(bboxes[k], np.float32).copy()
+        lm = np.array(lms[k], np.float32).copy()
+        if flipped:
+            bbox[[0, 2]] = width - bbox[[2, 0]] - 1
+            if lm[0] >= 0:
+                lm[0::2] = width - lm[0::2] - 1
+                l_tmp = lm.copy()
+                lm[0:2] = l_tmp[2:4]
+                lm[2:4] = l_tmp[0:2]
+                lm[6:8] = l_tmp[8:10]
+                lm[8:10] = l_tmp[6:8]
+        bbox[:2] = affine_transform(bbox[:2], trans_output)
+        bbox[2:] = affine_transform(bbox[2:], trans_output)
+        if lm[0] >= 0:
+            lm[:2] = affine_transform(lm[:2], trans_output)
+            lm[2:4] = affine_transform(lm[2:4], trans_output)
+            lm[4:6] = affine_transform(lm[4:6], trans_output)
+            lm[6:8] = affine_transform(lm[6:8], trans_output)
+            lm[8:10] = affine_transform(lm[8:10], trans_output)
+        out_b.append(bbox); out_l.append(lm)
+    return np.array(out_b, np.float32).reshape(-1, 4), np.array(out_l, np.float32).reshape(-1, 10)
+
+
 def neg_loss(pred, gt):
     """Modified focal loss, model/losses.py:142-167."""
     pos_inds = gt.eq(1).float()

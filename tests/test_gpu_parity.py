@@ -801,6 +801,35 @@ def test_target_encoder_kernel_vs_reference_goldens(golden):
         np.testing.assert_allclose(t["hm"][b], r["hm"], rtol=2e-7, atol=1e-9)
 
 
+def test_dataset_affine_and_rotated_transform_vs_oracle():
+    """dataset/dataset.py:146,160-179 (boxes / landmarks -> output-map coordinates, incl. the flip) in front of the
+    target encoder, and get_affine_transform with rotation and shift (utils/image.py:27-60), against the oracle's
+    restatement (cv2.getAffineTransform is replaced by a float64 solve on both sides; pinned analytically in
+    test_oracle_vs_golden.py::test_post_process_affine_analytic)."""
+    from centerface_amd import losses, post_process as pp
+    rng = np.random.default_rng(9)
+    boxes = np.sort(rng.uniform(0, 600, (7, 2, 2)), axis=1).transpose(0, 1, 2).reshape(7, 4).astype(np.float32)
+    boxes = boxes[:, [0, 1, 2, 3]]
+    lms = rng.uniform(0, 600, (7, 10)).astype(np.float32)
+    lms[2, 0] = -1.0                                                    # no landmarks on this face
+    c, s = np.array([311.5, 287.0], np.float32), np.float32(731.0)
+    for flipped in (False, True):
+        gb, gl = losses.to_output_map(boxes, lms, c, s, 160, 160, flipped=flipped, width=640)
+        rb, rl = O.dataset_to_output_map(boxes, lms, c, s, 160, 160, flipped=flipped, width=640)
+        assert np.array_equal(gb, rb) and np.array_equal(gl, rl), flipped
+    enc = losses.encode_targets(gb[None], gl[None], np.array([7], np.int32), 160, 160)
+    ref = O.encode_targets(rb, rl, 160, 160, 7)
+    assert np.array_equal(enc["ind"][0], ref["ind"]) and np.array_equal(enc["hm"][0], ref["hm"])
+    for rot, shift, inv in ((0, None, 0), (30, None, 1), (-75.5, np.array([0.1, -0.2], np.float32), 0), (180, None, 1)):
+        kw = {} if shift is None else {"shift": shift}
+        got = pp.get_affine_transform(c, s, rot, [160, 120], inv=inv, **kw)
+        want = O.get_affine_transform(c, s, rot, [160, 120], inv=inv, **kw)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    # rot = 0 inverse: the library's matrix (the one the decode kernel applies) equals the general host solve
+    np.testing.assert_allclose(pp.get_affine_transform(c, s, 0, [160, 120], inv=1), O.get_affine_transform(c, s, 0, [160, 120], inv=1),
+                               rtol=0, atol=1e-9)
+
+
 def test_ctdet_loss_kernel_vs_reference_goldens(golden):
     """cf_op_ctdet_loss against model/losses.py CtdetLoss outputs (focal + 3 x RegL1), incl. the num_pos == 0 branch;
     fp32 terms, double sums: 2e-5 relative."""
