@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcenterface_hip.so")
+# CF_LIB: load another build of the same library (A/B runs of kernel variants: tools/ab_build.sh); default = the in-tree build
+LIB_PATH = os.environ.get("CF_LIB") or os.path.join(_HERE, "libcenterface_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CF_OK = 0
