@@ -81,6 +81,17 @@ __device__ __forceinline__ f32x2 swish2_prescaled(f32x2 u) {
 }
 static constexpr float kNegLog2e = -1.44269504088896341f, kNegLn2 = -0.69314718055994531f;
 
+// first tap of an accumulation: acc = w . e (+ 0) -- v_dot2_f32_f16 with an inline-constant addend instead of
+// v_mov_b32 acc, 0 followed by the accumulating v_dot2c
+template <bool FIRST> __device__ __forceinline__ void dot2s(float& acc, uint32_t w, uint32_t e) {
+    if constexpr (FIRST) acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(hf2, w), __builtin_bit_cast(hf2, e), 0.0f, false);
+    else dot2c(acc, w, e);
+}
+#define CF_DOT8(FIRST, A, W, E0, E1)                                                                     \
+    dot2s<FIRST>(A[0], W[0], E0.x); dot2s<FIRST>(A[1], W[1], E0.y); dot2s<FIRST>(A[2], W[2], E0.z);      \
+    dot2s<FIRST>(A[3], W[3], E0.w); dot2s<FIRST>(A[4], W[4], E1.x); dot2s<FIRST>(A[5], W[5], E1.y);      \
+    dot2s<FIRST>(A[6], W[6], E1.z); dot2s<FIRST>(A[7], W[7], E1.w)
+
 // ---------------------------------------------------------------- geometry shared by host and device
 template <int KS, int S, int HC, int TOH, int TOW, int JX, int NW>
 struct Px {
@@ -255,8 +266,6 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     // depthwise + Swish for hidden chunk c (8 channels) of chunk group q on this lane's pixel -> bf16x8
     auto dw_chunk = [&](int q, int c) -> u32x4 {
         float a8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a8[i] = 0.0f;
         const CF_AS4 u32x8* wq = wtab + ((p.nw & 2) ? (size_t)0 : (size_t)(((q * NPARW + par) * (HC / 8) + c) * KS) * NT);   // bit 1: timing experiment (one hot table row)
         const char* eb = E + e_pix + c * 32;
         if constexpr (KS == 3) {
@@ -285,10 +294,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const u32x8 wv = wa[ky * NT + t];
-                dot2c(a8[0], wv[0], ec[t][0].x); dot2c(a8[1], wv[1], ec[t][0].y);
-                dot2c(a8[2], wv[2], ec[t][0].z); dot2c(a8[3], wv[3], ec[t][0].w);
-                dot2c(a8[4], wv[4], ec[t][1].x); dot2c(a8[5], wv[5], ec[t][1].y);
-                dot2c(a8[6], wv[6], ec[t][1].z); dot2c(a8[7], wv[7], ec[t][1].w);
+                if (ky == 0 && t == 0) { CF_DOT8(true, a8, wv, ec[t][0], ec[t][1]); }
+                else { CF_DOT8(false, a8, wv, ec[t][0], ec[t][1]); }
             }
         }
         } else {
@@ -311,10 +318,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                dot2c(a8[0], wc[t][0], ec[t][0].x); dot2c(a8[1], wc[t][1], ec[t][0].y);
-                dot2c(a8[2], wc[t][2], ec[t][0].z); dot2c(a8[3], wc[t][3], ec[t][0].w);
-                dot2c(a8[4], wc[t][4], ec[t][1].x); dot2c(a8[5], wc[t][5], ec[t][1].y);
-                dot2c(a8[6], wc[t][6], ec[t][1].z); dot2c(a8[7], wc[t][7], ec[t][1].w);
+                if (ky == 0 && t == 0) { CF_DOT8(true, a8, wc[t], ec[t][0], ec[t][1]); }
+                else { CF_DOT8(false, a8, wc[t], ec[t][0], ec[t][1]); }
             }
         }
         }
@@ -554,8 +559,6 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
 #pragma unroll
     for (int c = 0; c < HC / 8; ++c) {
         float a8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a8[i] = 0.0f;
         const CF_AS4 u32x8* wq = wtab + (size_t)(((grp * NPARW + par) * (HC / 8) + c) * KS) * NT;
         const char* eb = eb0 + c * 32;
         u32x8 wn[NT]; u32x4 en[NT][2];
@@ -575,10 +578,8 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                dot2c(a8[0], wc[t][0], ec[t][0].x); dot2c(a8[1], wc[t][1], ec[t][0].y);
-                dot2c(a8[2], wc[t][2], ec[t][0].z); dot2c(a8[3], wc[t][3], ec[t][0].w);
-                dot2c(a8[4], wc[t][4], ec[t][1].x); dot2c(a8[5], wc[t][5], ec[t][1].y);
-                dot2c(a8[6], wc[t][6], ec[t][1].z); dot2c(a8[7], wc[t][7], ec[t][1].w);
+                if (ky == 0 && t == 0) { CF_DOT8(true, a8, wc[t], ec[t][0], ec[t][1]); }
+                else { CF_DOT8(false, a8, wc[t], ec[t][0], ec[t][1]); }
             }
         }
         // a8 = -log2(e) * depthwise output -> swish, with the leftover -log2(e) taken out again
