@@ -67,10 +67,10 @@ def main():
     with open(os.path.join(out, "traffic_%s.json" % a.tag), "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
     lines = ["# rocprofv3 summary `%s`" % a.tag, "",
-             "Note: `peak_topk_kernel` runs on the context's second stream underneath the next forward (device-output "
-             "decode in bench.py), so its duration here is stretched by sharing the chip; timed alone it is ~0.10 ms "
-             "(per-launch table below).", "",
-             "Source: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline` "
+             "Note: the decode kernels (`peak_collect_kernel`, `topk_select_kernel`) run on the context's second stream "
+             "underneath the next forward (device-output decode in bench.py), so their durations here are stretched by "
+             "sharing the chip; timed alone they are in the per-launch table below.", "",
+             "Source: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras` "
              "(kernel durations) and two `--pmc` passes over `tools/profile_ops.py` (FETCH_SIZE, WRITE_SIZE; "
              "read side doubled per the gfx950 note in MI355X_MICROARCH.md).", "",
              "| kernel | calls | avg us | % GPU time | HBM MB/launch (PMC) |", "|---|---:|---:|---:|---:|"]
