@@ -916,3 +916,66 @@ def test_bf16_forward_is_bit_reproducible():
         ref = ref or cur
         assert cur == ref, it
     e.close()
+
+
+# ----------------------------------------------------------------------------- round-2 hardening
+def test_threshold_decode_takes_any_candidate_count_and_reports_truncation():
+    """The reference's decode handles any number of cells above the threshold (centerface.py:78-79).  An early-training
+    heat map (hm bias -1.79 -> sigmoid 0.143) with a low threshold puts most of a 160x160 map above it: the candidate
+    workspace starts at 4096 per image and must grow (one retry) instead of failing with CF_EOVERFLOW; more survivors
+    than `max_out` rows are reported through counts (the Python host then retries with enough rows)."""
+    rng = np.random.default_rng(77)
+    B, h, w = 2, 160, 160
+    hm = np.clip(0.143 + 0.05 * rng.standard_normal((B, 1, h, w)), 1e-4, 1 - 1e-4).astype(np.float32)   # ~80 % of 25600 cells > 0.1
+    wh = rng.uniform(0.5, 3.0, (B, 2, h, w)).astype(np.float32)                                          # small boxes: little suppression
+    reg = rng.uniform(0, 1, (B, 2, h, w)).astype(np.float32)
+    from centerface_amd import eval_widerface as ew
+    for b in range(B):
+        got = ew.decode(hm[b], wh[b], reg[b], None, (640, 640), threshold=0.1, nms_thresh=0.3)
+        ref = O.decode_d2(hm[b], wh[b], reg[b], (640, 640), threshold=0.1)
+        assert len(ref) > 4096, len(ref)                                     # beyond the initial capacity AND the initial max_out
+        assert np.array_equal(np.asarray(got, np.float32), np.asarray(ref, np.float32))
+    # raw C ABI: truncation is visible in counts
+    import ctypes as C
+    L = cfa._lib.lib()
+    dets = np.empty((1, 100, 5), np.float32); cnt = np.zeros(1, np.int32)
+    rc = L.cf_op_decode_threshold_ex(0, 1, cfa._lib.ptr(hm[:1]), cfa._lib.ptr(wh[:1]), cfa._lib.ptr(reg[:1]), None, 1, h, w, 640, 640,
+                                     C.c_float(0.1), C.c_float(0.3), 100, cfa._lib.ptr(dets), None, cfa._lib.ptr(cnt))
+    assert rc == 0 and cnt[0] == len(O.decode_d2(hm[0], wh[0], reg[0], (640, 640), threshold=0.1)) > 100
+    assert np.array_equal(dets[0], np.asarray(O.decode_d2(hm[0], wh[0], reg[0], (640, 640), threshold=0.1), np.float32)[:100])
+
+
+def test_stream_and_buffer_hazards_between_entry_points():
+    """(1) forward_resized followed by a host-input forward WITHOUT a sync in between: the resize writes a dedicated
+    buffer, so the second call's H2D copy cannot overwrite what the first forward's stem still reads.  (2) A
+    device-output top-K decode (decode stream) followed by a host-output decode (main stream): they share the key
+    list, the second must wait for the first."""
+    import torch
+    rng = np.random.default_rng(3)
+    H, W, B = 160, 224, 4
+    small = rng.integers(0, 256, (B, 97, 131, 3), dtype=np.uint8)
+    full = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    eng = cfa.Engine(H, W, max_batch=B, dtype="bf16")
+    ref_eng = cfa.Engine(H, W, max_batch=B, dtype="bf16")
+    ref_eng.forward_resized_enqueue(small); want_small = ref_eng.heads()
+    ref_eng.forward_enqueue(full); want_full = ref_eng.heads()
+    for _ in range(3):
+        eng.forward_resized_enqueue(small)
+        d_small = torch.empty((B, 20, 6), dtype=torch.float32, device="cuda")
+        eng.decode_topk_device(20, d_small.data_ptr())                          # decode stream, asynchronous
+        eng.forward_enqueue(full)                                               # no sync: H2D on the copy stream
+        got_full = eng.heads()
+        for k in ("hm", "wh", "lm", "reg"):
+            assert np.array_equal(got_full[k], want_full[k]), k
+        eng.synchronize()
+        ref_eng.forward_resized_enqueue(small)
+        assert np.array_equal(d_small.cpu().numpy(), ref_eng.decode_topk(20)[0])
+    # (2) same forward decoded twice, back to back, through both streams
+    eng.forward_enqueue(full)
+    d_dev = torch.empty((B, 50, 6), dtype=torch.float32, device="cuda")
+    for _ in range(4):
+        eng.decode_topk_device(50, d_dev.data_ptr())
+        d_host = eng.decode_topk(50)[0]
+        eng.synchronize()
+        assert np.array_equal(d_dev.cpu().numpy(), d_host)
+    eng.close(); ref_eng.close()
