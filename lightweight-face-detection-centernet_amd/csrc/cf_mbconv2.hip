@@ -692,7 +692,7 @@ static hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
     dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
     // XCD-aware tile order: measured neutral-to-slower on these VALU-bound kernels (layer1.0 0.234 -> 0.237-0.244 ms; their
     // PMC traffic is already 1.0-1.13x algorithmic), so it stays off here (CF_XCD_ORDER=2 switches it on for A/B runs);
-    // the stem and the up3+heads kernel, whose halo re-fetches across XCDs tripled the input traffic, use it
+    // the stem and the up3+heads kernel take it with CF_XCD_ORDER=1 (it removes their cross-XCD halo re-fetches, not time)
     static const bool xcd_on = getenv("CF_XCD_ORDER") && atoi(getenv("CF_XCD_ORDER")) == 2;
     static const bool whack = getenv("CF_DW_WHACK") && atoi(getenv("CF_DW_WHACK")) == 1;     // timing experiment only: results invalid
     MbParams q = p; q.nw = (xcd_on ? 1 : 0) | (whack ? 2 : 0);
