@@ -214,6 +214,10 @@ int cf_get_streams(cf_ctx* ctx, void** main_stream, void** decode_stream);
 /* hipGraph replay state: number of captured forward graphs held by the context, and how many
  * (input, format, batch) keys could not be captured and run as eager launches instead. */
 int cf_graph_stats(cf_ctx* ctx, int* n_graphs, int* n_uncapturable);
+/* page-locked host memory: a batch staged here is copied by DMA, asynchronously, underneath the previous forward
+ * (cf_forward from pageable memory stages through the driver and blocks the caller for the copy) */
+int cf_host_alloc(cf_ctx* ctx, uint64_t bytes, void** hptr);
+int cf_host_free(cf_ctx* ctx, void* hptr);
 /* device memory helpers so a host language without a GPU allocator can keep inputs resident */
 int cf_device_alloc(cf_ctx* ctx, uint64_t bytes, void** dptr);
 int cf_device_free(cf_ctx* ctx, void* dptr);

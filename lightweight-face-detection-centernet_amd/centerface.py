@@ -55,6 +55,10 @@ class Engine(object):
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
+            self._L.cf_synchronize(self._h)
+            for p in getattr(self, "_pinned", []):
+                self._L.cf_host_free(self._h, p)
+            self._pinned = []
             self._L.cf_destroy(self._h)
             self._h = None
 
@@ -248,6 +252,18 @@ class Engine(object):
         self._chk(self._L.cf_graph_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def pinned_array(self, shape, dtype=np.uint8):
+        """A numpy array in page-locked host memory (cf_host_alloc): forward_enqueue / forward_resized_enqueue from it
+        are asynchronous DMA copies.  Freed with the engine (close)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self._L.cf_host_alloc(self._h, max(n, 1), C.byref(p)))
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(p)
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def device_alloc(self, nbytes):
         p = C.c_void_p()
         self._chk(self._L.cf_device_alloc(self._h, int(nbytes), C.byref(p)))
@@ -285,17 +301,45 @@ class CenterFace(object):
         scale_h, scale_w = img_h_new / h, img_w_new / w
         return img_h_new, img_w_new, scale_h, scale_w
 
+    @staticmethod
+    def _floordiv(a, scale):
+        """``a // scale`` for a float32 array and a Python float exactly as numpy evaluates it (float32 operands, result the
+        mathematically exact floor of the quotient), computed as floor of the float64 quotient: two float32 values whose
+        ratio is not an integer differ from it by far more than a double's rounding, so the results are identical
+        (tests/test_abi.py::test_fast_floor_division_equals_numpy_floor_divide, adversarial near-multiples included) --
+        and numpy's own float32 floor_divide (an fmod per element) is 12x slower, which made this rescale half of the
+        host time of a VGA-bucket batch."""
+        return np.floor(a.astype(np.float64) / np.float64(np.float32(scale))).astype(np.float32)
+
     def _postprocess(self, dets, lms):
         # centerface.py:55-62: floor-division rescale, empty -> [0,5] / [0,10]
         if len(dets) > 0:
-            dets[:, 0:4:2], dets[:, 1:4:2] = dets[:, 0:4:2] // self.scale_w, dets[:, 1:4:2] // self.scale_h
+            dets[:, 0:4:2], dets[:, 1:4:2] = self._floordiv(dets[:, 0:4:2], self.scale_w), self._floordiv(dets[:, 1:4:2], self.scale_h)
             if self.landmarks:
-                lms[:, 0:10:2], lms[:, 1:10:2] = lms[:, 0:10:2] // self.scale_w, lms[:, 1:10:2] // self.scale_h
+                lms[:, 0:10:2], lms[:, 1:10:2] = self._floordiv(lms[:, 0:10:2], self.scale_w), self._floordiv(lms[:, 1:10:2], self.scale_h)
         else:
             dets = np.empty(shape=[0, 5], dtype=np.float32)
             if self.landmarks:
                 lms = np.empty(shape=[0, 10], dtype=np.float32)
         return (dets, lms) if self.landmarks else dets
+
+    def _postprocess_many(self, results):
+        """_postprocess for a list of (dets, lms) that share one (scale_h, scale_w): ONE floor division over the
+        concatenated rows (elementwise, so identical to per-image calls), then split again."""
+        n = [len(d) for d, _ in results]
+        if sum(n) == 0:
+            return [self._postprocess(d, l) for d, l in results]
+        dets = np.concatenate([d for d, _ in results if len(d)])
+        lms = np.concatenate([l for d, l in results if len(d)])
+        dets, lms = self._postprocess(dets, lms) if self.landmarks else (self._postprocess(dets, lms), None)
+        out, o = [], 0
+        for k in n:
+            if k == 0:
+                out.append(self._postprocess(np.empty((0, 5), np.float32), np.empty((0, 10), np.float32)))
+            else:
+                out.append((dets[o:o + k], lms[o:o + k]) if self.landmarks else dets[o:o + k])
+            o += k
+        return out
 
     def __call__(self, img, threshold=0.2):
         """img: BGR uint8 HWC (what cv2.imread returns).  Returns (dets [N,5], lms [N,10]) or dets."""
@@ -314,8 +358,7 @@ class CenterFace(object):
                 self.engine.forward_enqueue(chunk)
             else:
                 self.engine.forward_resized_enqueue(chunk)           # cv2.resize stand-in, on the device
-            for dets, lms in self.engine.decode_threshold(0.3, self.nms_thresh, self.max_dets):
-                out.append(self._postprocess(dets, lms))
+            out.extend(self._postprocess_many(self.engine.decode_threshold(0.3, self.nms_thresh, self.max_dets)))
         return out
 
     def forward(self, x):
@@ -393,6 +436,14 @@ class CenterFaceBuckets(object):
         self._buckets[key] = eng
         return eng
 
+    def _staging(self, eng, n, h, w):
+        """Page-locked staging array [n, h, w, 3] of an engine (one per raw size and chunk length, reused)."""
+        cache = eng.__dict__.setdefault("_staging", {})
+        key = (n, h, w)
+        if key not in cache:
+            cache[key] = eng.pinned_array((n, h, w, 3), np.uint8)
+        return cache[key]
+
     def detect(self, imgs, threshold=0.2):
         del threshold                                              # ignored by the reference's decode (centerface.py:77)
         groups = {}                                                # network shape -> raw shape -> indices
@@ -403,19 +454,40 @@ class CenterFaceBuckets(object):
         out = [None] * len(imgs)
         post = CenterFace.__new__(CenterFace)                      # only for _postprocess (no engine of its own)
         post.landmarks = self.landmarks
+        keys = list(groups)
+        for g0 in range(0, len(keys), self.max_buckets):           # at most max_buckets contexts alive at a time (LRU eviction)
+            self._run_buckets({k: groups[k] for k in keys[g0:g0 + self.max_buckets]}, imgs, out, post)
+        return out
+
+    def _run_buckets(self, groups, imgs, out, post):
+        # one work list per bucket (engine): chunks of one raw size, at most max_batch images
+        work = []
         for (H, W), raws in groups.items():
             eng = self._engine(H, W)
-            for (h, w), idx in raws.items():
-                post.scale_h, post.scale_w = H / h, W / w
-                for j in range(0, len(idx), eng.max_batch):
-                    chunk = np.stack([np.asarray(imgs[i], dtype=np.uint8) for i in idx[j:j + eng.max_batch]])
-                    if (h, w) == (H, W):
-                        eng.forward_enqueue(chunk)
-                    else:
-                        eng.forward_resized_enqueue(chunk)
-                    for i, (dets, lms) in zip(idx[j:j + eng.max_batch], eng.decode_threshold(0.3, self.nms_thresh, self.max_dets)):
-                        out[i] = post._postprocess(dets, lms)
-        return out
+            work.append([eng, [((h, w), idx[j:j + eng.max_batch]) for (h, w), idx in raws.items()
+                               for j in range(0, len(idx), eng.max_batch)]])
+        # Rounds: every bucket stages its next chunk into page-locked memory and enqueues it (asynchronous DMA + forward on
+        # that context's own streams), THEN the results of the round are collected -- the host copy of bucket k+1 runs
+        # underneath the GPU work of bucket k instead of behind a synchronising decode.
+        while any(chunks for _, chunks in work):
+            inflight = []
+            for eng, chunks in work:
+                if not chunks:
+                    continue
+                (h, w), idx = chunks.pop(0)
+                stage = self._staging(eng, len(idx), h, w)
+                for k, i in enumerate(idx):
+                    np.copyto(stage[k], np.asarray(imgs[i], dtype=np.uint8))
+                if (h, w) == (eng.H, eng.W):
+                    eng.forward_enqueue(stage)
+                else:
+                    eng.forward_resized_enqueue(stage)
+                inflight.append((eng, (h, w), idx))
+            for eng, (h, w), idx in inflight:
+                post.scale_h, post.scale_w = eng.H / h, eng.W / w
+                res = post._postprocess_many(eng.decode_threshold(0.3, self.nms_thresh, self.max_dets))
+                for i, r in zip(idx, res):
+                    out[i] = r
 
     __call__ = detect
 

@@ -1177,6 +1177,17 @@ int cf_graph_stats(cf_ctx* c, int* n_graphs, int* n_uncapturable) {
     return CF_OK;
 }
 
+int cf_host_alloc(cf_ctx* c, uint64_t bytes, void** hptr) {
+    if (!c || !hptr) return CF_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return CF_OK;
+}
+int cf_host_free(cf_ctx* c, void* hptr) {
+    if (!c) return CF_EINVAL;
+    HIPCHK(c, hipHostFree(hptr));
+    return CF_OK;
+}
 int cf_device_alloc(cf_ctx* c, uint64_t bytes, void** dptr) {
     if (!c || !dptr) return CF_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));

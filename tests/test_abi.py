@@ -93,3 +93,20 @@ def test_wider_result_format(tmp_path):
     assert txt == "0--Parade/0_Parade_marchingband_1_465.jpg\n2\n10.0 20.0 20.0 40.0 0.988\n0.0 0.0 6.5 8.2 0.050\n"
     p = cfa.demo.write_wider_result(str(tmp_path), "0--Parade", "img_1", np.empty((0, 5), np.float32))
     assert open(p).read() == "0--Parade/img_1.jpg\n0\n" and p.endswith("0--Parade/img_1.txt")
+
+
+def test_fast_floor_division_equals_numpy_floor_divide():
+    """CenterFace._floordiv must be `a // scale` (centerface.py:56,58) bit for bit: random coordinates, values at and one
+    ulp around exact integer multiples of the scale, negatives (landmarks left of the image), signed zeros, scale 1."""
+    import centerface_amd as cfa
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        h = int(rng.integers(33, 1300))
+        s = (int(np.ceil(h / 32) * 32) / h) if trial else 1.0
+        s32 = np.float32(s)
+        n = rng.integers(0, 1300, 20000).astype(np.float32)
+        near = (n * s32).astype(np.float32)
+        a = np.concatenate([rng.uniform(-50, 1300, 50000).astype(np.float32), near, np.nextafter(near, np.float32(np.inf)),
+                            np.nextafter(near, np.float32(-np.inf)), -near[:500], np.array([0.0, -0.0], np.float32)])
+        ref, got = a // s, cfa.CenterFace._floordiv(a, s)
+        assert got.dtype == np.float32 and np.array_equal(ref, got) and np.array_equal(np.signbit(ref), np.signbit(got)), s
