@@ -408,80 +408,111 @@ hipError_t launch_peak_topk(hipStream_t s, const TopkParams& p) {
 }
 
 // ================================================================== D1: threshold decode + NMS
-// Stage 1: one workgroup per image scans the heat map in row-major order in rounds of 1024 cells
-// and appends the cells above the threshold, in order, with their boxes and landmarks.
+// Stage 1: one workgroup per image collects the cells above the threshold IN ROW-MAJOR ORDER (the reference's
+// np.where order, centerface.py:78; it decides ties in the NMS order) with their boxes and landmarks.  Each of the 16
+// waves owns a contiguous segment of the map: pass 1 counts its hits (ballot + popcount per 64 cells, no barrier), one
+// barrier publishes the 16 counts, pass 2 re-scans the segment and writes every hit at segment base + running offset.
+// (The previous version walked the map in 1024-cell rounds with three workgroup barriers each: 74 us for one 160x160 map.)
+__device__ __forceinline__ void thresh_emit(const ThreshParams& p, const float* heads, float* cand, int i, uint32_t pos) {
+    const float* rec = heads + (size_t)i * 16;
+    const float s = rec[0];
+    const int cy = i / p.w, cx = i - cy * p.w;
+    // centerface.py:84-91 -- float32 sizes, float64 centre arithmetic, cast at the end
+    const float s0 = rec[1] * 4.0f, s1 = rec[2] * 4.0f;
+    // D2 (eval_widerface.py:102-104) adds the offsets -- channel 1 to x, channel 0 to y, as the
+    // reference does -- in float64 (int64 + float32 promotes to float64 in numpy)
+    const double ox = p.mode == 1 ? (double)rec[14] : 0.0, oy = p.mode == 1 ? (double)rec[13] : 0.0;
+    double x1 = fmax(0.0, ((double)cx + ox + 0.5) * 4.0 - (double)(s0 / 2.0f));
+    double y1 = fmax(0.0, ((double)cy + oy + 0.5) * 4.0 - (double)(s1 / 2.0f));
+    x1 = fmin(x1, (double)p.img_w); y1 = fmin(y1, (double)p.img_h);
+    const double x2 = fmin(x1 + (double)s0, (double)p.img_w);
+    const double y2 = fmin(y1 + (double)s1, (double)p.img_h);
+    float* c = cand + (size_t)pos * 16;
+    c[0] = (float)x1; c[1] = (float)y1; c[2] = (float)x2; c[3] = (float)y2; c[4] = s;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {                       // centerface.py:94-99
+        c[5 + 2 * j] = (float)(((double)rec[3 + 2 * j] + (double)cx + 0.5) * 4.0);
+        c[6 + 2 * j] = (float)(((double)rec[4 + 2 * j] + (double)cy + 0.5) * 4.0);
+    }
+    c[15] = 0.0f;
+}
+
 __global__ __launch_bounds__(1024) void thresh_collect_kernel(ThreshParams p) {
     __shared__ uint32_t wave_cnt[16];
-    __shared__ uint32_t base_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int HW = p.h * p.w;
     const float* heads = p.heads + (size_t)b * HW * 16;
     float* cand = p.cand + (size_t)b * p.cap * 16;
-    if (tid == 0) base_s = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < HW; i0 += 1024) {
-        const int i = i0 + tid;
-        float s = 0.0f;
-        bool hit = false;
-        if (i < HW) { s = heads[(size_t)i * 16]; hit = s > p.score_thresh; }     // hm > 0.3, centerface.py:77
-        const unsigned long long bal = __ballot(hit);
-        const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wave] = __popcll(bal);
-        __syncthreads();
-        uint32_t off = base_s;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        uint32_t total = 0;
-        for (int w = 0; w < 16; ++w) total += wave_cnt[w];
-        if (hit) {
-            const uint32_t pos = off + before;
-            if (pos < (uint32_t)p.cap) {
-                const float* rec = heads + (size_t)i * 16;
-                const int cy = i / p.w, cx = i - cy * p.w;
-                // centerface.py:84-91 -- float32 sizes, float64 centre arithmetic, cast at the end
-                const float s0 = rec[1] * 4.0f, s1 = rec[2] * 4.0f;
-                // D2 (eval_widerface.py:102-104) adds the offsets -- channel 1 to x, channel 0 to y, as the
-                // reference does -- in float64 (int64 + float32 promotes to float64 in numpy)
-                const double ox = p.mode == 1 ? (double)rec[14] : 0.0, oy = p.mode == 1 ? (double)rec[13] : 0.0;
-                double x1 = fmax(0.0, ((double)cx + ox + 0.5) * 4.0 - (double)(s0 / 2.0f));
-                double y1 = fmax(0.0, ((double)cy + oy + 0.5) * 4.0 - (double)(s1 / 2.0f));
-                x1 = fmin(x1, (double)p.img_w); y1 = fmin(y1, (double)p.img_h);
-                const double x2 = fmin(x1 + (double)s0, (double)p.img_w);
-                const double y2 = fmin(y1 + (double)s1, (double)p.img_h);
-                float* c = cand + (size_t)pos * 16;
-                c[0] = (float)x1; c[1] = (float)y1; c[2] = (float)x2; c[3] = (float)y2; c[4] = s;
+    int* idx = p.order + (size_t)b * p.cap;                // scratch until the rank kernel overwrites it with the sort order
+    // the threshold scan reads the dense heat plane when the head kernel wrote one (256 contiguous bytes per wave load
+    // instead of one float out of each of 64 records)
+    const float* hm = p.hm_plane ? p.hm_plane + (size_t)b * HW : heads;
+    const int hs = p.hm_plane ? 1 : 16;
+    const int seg = ((HW + 15) / 16 + 63) / 64 * 64;       // cells per wave, a multiple of 64
+    const int lo = wave * seg, hi = min(lo + seg, HW);
+    uint32_t mine = 0;
+    for (int i0 = lo; i0 < hi; i0 += 256) {                // four independent 64-cell groups per trip (loads in flight)
+        bool hit[4];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {                       // centerface.py:94-99
-                    c[5 + 2 * j] = (float)(((double)rec[3 + 2 * j] + (double)cx + 0.5) * 4.0);
-                    c[6 + 2 * j] = (float)(((double)rec[4 + 2 * j] + (double)cy + 0.5) * 4.0);
-                }
-                c[15] = 0.0f;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) base_s += total;
-        __syncthreads();
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; hit[u] = i < hi && hm[(size_t)i * hs] > p.score_thresh; }   // hm > 0.3, centerface.py:77
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mine += (uint32_t)__popcll(__ballot(hit[u]));
     }
+    if (lane == 0) wave_cnt[wave] = mine;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+    for (int w2 = 0; w2 < 16; ++w2) { if (w2 < wave) off += wave_cnt[w2]; total += wave_cnt[w2]; }
+    for (int i0 = lo; i0 < hi; i0 += 256) {
+        bool hit[4]; unsigned long long bal[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; hit[u] = i < hi && hm[(size_t)i * hs] > p.score_thresh; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bal[u] = __ballot(hit[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (hit[u]) {
+                const uint32_t pos = off + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull));
+                if (pos < (uint32_t)p.cap) idx[pos] = i0 + u * 64 + lane;          // only the cell index: 4 bytes, no divergent box code
+            }
+            off += (uint32_t)__popcll(bal[u]);
+        }
+    }
+    __syncthreads();
+    // pass 3: one candidate per thread, densely (the box / landmark arithmetic inside the scan ran once per 64-cell group
+    // with a hit -- ~25 times per wave for a few hundred candidates -- with one or two lanes active: 40 of the 48 us)
+    const int ncand = min((int)total, p.cap);
+    for (int t = tid; t < ncand; t += 1024) thresh_emit(p, heads, cand, idx[t], (uint32_t)t);
     if (tid == 0) {
-        uint32_t n = base_s;
+        uint32_t n = total;
         if (n > (uint32_t)p.cap) { atomicMax(p.overflow, (int)n); n = p.cap; }     // the host grows the workspace to the largest count and reruns
         p.cand_count[b] = (int)n;
     }
 }
 
-// Stage 2: rank candidates by (score desc, index desc) -- rank = number of candidates that precede
+// Stage 2: rank candidates by (score desc, index desc) -- rank = number of candidates that precede.  The scores are
+// staged in LDS in chunks (a thread's n comparisons were n dependent 64-byte-stride global loads: 41 us for n = 500).
 __global__ __launch_bounds__(256) void thresh_rank_kernel(ThreshParams p) {
+    constexpr int CH = 4096;
+    __shared__ float sc[CH];
     const int b = blockIdx.y;
     const int n = p.cand_count[b];
+    if ((int)(blockIdx.x * 256) >= n) return;                      // workgroup-uniform
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     const float* cand = p.cand + (size_t)b * p.cap * 16;
-    const float si = cand[(size_t)i * 16 + 4];
+    const float si = i < n ? cand[(size_t)i * 16 + 4] : 0.0f;
     int rank = 0;
-    for (int j = 0; j < n; ++j) {
-        const float sj = cand[(size_t)j * 16 + 4];
-        rank += (sj > si) || (sj == si && j > i);
+    for (int j0 = 0; j0 < n; j0 += CH) {
+        const int m = min(CH, n - j0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < m; j += 256) sc[j] = cand[(size_t)(j0 + j) * 16 + 4];
+        __syncthreads();
+        if (i < n)
+            for (int j = 0; j < m; ++j) {
+                const float sj = sc[j];
+                rank += (sj > si) || (sj == si && (j0 + j) > i);
+            }
     }
-    p.order[(size_t)b * p.cap + rank] = i;
+    if (i < n) p.order[(size_t)b * p.cap + rank] = i;
 }
 
 // Stage 3: suppression bit matrix in sorted order: bit (r, c) set when sorted candidate r
@@ -518,30 +549,112 @@ __global__ __launch_bounds__(256) void thresh_mask_kernel(ThreshParams p) {
     }
 }
 
-// Stage 4: sequential greedy sweep by one wave per image; emits kept rows in keep order.
+// Stage 4: greedy sweep by one wave per image in blocks of 64 sorted candidates; emits kept rows in keep order.
+// Inside a block the 64 x 64 diagonal part of the suppression matrix sits in registers (lane i = row i) and the
+// sequential dependence is resolved with scalar bit tests + v_readlane -- no memory access in the serial loop; the
+// kept rows of the block are then written by their own lanes in parallel and OR-ed into the `removed` bitmap of the
+// later blocks with coalesced row loads.  (One candidate per iteration with a dependent global load each: 200 us for
+// 350 boxes, longer than the network forward of a single image.)
 __global__ __launch_bounds__(64) void thresh_sweep_kernel(ThreshParams p) {
-    extern __shared__ unsigned long long removed[];      // words
+    extern __shared__ unsigned long long sweep_lds[];     // removed[words] | keptbits[words] | keptbase[words] (int)
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = p.cand_count[b];
     const int words = (p.cap + 63) >> 6;
     const int nw = (n + 63) >> 6;
+    unsigned long long* removed = sweep_lds;
+    unsigned long long* keptbits = sweep_lds + words;
+    int* keptbase = reinterpret_cast<int*>(sweep_lds + 2 * words);
     for (int w = lane; w < nw; w += 64) removed[w] = 0ull;
-    __syncthreads();
     const float* cand = p.cand + (size_t)b * p.cap * 16;
     const int* order = p.order + (size_t)b * p.cap;
+    const unsigned long long* gmask = p.mask + (size_t)b * p.cap * words;
+    // (staging the n x nw words that matter in LDS first was tried: 44 -> 55 us for 500 candidates -- the sweep is bound by
+    //  its serial scalar loop, not by the row loads)
+    __syncthreads();
+    const unsigned long long* mask = gmask;
+    const int mstride = words;
     int kept = 0;
-    for (int r = 0; r < n; ++r) {
-        const bool dead = (removed[r >> 6] >> (r & 63)) & 1ull;      // uniform
-        if (dead) continue;
-        const unsigned long long* row = p.mask + ((size_t)b * p.cap + r) * words;
-        for (int w = (r >> 6) + lane; w < nw; w += 64) removed[w] |= row[w];
-        if (kept < p.max_out) {
-            const float* c = cand + (size_t)order[r] * 16;
-            if (lane < 5) p.dets[((size_t)b * p.max_out + kept) * 5 + lane] = c[lane];
-            if (p.lms && lane >= 5 && lane < 15) p.lms[((size_t)b * p.max_out + kept) * 10 + (lane - 5)] = c[lane];
+    for (int blk = 0; blk < nw; ++blk) {
+        const int r = blk * 64 + lane;
+        const unsigned long long diag = r < n ? mask[(size_t)r * mstride + blk] : 0ull;
+        const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+        const unsigned long long remv = removed[blk];      // the same value in every lane
+        // scalar state (SGPRs): removed bits and kept bits of this block as 32-bit halves; candidate i can only suppress
+        // candidates j > i, so while i < 32 both halves of its row matter, afterwards only the high one
+        uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)remv);
+        uint32_t rhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(remv >> 32));
+        uint32_t klo = 0u, khi = 0u;
+        const int nvalid = min(64, n - blk * 64);
+        // branch-free and fully unrolled (constant lane numbers, constant shifts): ~10 scalar instructions per candidate
+        // instead of two taken branches; rows past n are all-zero and are masked out of the kept bits afterwards
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t alive = ((rlo >> i) & 1u) - 1u;                    // all ones when candidate i is still alive
+            klo |= (1u << i) & alive;
+            rlo |= (uint32_t)__builtin_amdgcn_readlane((int)dlo, i) & alive;
+            rhi |= (uint32_t)__builtin_amdgcn_readlane((int)dhi, i) & alive;
         }
-        ++kept;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t alive = ((rhi >> i) & 1u) - 1u;
+            khi |= (1u << i) & alive;
+            rhi |= (uint32_t)__builtin_amdgcn_readlane((int)dhi, 32 + i) & alive;
+        }
+        if (nvalid < 64) {
+            const unsigned long long vm = (1ull << nvalid) - 1ull;
+            klo &= (uint32_t)vm; khi &= (uint32_t)(vm >> 32);
+        }
+        const unsigned long long kb = ((unsigned long long)khi << 32) | klo;
+        if (lane == 0) { keptbits[blk] = kb; keptbase[blk] = kept; }
+        kept += __popcll(kb);
+        // the kept rows of this block suppress candidates of the later blocks
+        const int rest = nw - (blk + 1);
+        if (rest > 0 && rest <= 16) {
+            // lane = row: every kept lane reads the remaining words of ITS row (contiguous), then one wave-wide OR per word
+            const bool kl = (kb >> lane) & 1ull;
+            unsigned long long v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = (kl && j < rest) ? mask[(size_t)r * mstride + blk + 1 + j] : 0ull;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < rest) {                              // uniform
+                    uint32_t vl = (uint32_t)v[j], vh = (uint32_t)(v[j] >> 32);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { vl |= __shfl_xor(vl, o); vh |= __shfl_xor(vh, o); }
+                    if (lane == 0) removed[blk + 1 + j] |= ((unsigned long long)vh << 32) | vl;
+                }
+            }
+        } else {
+            for (int w0 = blk + 1; w0 < nw; w0 += 64) {     // many words: lane = word, one coalesced row load per kept row
+                const int w = w0 + lane;
+                unsigned long long acc = 0ull;
+                unsigned long long k2 = kb;
+                while (k2) {                                // uniform
+                    const int i = __builtin_ctzll(k2);
+                    k2 &= k2 - 1;
+                    if (w < nw) acc |= mask[(size_t)(blk * 64 + i) * mstride + w];
+                }
+                if (w < nw) removed[w] |= acc;
+            }
+        }
         __syncthreads();
+    }
+    // emit the kept rows in keep order: every candidate's lane knows its position from the block's kept bits
+    for (int blk = 0; blk < nw; ++blk) {
+        const int r = blk * 64 + lane;
+        const unsigned long long kb = keptbits[blk];
+        if (!((kb >> lane) & 1ull)) continue;
+        const int pos = keptbase[blk] + __popcll(kb & ((1ull << lane) - 1ull));
+        if (pos >= p.max_out) continue;
+        const float* c = cand + (size_t)order[r] * 16;
+        float* d = p.dets + ((size_t)b * p.max_out + pos) * 5;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) d[j] = c[j];
+        if (p.lms) {
+            float* l = p.lms + ((size_t)b * p.max_out + pos) * 10;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) l[j] = c[5 + j];
+        }
     }
     if (lane == 0) p.counts[b] = kept;            // may exceed max_out: rows past max_out are not written, the caller sees the truncation
 }
@@ -561,22 +674,37 @@ hipError_t launch_affine_boxes(hipStream_t s, float* dets, const double* trans, 
     return hipGetLastError();
 }
 
+// dynamic LDS of the sweep: removed / kept bitmaps and kept bases
+static size_t sweep_lds_bytes(int words) { return ((size_t)2 * words + (words + 1) / 2) * sizeof(unsigned long long); }
+static hipError_t sweep_configure() {                      // > 64 KB of dynamic LDS needs the function attribute, once per device
+    static thread_local bool configured_dev[32] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (configured_dev[dev & 31]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thresh_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) configured_dev[dev & 31] = true;
+    return e;
+}
+
 hipError_t launch_nms_stages(hipStream_t s, const ThreshParams& p) {
     if (p.B <= 0) return hipSuccess;
     const int words = (p.cap + 63) >> 6;
+    { hipError_t e = sweep_configure(); if (e != hipSuccess) return e; }
+    if (sweep_lds_bytes(words) > 160 * 1024) return hipErrorInvalidValue;   // > ~520 k candidates per image
     hipLaunchKernelGGL(thresh_rank_kernel, dim3((p.cap + 255) / 256, p.B), dim3(256), 0, s, p);
     hipLaunchKernelGGL(thresh_mask_kernel, dim3(128, p.B), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(thresh_sweep_kernel, dim3(p.B), dim3(64), words * sizeof(unsigned long long), s, p);
+    hipLaunchKernelGGL(thresh_sweep_kernel, dim3(p.B), dim3(64), sweep_lds_bytes(words), s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_decode_threshold(hipStream_t s, const ThreshParams& p) {
     if (p.B <= 0) return hipSuccess;
     const int words = (p.cap + 63) >> 6;
+    { hipError_t e = sweep_configure(); if (e != hipSuccess) return e; }
+    if (sweep_lds_bytes(words) > 160 * 1024) return hipErrorInvalidValue;   // > ~520 k candidates per image
     hipLaunchKernelGGL(thresh_collect_kernel, dim3(p.B), dim3(1024), 0, s, p);
     hipLaunchKernelGGL(thresh_rank_kernel, dim3((p.cap + 255) / 256, p.B), dim3(256), 0, s, p);
     hipLaunchKernelGGL(thresh_mask_kernel, dim3(128, p.B), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(thresh_sweep_kernel, dim3(p.B), dim3(64), words * sizeof(unsigned long long), s, p);
+    hipLaunchKernelGGL(thresh_sweep_kernel, dim3(p.B), dim3(64), sweep_lds_bytes(words), s, p);
     return hipGetLastError();
 }
 

@@ -203,6 +203,7 @@ hipError_t launch_peak_topk(hipStream_t s, const TopkParams& p);
 // D1: threshold compaction (row-major) + box/landmark arithmetic + greedy NMS
 struct ThreshParams {
     const float* heads;   // [B][h*w][16]
+    const float* hm_plane; // optional dense [B][h*w] copy of channel 0 (coalesced threshold scan), else nullptr
     int B, h, w, img_h, img_w;
     float score_thresh, nms_thresh;
     int cap;              // candidate capacity per image
@@ -217,7 +218,7 @@ struct ThreshParams {
     float* dets;          // [B][max_out][5]
     float* lms;           // [B][max_out][10] or nullptr
     int* counts;          // [B]
-    int* overflow;        // [1] set to 1 when some image exceeded cap
+    int* overflow;        // [1] largest candidate count seen when some image exceeded cap (else untouched)
 };
 hipError_t launch_decode_threshold(hipStream_t s, const ThreshParams& p);
 // apply per-image 2x3 affines to the (x1,y1),(x2,y2) corners of dets [B][K][stride] in place (utils/post_process.py:83-90)

@@ -41,6 +41,23 @@ def main():
     for B in bs:
         r = {g: run(engs[g], xs[g], B, a.topk, a.iters) for g in (False, True)}
         print("| %d | %.3f / %.3f | %.3f / %.3f | %.0f |" % (B, r[False][0], r[False][1], r[True][0], r[True][1], B / r[True][0] * 1e3))
+    for e in engs.values():
+        e.close()
+    # the reference's own call: CenterFace(h, w)(img) -- host uint8 image in, thresholded + NMS'ed boxes out (numpy)
+    print()
+    print("| CenterFace(h, w)(img), one host image | ms (p50 / p95) |")
+    print("|---|---:|")
+    for (h, w) in ((a.size, a.size), (478, 720)):
+        face = cfa.CenterFace(h, w, dtype=a.dtype)
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for _ in range(3):
+            face(img)
+        ts = []
+        for _ in range(a.iters):
+            t0 = time.perf_counter(); face(img); ts.append(time.perf_counter() - t0)
+        print("| %dx%d%s | %.3f / %.3f |" % (h, w, "" if (h % 32 == 0 and w % 32 == 0) else " (device resize to %dx%d)" % (face.img_h_new, face.img_w_new),
+                                          np.median(ts) * 1e3, np.percentile(ts, 95) * 1e3))
+        face.close()
 
 
 if __name__ == "__main__":
