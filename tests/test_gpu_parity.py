@@ -979,3 +979,40 @@ def test_stream_and_buffer_hazards_between_entry_points():
         eng.synchronize()
         assert np.array_equal(d_dev.cpu().numpy(), d_host)
     eng.close(); ref_eng.close()
+
+
+def test_two_contexts_driven_from_two_threads():
+    """include/centerface_hip.h: "different ctxs may be driven from different threads".  Two threads, each with its own
+    Engine (different shapes and modes), run forwards, both decoders and a weight reload concurrently; every result must
+    equal the single-threaded result of the same calls."""
+    import threading
+    rng = np.random.default_rng(21)
+    jobs = [dict(size=(160, 224), dtype="bf16", B=3), dict(size=(96, 128), dtype="fp32", B=2)]
+    for j in jobs:
+        j["x"] = rng.integers(0, 256, (j["B"],) + j["size"] + (3,), dtype=np.uint8)
+
+    def work(j, out, iters):
+        eng = cfa.Engine(j["size"][0], j["size"][1], max_batch=j["B"], dtype=j["dtype"])
+        res = []
+        for it in range(iters):
+            eng.forward_enqueue(j["x"])
+            d, l, i = eng.decode_topk(30)
+            t = eng.decode_threshold(0.3, 0.3, 256)
+            if it == iters // 2:
+                eng.load_state_dict(cfa.weights.synthetic_state_dict(0))        # same weights again: graphs dropped, results unchanged
+            res.append((d, l, i, [a for a, _ in t]))
+        eng.close()
+        out.append(res)
+
+    ref = []
+    for j in jobs:
+        o = []; work(j, o, 2); ref.append(o[0][0])
+    outs = [[], []]
+    th = [threading.Thread(target=work, args=(jobs[k], outs[k], 12)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for k in range(2):
+        assert len(outs[k]) == 1 and len(outs[k][0]) == 12
+        for d, l, i, t in outs[k][0]:
+            assert np.array_equal(d, ref[k][0]) and np.array_equal(l, ref[k][1]) and np.array_equal(i, ref[k][2])
+            assert all(np.array_equal(a, b) for a, b in zip(t, ref[k][3]))
