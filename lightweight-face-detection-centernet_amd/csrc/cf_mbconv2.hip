@@ -81,16 +81,17 @@ __device__ __forceinline__ f32x2 swish2_prescaled(f32x2 u) {
 }
 static constexpr float kNegLog2e = -1.44269504088896341f, kNegLn2 = -0.69314718055994531f;
 
-// first tap of an accumulation: acc = w . e (+ 0) -- v_dot2_f32_f16 with an inline-constant addend instead of
-// v_mov_b32 acc, 0 followed by the accumulating v_dot2c
-template <bool FIRST> __device__ __forceinline__ void dot2s(float& acc, uint32_t w, uint32_t e) {
-    if constexpr (FIRST) acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(hf2, w), __builtin_bit_cast(hf2, e), 0.0f, false);
-    else dot2c(acc, w, e);
-}
+#define CF_DOT8_ACC(A, W, E0, E1)                                                                        \
+    dot2c(A[0], W[0], E0.x); dot2c(A[1], W[1], E0.y); dot2c(A[2], W[2], E0.z); dot2c(A[3], W[3], E0.w);  \
+    dot2c(A[4], W[4], E1.x); dot2c(A[5], W[5], E1.y); dot2c(A[6], W[6], E1.z); dot2c(A[7], W[7], E1.w)
+// first tap through the builtin: acc = w . e + 0 (the compiler zeroes the accumulators with v_mov and uses v_dot2c).
+// Measured per kernel under rocprofv3 (B = 64, 640x640): the asm block dot8_first() is 1-3 % faster on the fused 3x3
+// kernels and the stem, neutral on the fused 5x5 ones and 3-7 % SLOWER on the expand+depthwise kernels (six waves per
+// SIMD: the block is a scheduling barrier in their row pipeline), so only the 3x3 fused path and the stem use it.
+#define CF_DOT8_Z(A, W, E0, E1)                                                                          \
+    do { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) A[i_] = 0.0f; CF_DOT8_ACC(A, W, E0, E1); } while (0)
 #define CF_DOT8(FIRST, A, W, E0, E1)                                                                     \
-    dot2s<FIRST>(A[0], W[0], E0.x); dot2s<FIRST>(A[1], W[1], E0.y); dot2s<FIRST>(A[2], W[2], E0.z);      \
-    dot2s<FIRST>(A[3], W[3], E0.w); dot2s<FIRST>(A[4], W[4], E1.x); dot2s<FIRST>(A[5], W[5], E1.y);      \
-    dot2s<FIRST>(A[6], W[6], E1.z); dot2s<FIRST>(A[7], W[7], E1.w)
+    do { if constexpr (FIRST) dot8_first(A, W, E0, E1); else { CF_DOT8_ACC(A, W, E0, E1); } } while (0)
 
 // ---------------------------------------------------------------- geometry shared by host and device
 template <int KS, int S, int HC, int TOH, int TOW, int JX, int NW>
@@ -118,6 +119,9 @@ struct Px {
 };
 
 // ---------------------------------------------------------------- device
+#ifndef CF_XRELOAD_COND
+#define CF_XRELOAD_COND (KS == 5 && S == 2 && NBO == 1 && NW == 3)
+#endif
 template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW>
 __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     typedef Px<KS, S, HC, TOH, TOW, JX, NW> G;
@@ -137,16 +141,17 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     const int nq = p.nq;
     const int pp = wave % NPP, jg = wave / NPP;
 
-    // wave-uniform x parity (stride 2: x0 = 2 ox is always even) and the wave's first pixel in its class
+    // wave-uniform x parity (stride 2: x0 = 2 ox is always even) and the wave's 64 pixels of that class
     const int par = S == 1 ? pp / G::WPP : 0;
-    const int r0 = (S == 1 ? pp - par * G::WPP : pp) * 64;
-    // pixel `blk * 32 + lane` of this wave -> (oy, ox); false when the slot is past the end of the class
+    static constexpr LaneMap<S, TOH, TOW, IWP> kLanes{};
+    const int lm0 = (S == 1 ? pp - par * G::WPP : pp) * 64;
+    // pixel `blk * 32 + lane` of this wave -> (oy, ox) through the bank-conflict-free lane map (cf_common.h);
+    // false when the lane has no pixel (partly filled last wave of a class)
     auto tile_pixel = [&](int blk, int lane31, int& oy, int& ox) -> bool {
-        const int r = r0 + blk * 32 + lane31;
-        const int rc = r < G::PPX ? r : G::PPX - 1;
-        if constexpr (S == 1) { oy = rc / (TOW / 2); ox = 2 * (rc - oy * (TOW / 2)) + par; }
-        else { oy = rc / TOW; ox = rc - oy * TOW; }
-        return r < G::PPX;
+        const uint32_t e = kLanes.v[lm0 + blk * 32 + lane31];
+        oy = (e >> 6) & 0x1ff;
+        ox = S == 1 ? 2 * (int)(e & 63) + par : (int)(e & 63);
+        return (e & 0x8000u) == 0;
     };
     // phase 2: this lane's depthwise pixel = pixel pl of block h of the wave
     int dy, dx; tile_pixel(h, pl, dy, dx);
@@ -174,7 +179,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     // X fragments of this wave's halo pixel blocks (MFMA A operand: lane = pixel, 8 contiguous Cin per
     // half), loaded once; clamped address + zero select = ZeroPad2d without predicated loads
     constexpr int MAXI = (NIB + NW - 1) / NW;
+    // XRELOAD: the fragments are fetched again (from L2) at the top of every hidden-chunk round instead of living in
+    // registers across the rounds -- 64 VGPRs less on the 5x5 stride-2 block (layer2.0: 203 -> occupancy 3)
+    constexpr bool XRELOAD = CF_XRELOAD_COND;
     u32x4 xf[MAXI][JX];
+    u32x4 xh[PART ? MAXI : 1][2];
+    auto load_x = [&]() {
 #pragma unroll
     for (int t = 0; t < MAXI; ++t) {
         const int ib = wave + NW * t;
@@ -194,7 +204,6 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     }
 
     // half block: A operands of the 16x16x32 MFMAs, lane (m = pixel of the 16-pixel sub-block, kg = Cin chunk)
-    u32x4 xh[PART ? MAXI : 1][2];
     if constexpr (PART) {
 #pragma unroll
         for (int t = 0; t < MAXI; ++t)
@@ -212,6 +221,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
                 xh[t][sub].z = valid ? v.z : 0u; xh[t][sub].w = valid ? v.w : 0u;
             }
     }
+    };
+    if constexpr (!XRELOAD) load_x();
 
     // expand one halo pixel block: D[pixel][channel] = X . We^T, Swish, pixel pairs -> E
     auto expand_block = [&](int ib, const u32x4* xfr, const u32x4* xhr, const char* wx) {
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (ky == 0 && t == 0) { CF_DOT8(true, a8, wc[t], ec[t][0], ec[t][1]); }
+                if (ky == 0 && t == 0) { CF_DOT8_Z(a8, wc[t], ec[t][0], ec[t][1]); }
                 else { CF_DOT8(false, a8, wc[t], ec[t][0], ec[t][1]); }
             }
         }
@@ -336,6 +347,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     stage_weights(0);
     for (int q = 0; q < nq; ++q) {
         const char* wx = Wst + (q & 1) * WXB;
+        if constexpr (XRELOAD) load_x();
         __syncthreads();      // previous chunk's depthwise done with E; this stage's expand weights landed
 
 #pragma unroll
@@ -545,12 +557,12 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
 
     // ---- phase 2: depthwise + Swish, one output pixel per lane, all HC channels of this chunk
     const int par = S == 1 ? wave / WPP : 0;
-    const int r = (S == 1 ? wave - par * WPP : wave) * 64 + lane;      // index within the parity class
-    const bool live = r < PPX;
-    const int rc = live ? r : PPX - 1;
-    int oy, ox;
-    if constexpr (S == 1) { oy = rc / (TOW / 2); ox = 2 * (rc - oy * (TOW / 2)) + par; }
-    else { oy = rc / TOW; ox = rc - oy * TOW; }
+    // lane -> pixel of the wave's parity class through the bank-conflict-free lane map (cf_common.h)
+    static constexpr LaneMap<S, TOH, TOW, IWP> kLanes{};
+    const uint32_t lme = kLanes.v[(S == 1 ? wave - par * WPP : wave) * 64 + lane];
+    const bool live = (lme & 0x8000u) == 0;
+    const int oy = (lme >> 6) & 0x1ff;
+    const int ox = S == 1 ? 2 * (int)(lme & 63) + par : (int)(lme & 63);
     const char* eb0 = E + (unsigned)(((oy * S) * IWP + (ox * S - par)) / 2) * (unsigned)PITCH;
     const int gy = oy0 + oy, gx = ox0 + ox;
     const bool store = live && gy < p.Hout && gx < p.Wout;
@@ -578,7 +590,7 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (ky == 0 && t == 0) { CF_DOT8(true, a8, wc[t], ec[t][0], ec[t][1]); }
+                if (ky == 0 && t == 0) { CF_DOT8_Z(a8, wc[t], ec[t][0], ec[t][1]); }
                 else { CF_DOT8(false, a8, wc[t], ec[t][0], ec[t][1]); }
             }
         }

@@ -498,9 +498,12 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
 
     // ---- phase 2 + 3: depthwise 3x3 + Swish on 64 same-parity pixels per wave -> project 32 -> 16
     const int par = wave >> 1;                                      // waves 0,1: even x; 2,3: odd x
-    auto tile_pixel = [](int u, int& oy, int& ox) {
-        const int pr = u >> 7, r = u & 127;
-        oy = r >> 3; ox = 2 * (r & 7) + pr;
+    // 128 pixels per parity class (two waves); lane -> pixel through the bank-conflict-free lane map (cf_common.h)
+    static constexpr LaneMap<1, S0_TOH, S0_TOW, S0_IW> kLanes{};
+    auto tile_pixel = [&](int u, int& oy, int& ox) {
+        const int pr = u >> 7;
+        const uint32_t e = kLanes.v[u & 127];
+        oy = (e >> 6) & 0x1ff; ox = 2 * (int)(e & 63) + pr;
     };
     int dy, dx; tile_pixel((wave * 2 + h) * 32 + pl, dy, dx);
     const char* eb0 = E + (unsigned)((dy * S0_IW + (dx - par)) / 2) * (unsigned)S0P_PITCH;
@@ -508,8 +511,6 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
 
     auto dw_chunk = [&](int c) -> u32x4 {
         float a8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a8[i] = 0.0f;
         const S0_AS4 s0_u32x8* wq = wtab + ((par * 4 + c) * 3) * 2;
         const char* eb = eb0 + c * 32;
 #pragma unroll
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
                 const s0_u32x8 wv = wq[ky * 2 + t];
                 const char* et = eb + (ky * (S0_IW / 2) + t) * S0P_PITCH;
                 const u32x4 e0 = ld16(et), e1 = ld16(et + 16);
+                if (ky == 0 && t == 0) { dot8_first(a8, wv, e0, e1); continue; }      // a8 = w . e + 0: no zero-init moves
                 s0_dot2c(a8[0], wv[0], e0.x); s0_dot2c(a8[1], wv[1], e0.y);
                 s0_dot2c(a8[2], wv[2], e0.z); s0_dot2c(a8[3], wv[3], e0.w);
                 s0_dot2c(a8[4], wv[4], e1.x); s0_dot2c(a8[5], wv[5], e1.y);
