@@ -93,6 +93,9 @@ static constexpr float kNegLog2e = -1.44269504088896341f, kNegLn2 = -0.693147180
 #define CF_DOT8(FIRST, A, W, E0, E1)                                                                     \
     do { if constexpr (FIRST) dot8_first(A, W, E0, E1); else { CF_DOT8_ACC(A, W, E0, E1); } } while (0)
 
+#ifndef CF_WDIRECT_COND
+#define CF_WDIRECT_COND (KS == 5 && S == 2 && NW == 3)
+#endif
 // ---------------------------------------------------------------- geometry shared by host and device
 template <int KS, int S, int HC, int TOH, int TOW, int JX, int NW>
 struct Px {
@@ -113,7 +116,13 @@ struct Px {
     static_assert(!PART || JX <= 2, "half block needs Cin <= 32");
     static constexpr int EBYTES = NIB * 16 * PITCH;          // whole pixel blocks: phase 1 stores are unconditional
     static constexpr int RED = (KG - 1) * NPP * 64 * 64;
-    static constexpr int LDS = (EBYTES + 2 * WXB) > RED ? (EBYTES + 2 * WXB) : RED;
+    // three-wave workgroups (layer2.0) read the expand weights straight from global memory (L1/L2 hits): without the
+    // staging buffers the tile fits four times into a CU, 12 waves = 3 on every SIMD.  With 46 KB three workgroups = 9
+    // waves were resident, one SIMD carried three waves against two on the others, and every workgroup ran at the pace of
+    // its wave on the crowded SIMD (barrier per phase).
+    static constexpr bool WDIRECT = CF_WDIRECT_COND;
+    static constexpr int WLDS = WDIRECT ? 0 : 2 * WXB;
+    static constexpr int LDS = (EBYTES + WLDS) > RED ? (EBYTES + WLDS) : RED;
     static_assert(NPP * KG == NW && TOW % 2 == 0, "tile / wave geometry");
     static_assert(HC % 16 == 0 && JS * KG == HALF, "hidden chunk / k-group geometry");
 };
@@ -344,9 +353,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
         return pack16<bf16_t>(a8);
     };
 
-    stage_weights(0);
+    if constexpr (!G::WDIRECT) stage_weights(0);
     for (int q = 0; q < nq; ++q) {
-        const char* wx = Wst + (q & 1) * WXB;
+        const char* wx = G::WDIRECT ? (const char*)p.wexp + (size_t)q * WXB : Wst + (q & 1) * WXB;
         if constexpr (XRELOAD) load_x();
         __syncthreads();      // previous chunk's depthwise done with E; this stage's expand weights landed
 
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
             if (ib < NIB) expand_block(ib, xf[t], xh[PART ? t : 0], wx);
         }
         __syncthreads();
-        if (q + 1 < nq) stage_weights(q + 1);
+        if (!G::WDIRECT && q + 1 < nq) stage_weights(q + 1);
 
 #pragma unroll
         for (int j = 0; j < HALF; ++j) {

@@ -498,12 +498,12 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
 
     // ---- phase 2 + 3: depthwise 3x3 + Swish on 64 same-parity pixels per wave -> project 32 -> 16
     const int par = wave >> 1;                                      // waves 0,1: even x; 2,3: odd x
-    // 128 pixels per parity class (two waves); lane -> pixel through the bank-conflict-free lane map (cf_common.h)
-    static constexpr LaneMap<1, S0_TOH, S0_TOW, S0_IW> kLanes{};
-    auto tile_pixel = [&](int u, int& oy, int& ox) {
-        const int pr = u >> 7;
-        const uint32_t e = kLanes.v[u & 127];
-        oy = (e >> 6) & 0x1ff; ox = 2 * (int)(e & 63) + pr;
+    // row-major lane -> pixel order.  (The bank-conflict-free LaneMap of cf_common.h was measured here too: LDS conflicts
+    // 47 % -> 19 % of the LDS cycles, kernel 190 -> 194 us -- this kernel is not LDS-bound and its 32-byte output rows
+    // coalesce better when neighbouring lanes own neighbouring pixels.)
+    auto tile_pixel = [](int u, int& oy, int& ox) {
+        const int pr = u >> 7, r = u & 127;
+        oy = r >> 3; ox = 2 * (r & 7) + pr;
     };
     int dy, dx; tile_pixel((wave * 2 + h) * 32 + pl, dy, dx);
     const char* eb0 = E + (unsigned)((dy * S0_IW + (dx - par)) / 2) * (unsigned)S0P_PITCH;
