@@ -69,6 +69,10 @@ void head_pack_weights(int dtype, int collapsed, const float* w0, const float* b
                 for (int lane = 0; lane < 64; ++lane) {
                     int i = lane & 31, h = lane >> 5;
                     int q = slot_channel(nb, i);
+                    // collapsed == 2 (cf_uphead.hip): MFMA row i = record slot i, so that BOTH lane halves of the
+                    // result hold eight slots of the pixel (rows 0-3, 8-11 | 4-7, 12-15) and store 32 bytes each;
+                    // slot 15 (hm_raw) repeats slot 0's weights -- the same dot product, bit for bit
+                    if (collapsed == 2) q = i < 15 ? i : i == 15 ? 0 : NQ;
                     int c = h * SPD + j;
                     if (q >= NQ || c >= CPD) continue;
                     char* dst = (char*)w0p_host + ((((size_t)nb * 3 + dy) * SPD + j) * 64 + lane) * 16;
@@ -81,6 +85,7 @@ void head_pack_weights(int dtype, int collapsed, const float* w0, const float* b
                     }
                 }
     for (int q = 0; q < (collapsed ? 16 : 96); ++q) b0_host[q] = q < NQ ? (float)bq[q] : 0.0f;
+    if (collapsed == 2) b0_host[15] = (float)bq[0];
     for (int i = 0; i < 96 * 16; ++i) w1d_host[i] = 0.0f;
     for (int o = 0; o < 16; ++o) b1_host[o] = (o < 15 && !collapsed) ? b1[o] : 0.0f;
     if (!collapsed)

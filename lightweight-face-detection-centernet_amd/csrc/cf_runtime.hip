@@ -558,7 +558,7 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
                 memcpy(&b1[o], ws.f(p + ".1.bias"), sizeof(float) * hc[h]);
                 o += hc[h];
             }
-            const int col = (c->flags & CF_FLAG_COLLAPSE_HEADS) ? 1 : 0;
+            const int col = (c->flags & CF_FLAG_COLLAPSE_HEADS) ? (op.partner >= 0 ? 2 : 1) : 0;   // 2: row order of the fused up3+heads kernel
             std::vector<char> packed(head_packed_bytes(dt, col));
             std::vector<float> b0h(96), w1d(96 * 16), b1h(16);
             head_pack_weights(dt, col, w0.data(), b0.data(), w1.data(), b1.data(), packed.data(), b0h.data(), w1d.data(), b1h.data());

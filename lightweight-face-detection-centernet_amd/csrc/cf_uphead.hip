@@ -115,21 +115,25 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
             }
         }
         const int gy = oy0 + oy, gx = ox0 + ox;
-        if (h != 0 || gy >= p.h || gx >= p.w) continue;
-        float out[16];
+        if (gy >= p.h || gx >= p.w) continue;
+        // head_pack_weights(collapsed = 2): MFMA row = record slot, so lane half h holds slots 4h..4h+3 (acc 0-3) and
+        // 8+4h..8+4h+3 (acc 4-7) of its pixel: every lane stores two 16-byte pieces and a 64-byte record is written by
+        // two store instructions of the wave instead of four half-empty ones.  Slot 15 = the raw hm logit (slot 0's
+        // weights again: identical arithmetic), slot 0 = its clamped sigmoid.
+        float out[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[r] = acc[r] + p.b0[r];
-        const float raw = out[0];
-        // centerface.py:43: clamp(sigmoid(hm), 1e-4, 1 - 1e-4); precise exp + IEEE divide
-        float sg = 1.0f / (1.0f + expf(-raw));
-        sg = fminf(fmaxf(sg, 1e-4f), 1.0f - 1e-4f);
-        out[0] = sg;
-        out[15] = raw;
+        for (int r = 0; r < 4; ++r) { out[r] = acc[r] + p.b0[h * 4 + r]; out[4 + r] = acc[4 + r] + p.b0[8 + h * 4 + r]; }
         const size_t m = ((size_t)b * p.h + gy) * p.w + gx;
-        if (p.hm_plane) p.hm_plane[m] = sg;
-        float* dst = p.heads + m * 16;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) st16(dst + g * 4, pack16<float>(&out[g * 4]));
+        if (h == 0) {
+            // centerface.py:43: clamp(sigmoid(hm), 1e-4, 1 - 1e-4); precise exp + IEEE divide
+            float sg = 1.0f / (1.0f + expf(-out[0]));
+            sg = fminf(fmaxf(sg, 1e-4f), 1.0f - 1e-4f);
+            out[0] = sg;
+            if (p.hm_plane) p.hm_plane[m] = sg;
+        }
+        float* dst = p.heads + m * 16 + h * 4;
+        st16(dst, pack16<float>(&out[0]));
+        st16(dst + 8, pack16<float>(&out[4]));
     }
 }
 
