@@ -11,6 +11,12 @@ normalise + stem -> 12 MBConv blocks -> IDAUp neck -> heads -> 3x3-peak / top-K 
 (-> RCCL all-gather of the final boxes when N > 1).  Weak scaling: every rank processes its own
 batch of 64; `value` is whole-job images/s.  Rank 0 prints ONE JSON line.
 
+Each rank drives `--depth` (default 2) independent contexts round-robin: step k is enqueued on context k mod depth, so two
+batches are in flight and the HBM- / latency-bound back half of one forward (project GEMMs on the small maps, up3+heads,
+decode) runs underneath the VALU-bound front half of the next (cfa.EngineRing; a C host does it with two cf_ctx).
+Every step still processes one whole batch; the windows are fenced by a synchronize of every context.
+`value_one_context` reports the same steps on a single context.
+
 Timing: W warm-up steps, then `--repeats` windows of EXACTLY K steps, each bracketed by barrier +
 synchronize on both sides, max over ranks per window; `value` comes from the MEDIAN window, min / max are
 reported next to it (`windows`).
@@ -50,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--topk", type=int, default=100)
+    ap.add_argument("--depth", type=int, default=2,
+                    help="contexts per GPU used round-robin (batches in flight); 1 = a single context, every step on one stream chain")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_with_h2d / fp32_parity_mode / parity (profiling runs)")
@@ -112,34 +120,42 @@ def cpu_baseline(seconds, size, topk, imgs):
                       "%d threads of %d host cores)" % (n16, t16, n1, t1, size, size, topk, torch.get_num_threads(), host_cores)}
 
 
-def make_step(cfa, eng, d_in_ptr, B, K, out, gather="none", comm=None):
-    """One benchmark step as a closure.  ``out``: dict of device tensors dets/lms/inds (single GPU) and ``all`` (the
-    gathered records).  gather: none | cf (cf_gather_topk on the decode stream) | torch (torch.distributed)."""
+def make_step(cfa, engs, d_in_ptr, B, K, outs, gather="none", comms=None):
+    """One benchmark step as a closure: forward + top-K decode (+ gather) of one batch.
+
+    ``engs`` / ``outs`` / ``comms``: one Engine / output dict / Comm, or lists of ``depth`` of them -- step k then runs
+    on context k % depth (cfa.EngineRing's schedule: two batches in flight, the back half of one forward under the front
+    half of the next).  ``out``: dict of device tensors dets/lms/inds and ``all`` (the gathered records).
+    gather: none | cf (cf_gather_topk on the decode stream) | torch (torch.distributed)."""
     import torch
     fmt = cfa._lib.CF_IN_U8_HWC_BGR
-    if gather == "cf":
-        def step():
-            eng.forward_enqueue(d_in_ptr, on_device=True, B=B, in_format=fmt)
-            comm.gather_topk_device(K, out["all"].data_ptr())
-            return out["all"]
-    elif gather == "torch":
+    if not isinstance(engs, (list, tuple)):
+        engs, outs, comms = [engs], [outs], [comms]
+    if comms is None:
+        comms = [None] * len(engs)
+    depth, k = len(engs), [0]
+    if gather == "torch":
         # the decode stream of the context and torch's stream (pack + all-gather) are chained with stream waits,
         # never a host sync: the gather of step i runs underneath the forward of step i+1
-        dec_stream = torch.cuda.ExternalStream(eng.streams()[1], device=out["dets"].device)
+        dec_streams = [torch.cuda.ExternalStream(e.streams()[1], device=o["dets"].device) for e, o in zip(engs, outs)]
 
-        def step():
-            eng.forward_enqueue(d_in_ptr, on_device=True, B=B, in_format=fmt)
-            dec_stream.wait_stream(torch.cuda.current_stream())      # last step's pack has consumed dets / lms
+    def step():
+        i = k[0] % depth
+        k[0] += 1
+        eng, out = engs[i], outs[i]
+        eng.forward_enqueue(d_in_ptr, on_device=True, B=B, in_format=fmt)
+        if gather == "cf":
+            comms[i].gather_topk_device(K, out["all"].data_ptr())
+            return out["all"]
+        if gather == "torch":
+            dec_streams[i].wait_stream(torch.cuda.current_stream())      # this slot's last pack has consumed dets / lms
             eng.decode_topk_device(K, out["dets"].data_ptr(), out["lms"].data_ptr(), out["inds"].data_ptr())
-            torch.cuda.current_stream().wait_stream(dec_stream)      # boxes are final before the pack reads them
+            torch.cuda.current_stream().wait_stream(dec_streams[i])      # boxes are final before the pack reads them
             rec = cfa.distributed.pack_records(out["dets"], out["lms"])
             out["all"] = cfa.distributed.gather_records(rec)
             return out["all"]
-    else:
-        def step():
-            eng.forward_enqueue(d_in_ptr, on_device=True, B=B, in_format=fmt)
-            eng.decode_topk_device(K, out["dets"].data_ptr(), out["lms"].data_ptr(), out["inds"].data_ptr())
-            return None
+        eng.decode_topk_device(K, out["dets"].data_ptr(), out["lms"].data_ptr(), out["inds"].data_ptr())
+        return None
     return step
 
 
@@ -228,22 +244,32 @@ def main():
     rng = np.random.default_rng(rank)
     host_imgs = rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)
     d_in = torch.from_numpy(host_imgs).to(dev)
-    out = {"dets": torch.empty((B, K, 6), dtype=torch.float32, device=dev),
-           "lms": torch.empty((B, K, 10), dtype=torch.float32, device=dev),
-           "inds": torch.empty((B, K), dtype=torch.int64, device=dev),
-           "all": torch.empty((world * B, K, 16), dtype=torch.float32, device=dev)}
+    D = max(1, args.depth)
+    outs = [{"dets": torch.empty((B, K, 6), dtype=torch.float32, device=dev),
+             "lms": torch.empty((B, K, 10), dtype=torch.float32, device=dev),
+             "inds": torch.empty((B, K), dtype=torch.int64, device=dev),
+             "all": torch.empty((world * B, K, 16), dtype=torch.float32, device=dev)} for _ in range(D)]
+    out = outs[0]
     torch.cuda.synchronize()
 
-    eng = cfa.Engine(S, S, max_batch=B, dtype=args.dtype, device=local_rank)
-    gather, comm = "none", None
+    engs = [cfa.Engine(S, S, max_batch=B, dtype=args.dtype, device=local_rank) for _ in range(D)]
+    eng = engs[0]
+    gather, comms = "none", []
+
+    def close_comms():
+        for cm in comms:
+            cm.close()
+        del comms[:]
     if world > 1 or args.exercise_gather_path:
         gather = "torch" if args.gather == "torch" else "cf"
         if gather == "cf":
-            # rendezvous over the torch.distributed store; every rank learns whether ALL ranks got a communicator
+            # rendezvous over the torch.distributed store (one RCCL communicator per context, created in the same order on
+            # every rank); every rank learns whether ALL ranks got their communicators
             ok = 1
+            uids = [cfa.distributed.broadcast_unique_id() if world > 1 else cfa.distributed.unique_id() for _ in engs]
             try:
-                uid = cfa.distributed.broadcast_unique_id() if world > 1 else cfa.distributed.unique_id()
-                comm = cfa.distributed.Comm(eng, rank, world, uid)
+                for e, uid in zip(engs, uids):
+                    comms.append(cfa.distributed.Comm(e, rank, world, uid))
             except Exception as exc:                                   # noqa: BLE001
                 ok = 0
                 print("rank %d: cf_comm_create failed (%s)" % (rank, exc), file=sys.stderr)
@@ -254,11 +280,13 @@ def main():
             if not ok:
                 if args.gather == "cf":
                     sys.exit(4)
-                gather, comm = "torch", None
-    step = make_step(cfa, eng, d_in.data_ptr(), B, K, out, gather, comm)
+                close_comms()
+                gather = "torch"
+    step = make_step(cfa, engs, d_in.data_ptr(), B, K, outs, gather, comms if gather == "cf" else None)
 
     def fence():
-        eng.synchronize()
+        for e in engs:
+            e.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -323,12 +351,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: batch=%d %dx%d %s on 1 MI355X per rank, forward + top-%d peak decode%s; "
-                                   "synthetic uint8 images resident in HBM, calibrated synthetic weights (seed 0)"
+                                   "synthetic uint8 images resident in HBM, calibrated synthetic weights (seed 0); "
+                                   "%d context(s) per GPU, batch k on context k mod %d"
                                    % ("BASELINE configs[1]" if (B, S, K, args.dtype) == (64, 640, 100, "bf16") else
                                       "BASELINE configs[4] per-GPU shard" if (S, K) == (1280, 1000) else "custom (not a BASELINE config)",
-                                      B, S, S, args.dtype, K, " + RCCL all-gather of boxes" if world > 1 else ""),
+                                      B, S, S, args.dtype, K, " + RCCL all-gather of boxes" if world > 1 else "", D, D),
                        "batch_per_gpu": B, "global_batch": B * world, "image": [S, S], "topk": K,
                        "parallelism": "dp%d" % world,
+                       "contexts_per_gpu": D,
                        "gather": {"none": None, "cf": "cf_gather_topk (C ABI, ncclAllGather on the decode stream)",
                                   "torch": "torch.distributed.all_gather_into_tensor"}[gather]},
             "windows": {"n": len(wins), "steps_each": args.steps, "median_ms": round(1e3 * med, 3),
@@ -341,7 +371,7 @@ def main():
             pinned = torch.from_numpy(host_imgs).pin_memory()
             hview = pinned.numpy()
 
-            def step_h2d():
+            def step_h2d():                     # one context: this step is PCIe-bound (78.6 MB per batch), a second batch in flight buys nothing
                 eng.forward_enqueue(hview)
                 eng.decode_topk_device(K, out["dets"].data_ptr(), out["lms"].data_ptr(), out["inds"].data_ptr())
             for _ in range(3):
@@ -349,13 +379,22 @@ def main():
             wh = time_windows(step_h2d, fence, args.steps, 7)
             result["value_with_h2d"] = {"value": round(B * args.steps / float(np.median(wh)), 1), "unit": "images/s",
                                         "note": "pinned host batch (%.1f MB) copied every step on the copy stream, overlapped with the "
-                                                "previous forward; median of 7 windows" % (host_imgs.nbytes / 1e6)}
+                                                "previous forward, one context (PCIe-bound: ~46 GB/s); median of 7 windows" % (host_imgs.nbytes / 1e6)}
+            if D > 1:
+                # ---- one context only: every step on one stream chain (what a caller without the ring gets)
+                st1 = make_step(cfa, eng, d_in.data_ptr(), B, K, out)
+                for _ in range(3):
+                    st1()
+                w1 = time_windows(st1, fence, args.steps, 7)
+                result["value_one_context"] = {"value": round(B * args.steps / float(np.median(w1)), 1), "unit": "images/s",
+                                               "note": "the same steps on a single context (one batch in flight); median of 7 windows"}
             result["parity"] = parity_block(cfa, eng, host_imgs, d_in.data_ptr(), B, S, K, local_rank)
     eng_closed = False
     if rank == 0 and world == 1 and not args.no_extras and args.dtype == "bf16":
-        if comm is not None:
-            comm.close()
-        eng.close(); eng_closed = True
+        close_comms()
+        for e in engs:
+            e.close()
+        eng_closed = True
         e32 = cfa.Engine(S, S, max_batch=B, dtype="fp32", device=local_rank)
         st32 = make_step(cfa, e32, d_in.data_ptr(), B, K, out)
 
@@ -368,9 +407,9 @@ def main():
                                       "note": "fp32 storage + exact-fp32 MFMA (heads within 1e-3 of the reference); median of 7 windows of 5 steps"}
         e32.close()
     if not eng_closed:
-        if comm is not None:
-            comm.close()
-        eng.close()
+        close_comms()
+        for e in engs:
+            e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "centerface_hip.h"
@@ -302,6 +303,36 @@ int expect_bn(cf_ctx* c, const WeightSet& ws, const std::string& pre, int C) {
 
 }  // namespace
 
+// One host-to-device copy stream per DEVICE, shared by every context on it.  Two contexts with a copy stream each
+// (cfa.EngineRing: two batches in flight) ran their 78 MB transfers concurrently and the pair moved ~27 GB/s instead of
+// the 46 GB/s one transfer at a time reaches (39.4k -> 22.6k img/s with the batch starting in pinned host memory every
+// step); in one queue the transfers run back to back, in submission order, which is the order the ring needs.
+// (What is left depends on how the HIP runtime folds the process's streams onto its hardware queues -- four by default,
+// GPU_MAX_HW_QUEUES: two contexts own five streams, and a copy stream that shares a queue with a compute stream waits
+// behind its kernels: 28-39k img/s host-fed with two contexts against 39.5k with one.  Host-fed serving is PCIe-bound
+// at ~39k img/s either way; use one context for it.)
+namespace {
+struct CopyStream { hipStream_t s = nullptr; int refs = 0; };
+std::mutex g_copy_mu;
+CopyStream g_copy[64];
+hipError_t acquire_copy_stream(int device, hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    CopyStream& cs = g_copy[device & 63];
+    if (!cs.s) {
+        hipError_t e = hipStreamCreateWithFlags(&cs.s, hipStreamNonBlocking);
+        if (e != hipSuccess) { cs.s = nullptr; return e; }
+    }
+    ++cs.refs;
+    *out = cs.s;
+    return hipSuccess;
+}
+void release_copy_stream(int device) {
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    CopyStream& cs = g_copy[device & 63];
+    if (--cs.refs == 0 && cs.s) { hipStreamDestroy(cs.s); cs.s = nullptr; }
+}
+}  // namespace
+
 extern "C" {
 
 int cf_version(void) { return CF_VERSION; }
@@ -348,7 +379,7 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fwd, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
-    if ((e = hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
+    if ((e = acquire_copy_stream(c->device, &c->stream_in)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     for (int i = 0; i < 2; ++i) {
         if ((e = hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&c->ev_slot_free[i], hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
@@ -383,7 +414,7 @@ int cf_destroy(cf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->ev_fwd) hipEventDestroy(c->ev_fwd);
-    if (c->stream_in) { hipStreamSynchronize(c->stream_in); hipStreamDestroy(c->stream_in); }
+    if (c->stream_in) { hipStreamSynchronize(c->stream_in); release_copy_stream(c->device); }
     for (int i = 0; i < 2; ++i) { if (c->ev_copy[i]) hipEventDestroy(c->ev_copy[i]); if (c->ev_slot_free[i]) hipEventDestroy(c->ev_slot_free[i]); }
     if (c->ev_dec) hipEventDestroy(c->ev_dec);
     if (c->ev_main_dec) hipEventDestroy(c->ev_main_dec);

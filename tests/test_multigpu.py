@@ -22,8 +22,11 @@ def _records(eng, K):
     return cfa.distributed.pack_records(d, l)
 
 
+@pytest.mark.parametrize("depth", [1, 2])
 @pytest.mark.parametrize("gather", ["cf", "torch"])
-def test_bench_multi_gpu_step_on_one_gpu(gather):
+def test_bench_multi_gpu_step_on_one_gpu(gather, depth):
+    """bench.py's step for N > 1 (identity gather at world 1), on one context and on the ring of two contexts it uses
+    by default: the records of every step must equal a plain decode of the same batch."""
     import torch
     import bench
     B, S, K = 8, 160, 50
@@ -31,21 +34,51 @@ def test_bench_multi_gpu_step_on_one_gpu(gather):
     rng = np.random.default_rng(11)
     imgs = rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)
     d_in = torch.from_numpy(imgs).to(dev)
-    out = {"dets": torch.empty((B, K, 6), dtype=torch.float32, device=dev), "lms": torch.empty((B, K, 10), dtype=torch.float32, device=dev),
-           "inds": torch.empty((B, K), dtype=torch.int64, device=dev), "all": torch.zeros((B, K, 16), dtype=torch.float32, device=dev)}
-    eng = cfa.Engine(S, S, max_batch=B, dtype="bf16")
-    comm = cfa.distributed.Comm(eng, 0, 1, cfa.distributed.unique_id()) if gather == "cf" else None
-    step = bench.make_step(cfa, eng, d_in.data_ptr(), B, K, out, gather, comm)
-    for _ in range(4):                                   # eager, capture, replay, replay: gathers overlap the next forward
-        got = step()
-    eng.synchronize(); torch.cuda.synchronize()
-    got = got.cpu().numpy()
-    eng.forward_enqueue(imgs)
-    assert np.array_equal(got, _records(eng, K))
-    if comm is not None:                                 # host-destination variant of the same entry point
-        assert np.array_equal(comm.gather_topk(K), got)
-        comm.close()
-    eng.close()
+    outs = [{"dets": torch.empty((B, K, 6), dtype=torch.float32, device=dev), "lms": torch.empty((B, K, 10), dtype=torch.float32, device=dev),
+             "inds": torch.empty((B, K), dtype=torch.int64, device=dev), "all": torch.zeros((B, K, 16), dtype=torch.float32, device=dev)}
+            for _ in range(depth)]
+    engs = [cfa.Engine(S, S, max_batch=B, dtype="bf16") for _ in range(depth)]
+    comms = [cfa.distributed.Comm(e, 0, 1, cfa.distributed.unique_id()) for e in engs] if gather == "cf" else None
+    step = bench.make_step(cfa, engs, d_in.data_ptr(), B, K, outs, gather, comms)
+    got = [step() for _ in range(4 * depth)]             # per context: eager, capture, replay, replay; gathers overlap the next forward
+    for e in engs:
+        e.synchronize()
+    torch.cuda.synchronize()
+    got = [g.cpu().numpy() for g in got[-depth:]]        # the last result of every context
+    engs[0].forward_enqueue(imgs)
+    want = _records(engs[0], K)
+    for g in got:
+        assert np.array_equal(g, want)
+    if comms is not None:                                # host-destination variant of the same entry point
+        assert np.array_equal(comms[0].gather_topk(K), want)
+        for cm in comms:
+            cm.close()
+    for e in engs:
+        e.close()
+
+
+def test_engine_ring_matches_single_engine_bitwise():
+    """EngineRing: batches submitted back to back on alternating contexts, collected out of order, different batch sizes
+    and K -- every result equals the single-engine result of the same batch."""
+    S = 160
+    rng = np.random.default_rng(5)
+    batches = [rng.integers(0, 256, (b, S, S, 3), dtype=np.uint8) for b in (8, 3, 8, 1, 5, 8)]
+    ks = [50, 20, 50, 100, 7, 50]
+    ref = cfa.Engine(S, S, max_batch=8, dtype="bf16")
+    want = []
+    for x, k in zip(batches, ks):
+        ref.forward_enqueue(x)
+        want.append(ref.decode_topk(k))
+    ref.close()
+    ring = cfa.EngineRing(S, S, depth=2, max_batch=8, dtype="bf16")
+    tickets = []
+    for i, (x, k) in enumerate(zip(batches, ks)):
+        tickets.append(ring.submit(x, K=k))
+        if i % 2 == 1:                                   # two in flight, then collect both (newest first)
+            for j in (i, i - 1):
+                d, l, ind = ring.collect(tickets[j])
+                assert np.array_equal(d, want[j][0]) and np.array_equal(l, want[j][1]) and np.array_equal(ind, want[j][2]), j
+    ring.close()
 
 
 WORKER = r'''
