@@ -24,7 +24,7 @@ struct Scope {
     hipError_t err = hipSuccess;
     explicit Scope(int device) {
         err = hipSetDevice(device);
-        if (err == hipSuccess) err = hipStreamCreate(&s);
+        if (err == hipSuccess) err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);   // never the legacy stream (see upload() in cf_runtime.hip)
     }
     ~Scope() {
         if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }

@@ -273,7 +273,11 @@ int upload(cf_ctx* c, const std::vector<T>& host, T** dptr) {
     void* d = nullptr;
     HIPCHK(c, hipMalloc(&d, host.size() * sizeof(T) + 64));
     c->owned.push_back(d);
-    HIPCHK(c, hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    // on the context's own (non-blocking) stream, never the legacy stream: another thread may be capturing a forward
+    // graph of ITS context, and a legacy-stream copy would implicitly synchronise with it ("would make the legacy stream
+    // depend on a capturing stream")
+    HIPCHK(c, hipMemcpyAsync(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     *dptr = (T*)d;
     return CF_OK;
 }
@@ -281,7 +285,8 @@ int upload_bytes(cf_ctx* c, const std::vector<char>& host, void** dptr) {
     void* d = nullptr;
     HIPCHK(c, hipMalloc(&d, host.size() + 64));
     c->owned.push_back(d);
-    HIPCHK(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpyAsync(d, host.data(), host.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     *dptr = d;
     return CF_OK;
 }
@@ -400,8 +405,9 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
         size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256;
         if ((e = hipMalloc(&b.p, bytes)) != hipSuccess) return bail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "hipMalloc(activations)", e);
         // zero-initialised incl. the slack: kernels may over-read (never write) one 16-byte chunk
-        if ((e = hipMemset(b.p, 0, bytes)) != hipSuccess) return bail(CF_EHIP, "hipMemset(activations)", e);
+        if ((e = hipMemsetAsync(b.p, 0, bytes, c->stream)) != hipSuccess) return bail(CF_EHIP, "hipMemset(activations)", e);
     }
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(CF_EHIP, "hipMemset(activations)", e);
     if ((e = hipMalloc((void**)&c->hm_plane, (size_t)max_batch * (H / 4) * (W / 4) * sizeof(float))) != hipSuccess)
         return bail(CF_EHIP, "hipMalloc(hm_plane)", e);
     *out = c;
@@ -738,7 +744,8 @@ int ensure_topk_ws(cf_ctx* c, int K) {
     if (!c->keys) HIPCHK(c, hipMalloc((void**)&c->keys, HW * c->max_batch * sizeof(unsigned long long)));
     if (!c->key_count) {
         HIPCHK(c, hipMalloc((void**)&c->key_count, (size_t)c->max_batch * kTopkCountStride * sizeof(int)));
-        HIPCHK(c, hipMemset(c->key_count, 0, (size_t)c->max_batch * kTopkCountStride * sizeof(int)));       // the select kernel leaves it zero
+        HIPCHK(c, hipMemsetAsync(c->key_count, 0, (size_t)c->max_batch * kTopkCountStride * sizeof(int), c->stream));   // the select kernel leaves it zero
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     if (c->decK < K) {
         HIPCHK(c, hipStreamSynchronize(c->stream));           // a decode in flight may still write the old buffers

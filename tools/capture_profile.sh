@@ -23,8 +23,11 @@ timeout 300 python bench.py --size 1280 --topk 1000 --batch 4 --no-cpu-baseline 
 timeout 300 python bench.py --size 1280 --topk 1000 --batch 32 --no-cpu-baseline --no-extras > "$OUT/bench_1280_b32.json" 2>> "$OUT/bench.err"
 timeout 300 python tools/vga_buckets_bench.py > "$OUT/vga_buckets.json" 2>> "$OUT/bench.err"
 cd /tmp
+# kernel durations with ONE context (what bench.py's roofline block times with HIP events), then the default two-context ring
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k" -o k -- \
-    python "$ROOT/bench.py" --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras > "$OUT/prof_k.log" 2>&1
+    python "$ROOT/bench.py" --depth 1 --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras > "$OUT/prof_k.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k2" -o k -- \
+    python "$ROOT/bench.py" --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras > "$OUT/prof_k2.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_k1280" -o k -- \
     python "$ROOT/bench.py" --size 1280 --topk 1000 --batch 4 --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras > "$OUT/prof_k1280.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch" -o f -- \
@@ -37,6 +40,9 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA 
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM \
     --kernel-trace --output-format csv -d "$OUT/prof_sq" -o s -- \
     python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_sq.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS \
+    --kernel-trace --output-format csv -d "$OUT/prof_lds" -o l -- \
+    python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_lds.log" 2>&1
 find "$OUT" -name '*.csv' | head -20
 # keep the merge-back under 64 MiB: drop per-dispatch traces, keep stats + counters
 find "$OUT" -name '*kernel_trace.csv' -size +8M -delete

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--ops", help="tools/profile_ops.py --json output (per-launch table)")
     ap.add_argument("--bench", help="bench.py JSON line measured in the same run")
+    ap.add_argument("--stats2", help="kernel stats of the default two-context run")
+    ap.add_argument("--lds", help="counter_collection.csv of the SQ_LDS_* pass")
     a = ap.parse_args()
     out = os.path.join(REPO, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -70,7 +72,9 @@ def main():
              "Note: the decode kernels (`peak_collect_kernel`, `topk_select_kernel`) run on the context's second stream "
              "underneath the next forward (device-output decode in bench.py), so their durations here are stretched by "
              "sharing the chip; timed alone they are in the per-launch table below.", "",
-             "Source: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras` "
+             "Source: `rocprofv3 --kernel-trace --stats -- python bench.py --depth 1 --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras` "
+             "(ONE context, as bench.py's roofline block times the kernels; with the default ring of two contexts kernels of two "
+             "batches share the chip and every duration stretches -- second table) "
              "(kernel durations) and two `--pmc` passes over `tools/profile_ops.py` (FETCH_SIZE, WRITE_SIZE; "
              "read side doubled per the gfx950 note in MI355X_MICROARCH.md).", "",
              "| kernel | calls | avg us | % GPU time | HBM MB/launch (PMC) |", "|---|---:|---:|---:|---:|"]
@@ -81,6 +85,24 @@ def main():
         t = traffic.get(name)
         lines.append("| `%s` | %s | %.1f | %s | %s |" % (name, r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"],
                                                        ("%.1f" % (t["hbm_bytes_per_launch"] / 1e6)) if t else "-"))
+    if a.stats2:
+        shutil.copyfile(a.stats2, os.path.join(out, "%s_kernel_stats_two_contexts.csv" % a.tag))
+        lines += ["", "Two contexts (bench.py default, `--depth 2`): kernels of two batches overlap, durations are per kernel while sharing the chip:", "",
+                  "| kernel | calls | avg us | % GPU time |", "|---|---:|---:|---:|"]
+        for r in csv.DictReader(open(a.stats2)):
+            if r["Name"].startswith(("void cf::", "cf::")):
+                lines.append("| `%s` | %s | %.1f | %s |" % (r["Name"], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    if a.lds:
+        agg = {}
+        for r in csv.DictReader(open(a.lds)):
+            agg.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], 0.0)
+            agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        lines += ["", "LDS bank conflicts (`--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS` over `tools/profile_ops.py`):", "",
+                  "| kernel | conflict cycles / LDS active cycles | LDS cycles per LDS instruction |", "|---|---:|---:|"]
+        for k, v in agg.items():
+            if k.startswith(("void cf::", "cf::")) and v.get("SQ_INSTS_LDS", 0) > 0:
+                lines.append("| `%s` | %.2f | %.1f |" % (k, v.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, v.get("SQ_LDS_IDX_ACTIVE", 0)),
+                                                      v.get("SQ_LDS_IDX_ACTIVE", 0) / v["SQ_INSTS_LDS"]))
     if a.bench:
         lines += ["", "bench.py line of the same session:", "", "```", open(a.bench).read().strip(), "```"]
     if a.ops:
