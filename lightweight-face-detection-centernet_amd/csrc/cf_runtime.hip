@@ -518,10 +518,12 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
         } else if (op.kind == OP_STEM0) {
             static const bool px_off = getenv("CF_STEM0_KIND") && atoi(getenv("CF_STEM0_KIND")) == 0;
             const bool px = dt == CF_BF16 && !px_off;                 // second-generation kernel (cf_stem0.hip)
-            // bit 1 = XCD-aware tile order (CF_XCD_ORDER=1): it cuts the stem's input fetch from 252 to 79 MB per launch (the
-            // excess is halo lines fetched by up to three XCD L2s, served by the Infinity Cache) but the kernel is VALU-bound
-            // and runs 2-3 % SLOWER with it (profiles/r02_ablation.md), so the hardware's round-robin order is the default
-            static const bool swz_on = getenv("CF_XCD_ORDER") && atoi(getenv("CF_XCD_ORDER")) >= 1;
+            // bit 1 = XCD-aware tile order: it cuts the stem's input fetch from 252 to 79 MB per launch (the excess is halo
+            // lines fetched by up to three XCD L2s, served by the Infinity Cache).  The kernel is VALU-bound: alone on the
+            // chip it runs 2-3 % slower with it (profiles/r02_ablation.md), with two batches in flight (EngineRing, the
+            // benchmarked schedule) there is no difference (44.8k img/s either way) and the fabric traffic is a third: on by
+            // default, CF_XCD_ORDER=0 switches it off
+            static const bool swz_on = !getenv("CF_XCD_ORDER") || atoi(getenv("CF_XCD_ORDER")) >= 1;
             op.geo.kind = px ? (swz_on ? 3 : 1) : 0;
             std::vector<char> w(px ? stem0px_wstem_bytes() : stem_packed_bytes(dt)), wp(stem0_proj_bytes(dt));
             std::vector<float> wd(px ? stem0px_wdw_dwords() : 9 * 32), lut(768);

@@ -93,8 +93,8 @@ def main():
              "instruction per SIMD (transcendental %.2f, packed %.2f, dot2c %.2f, VOP3 / cvt_pk %.1f, plain VOP1/2 %.1f cycles;" %
              (COST["trans"], COST["pk"], COST["dot"], COST["vop3"], COST["plain"]),
              "LDS / VMEM / MFMA instructions charged one %.0f-cycle issue slot each) spread over %d SIMDs at %.1f GHz, against the" % (LDS_ISSUE, SIMDS, CLK / 1e9),
-             "measured duration.  `bound/measured` near 1 = the kernel runs at its own instruction-issue bound; the chip",
-             "clocks VALU-dense kernels below 2.4 GHz (DVFS), so ~0.85-0.9 is the practical ceiling.", "",
+             "measured duration.  `bound/measured` near 1 = the kernel runs at its own instruction-issue bound (rocm-smi shows",
+             "sclk 2375-2382 MHz and ~1225 W of the 1400 W cap while bench.py runs: the clock is not the gap).", "",
              "| kernel | M VALU | of which trans | M MFMA | M LDS | avg cost non-trans | issue-bound us | measured us | bound / measured |",
              "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
     for k, c in sorted(cnt.items(), key=lambda kv: -dur.get(kv[0], 0)):
