@@ -26,6 +26,7 @@
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace cf {
 
@@ -234,7 +235,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     if constexpr (!XRELOAD) load_x();
 
     // expand one halo pixel block: D[pixel][channel] = X . We^T, Swish, pixel pairs -> E
-    auto expand_block = [&](int ib, const u32x4* xfr, const u32x4* xhr, const char* wx) {
+    // The LAST halo block holds only VP = (IPX - 32 (NIB - 1)) / 2 real pixel pairs (2 of 16 on an 18x18 halo); the Swish and
+    // the store of a register pair whose pixels lie past the halo are skipped there (LASTB, compile-time per call site):
+    // 5-7 % of the expand-phase VALU work of the 3x3 kernels.
+    constexpr int VP = (IPX - 32 * (NIB - 1)) / 2;
+    auto expand_block = [&](auto lastb, int ib, const u32x4* xfr, const u32x4* xhr, const char* wx) {
+        constexpr bool LASTB = decltype(lastb)::value && VP < 16;
         if constexpr (PART) {
             const u32x4 wv = ld16(wx + (NBF * JX * 64 + lane) * 16);
             char* ecol = E + (NBF * 32 + (lane & 15)) * 4 + (unsigned)(ib * 16 + 2 * (lane >> 4)) * (unsigned)PITCH;
@@ -246,6 +252,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
                 // lane (channel n, row group g): rows 4g .. 4g+3 of the sub-block = pixel pairs 2g, 2g+1
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
+                    if (LASTB && sub * 8 + t >= VP) continue;     // pairs sub*8 + 2g + t, g = lane >> 4: none of them is real
                     f32x2 x2; x2.x = a4[2 * t]; x2.y = a4[2 * t + 1];
                     const f32x2 y2 = swish2_prescaled(x2);
                     *reinterpret_cast<uint32_t*>(ecol + (sub * 8 + t) * PITCH) =
@@ -271,13 +278,16 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
             uint32_t d[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
+                if (LASTB && (t & 1) + 4 * (t >> 1) >= VP) continue;      // pair (t & 1) + 4 (t >> 1) + 2 h: past the halo on both halves
                 f32x2 x2; x2.x = a[2 * t]; x2.y = a[2 * t + 1];
                 const f32x2 y2 = swish2_prescaled(x2);            // E' = -log2(e) swish(expand)
                 d[t] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int t = 0; t < 8; ++t) {
+                if (LASTB && (t & 1) + 4 * (t >> 1) >= VP) continue;
                 *reinterpret_cast<uint32_t*>(ecol + ((t & 1) + 4 * (t >> 1)) * PITCH) = d[t];
+            }
         }
     };
 
@@ -362,7 +372,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
 #pragma unroll
         for (int t = 0; t < MAXI; ++t) {
             const int ib = wave + NW * t;
-            if (ib < NIB) expand_block(ib, xf[t], xh[PART ? t : 0], wx);
+            if (t == (NIB - 1) / NW && ib == NIB - 1) expand_block(std::true_type{}, ib, xf[t], xh[PART ? t : 0], wx);   // only this round can hold it
+            else if (ib < NIB) expand_block(std::false_type{}, ib, xf[t], xh[PART ? t : 0], wx);
         }
         __syncthreads();
         if (!G::WDIRECT && q + 1 < nq) stage_weights(q + 1);
@@ -535,6 +546,8 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
         const bool more = ib + NW < NIB;
         bool vn = false;
         if (more) vn = load_x(ib + NW, xn);                        // next block's X under this block's math
+        // (skipping the activation of the padding pairs of the LAST halo block, as the fused kernel does, was measured here:
+        // the uniform branch breaks this loop's load/compute overlap and the kernels run 4-10 % slower)
 #pragma unroll
         for (int nbl = 0; nbl < NBE; ++nbl) {
             f32x16 a;

@@ -16,6 +16,7 @@
 //           (as cf_stem.hip), Swish -> E[pixel][32] in LDS; pixels outside the map are written as 0
 //           (the depthwise conv's ZeroPad2d(1,1,1,1) acts on the stem OUTPUT).
 //   phase 2 depthwise 3x3 + Swish per lane from LDS, feeding the project MFMA directly (cf_mbconv.hip).
+#include <type_traits>
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include "centerface_hip.h"
@@ -486,13 +487,21 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
             a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xg[t][c]),
                                                         __builtin_bit_cast(mfma_bf16x8, ws[c]), a, 0, 0, 0);
         char* ecol = E + pl * 4 + (unsigned)(ib * 16 + 2 * h) * (unsigned)S0P_PITCH;
+        // the last halo block (18 x 18 = 10 blocks + 4 pixels) holds VP = 2 real pixel pairs: the register pairs past them
+        // are neither activated nor stored (wave-uniform branch; only the round that can hold the last block tests it)
+        constexpr int VP = (S0_IPX - 32 * (S0P_NIB - 1)) / 2;
+        auto activate = [&](auto lastb) {
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-            f32x2 x2; x2.x = a[2 * tt]; x2.y = a[2 * tt + 1];
-            const f32x2 y2 = s0_swish2_prescaled(x2);
-            *reinterpret_cast<uint32_t*>(ecol + ((tt & 1) + 4 * (tt >> 1)) * S0P_PITCH) =
-                __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
-        }
+            for (int tt = 0; tt < 8; ++tt) {
+                if (decltype(lastb)::value && (tt & 1) + 4 * (tt >> 1) >= VP) continue;
+                f32x2 x2; x2.x = a[2 * tt]; x2.y = a[2 * tt + 1];
+                const f32x2 y2 = s0_swish2_prescaled(x2);
+                *reinterpret_cast<uint32_t*>(ecol + ((tt & 1) + 4 * (tt >> 1)) * S0P_PITCH) =
+                    __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y2.x, y2.y));
+            }
+        };
+        if (VP < 16 && t == (S0P_NIB - 1) / S0P_NW && ib == S0P_NIB - 1) activate(std::true_type{});
+        else activate(std::false_type{});
     }
     __syncthreads();
 
