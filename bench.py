@@ -120,6 +120,16 @@ def cpu_baseline(seconds, size, topk, imgs):
                       "%d threads of %d host cores)" % (n16, t16, n1, t1, size, size, topk, torch.get_num_threads(), host_cores)}
 
 
+def flush_c_stdio():
+    """Flush Python's and the C library's stdout buffers (librccl's banner must not land after the JSON line)."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                   # noqa: BLE001
+        pass
+
+
 def make_step(cfa, engs, d_in_ptr, B, K, outs, gather="none", comms=None):
     """One benchmark step as a closure: forward + top-K decode (+ gather) of one batch.
 
@@ -283,6 +293,7 @@ def main():
                 close_comms()
                 gather = "torch"
     step = make_step(cfa, engs, d_in.data_ptr(), B, K, outs, gather, comms if gather == "cf" else None)
+    flush_c_stdio()          # librccl prints a version banner through C stdio when a communicator is created: get it out now
 
     def fence():
         for e in engs:
@@ -418,7 +429,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds, S, K, host_imgs)
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result))
+        flush_c_stdio()
+        print(json.dumps(result), flush=True)       # the one JSON line, last on stdout
 
 
 if __name__ == "__main__":
