@@ -262,7 +262,8 @@ def main():
     out = outs[0]
     torch.cuda.synchronize()
 
-    engs = [cfa.Engine(S, S, max_batch=B, dtype=args.dtype, device=local_rank) for _ in range(D)]
+    ring = cfa.EngineRing(S, S, depth=D, max_batch=B, dtype=args.dtype, device=local_rank)   # contexts of alternating stream priority
+    engs = ring.engines
     eng = engs[0]
     gather, comms = "none", []
 

@@ -211,6 +211,15 @@ int cf_forward_trace(cf_ctx* ctx, const void* in, int in_format, int in_on_devic
  * device work (e.g. an RCCL all-gather of the decoded boxes on another stream) with stream/event waits
  * instead of cf_synchronize(). */
 int cf_get_streams(cf_ctx* ctx, void** main_stream, void** decode_stream);
+/* Two contexts with a batch in flight on each overlap their forwards on the GPU -- unless their MAIN streams were folded
+ * onto the same hardware queue (HIP maps a process's streams onto 4 queues; which one a new stream gets depends on every
+ * stream the process created before): then the two forwards run strictly one after the other (42 k instead of 46 k img/s
+ * at 64 x 640x640).  cf_streams_share_queue tells (a ~0.3 ms spin on a's main stream, an empty kernel on b's, both contexts
+ * idle); cf_reroll_streams replaces the context's main and decode streams by new ones (new streams are created BEFORE the
+ * old ones are destroyed, so they land on other queues; the context must be idle; captured graphs stay valid).  A host that
+ * keeps two contexts calls the pair in a loop once, at start-up (EngineRing does). */
+int cf_streams_share_queue(cf_ctx* a, cf_ctx* b, int* shared);
+int cf_reroll_streams(cf_ctx* ctx);
 /* hipGraph replay state: number of captured forward graphs held by the context, and how many
  * (input, format, batch) keys could not be captured and run as eager launches instead. */
 int cf_graph_stats(cf_ctx* ctx, int* n_graphs, int* n_uncapturable);

@@ -13,6 +13,7 @@ reference's ``weight/model_epoch_100.pt`` is not distributed), ``dtype=`` ('fp32
 ``detect_batch``, ``decode_topk`` (the ``ctdet_decode`` path of centerface_ext.py:52-82).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -246,6 +247,16 @@ class Engine(object):
         self._chk(self._L.cf_get_streams(self._h, C.byref(a), C.byref(b)))
         return a.value or 0, b.value or 0
 
+    def shares_queue_with(self, other):
+        """True when this context's main stream waits behind ``other``'s (same hardware queue).  Both must be idle."""
+        sh = C.c_int(0)
+        self._chk(self._L.cf_streams_share_queue(other._h, self._h, C.byref(sh)))
+        return bool(sh.value)
+
+    def reroll_streams(self):
+        """Replace the main and decode streams by newly created ones (cf_reroll_streams).  The context must be idle."""
+        self._chk(self._L.cf_reroll_streams(self._h))
+
     def graph_stats(self):
         """(captured forward graphs, keys that fell back to eager launches)."""
         a, b = C.c_int(), C.c_int()
@@ -304,6 +315,17 @@ class EngineRing(object):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.engines = [Engine(height, width, **engine_kwargs) for _ in range(int(depth))]
+        # HIP folds a process's streams onto four hardware queues; which queue a new stream gets depends on every stream the
+        # process created before.  When the MAIN streams of two contexts land on one queue their forwards run strictly one
+        # after the other (42.0k img/s instead of 45.8k at 64 x 640x640, 4 of 5 start-up arrangements tried): test the pairs
+        # and re-create the streams of the later context until no two main streams share a queue (profiles/r02_ablation.md).
+        self.queue_rerolls = 0
+        for i in range(1, len(self.engines)):
+            for _ in range(8):
+                if not any(self.engines[i].shares_queue_with(self.engines[j]) for j in range(i)):
+                    break
+                self.engines[i].reroll_streams()
+                self.queue_rerolls += 1
         self.depth = int(depth)
         self._n = 0
         self._out = [None] * self.depth               # per slot: (K, dets_ptr, lms_ptr, inds_ptr, B)

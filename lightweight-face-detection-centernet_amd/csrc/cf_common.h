@@ -135,6 +135,7 @@ template <int S, int TOH, int TOW, int IWP>
 struct LaneMap {
     static constexpr int NPIX = TOH * TOW, PPX = S == 1 ? NPIX / 2 : NPIX, WPP = (PPX + 63) / 64, NSLOT = WPP * 64;
     static constexpr int ROWW = S == 1 ? TOW / 2 : TOW;                     // class pixels per tile row
+    static_assert(ROWW <= 64 && TOH <= 256, "entry packing: 6 bits of x, 9 bits of y below the idle flag");
     uint16_t v[NSLOT];
     static constexpr int pair_index(int r) {                                // e of class pixel r (row-major)
         const int oy = r / ROWW, oxh = r - oy * ROWW;

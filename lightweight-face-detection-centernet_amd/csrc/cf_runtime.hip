@@ -308,6 +308,12 @@ int expect_bn(cf_ctx* c, const WeightSet& ws, const std::string& pre, int C) {
 
 }  // namespace
 
+// spins for `ticks` of the 100 MHz wall clock (cf_streams_share_queue)
+__global__ void cf_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) { }
+}
+
 // One host-to-device copy stream per DEVICE, shared by every context on it.  Two contexts with a copy stream each
 // (cfa.EngineRing: two batches in flight) ran their 78 MB transfers concurrently and the pair moved ~27 GB/s instead of
 // the 46 GB/s one transfer at a time reaches (39.4k -> 22.6k img/s with the batch starting in pinned host memory every
@@ -1217,6 +1223,46 @@ int cf_get_streams(cf_ctx* c, void** main_stream, void** decode_stream) {
     if (!c) return CF_EINVAL;
     if (main_stream) *main_stream = (void*)c->stream;
     if (decode_stream) *decode_stream = (void*)c->stream2;
+    return CF_OK;
+}
+
+int cf_streams_share_queue(cf_ctx* a, cf_ctx* b, int* shared) {
+    if (!a || !b || !shared || a == b) return CF_EINVAL;
+    if (a->device != b->device) { *shared = 0; return CF_OK; }
+    HIPCHK(a, hipSetDevice(a->device));
+    HIPCHK(a, hipStreamSynchronize(a->stream));
+    HIPCHK(a, hipStreamSynchronize(b->stream));
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+    HIPCHK(a, hipEventCreate(&e0)); HIPCHK(a, hipEventCreate(&ea)); HIPCHK(a, hipEventCreate(&eb));
+    // ~0.3 ms spin on a's main stream, then an empty kernel on b's: on one hardware queue the second waits for the first
+    HIPCHK(a, hipEventRecord(e0, a->stream));
+    hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, a->stream, (long long)30000);
+    HIPCHK(a, hipEventRecord(ea, a->stream));
+    hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, b->stream, (long long)0);
+    HIPCHK(a, hipEventRecord(eb, b->stream));
+    HIPCHK(a, hipStreamSynchronize(a->stream));
+    HIPCHK(a, hipStreamSynchronize(b->stream));
+    float ta = 0.0f, tb = 0.0f;
+    HIPCHK(a, hipEventElapsedTime(&ta, e0, ea));
+    HIPCHK(a, hipEventElapsedTime(&tb, e0, eb));
+    hipEventDestroy(e0); hipEventDestroy(ea); hipEventDestroy(eb);
+    *shared = tb > 0.5f * ta ? 1 : 0;
+    return CF_OK;
+}
+
+int cf_reroll_streams(cf_ctx* c) {
+    if (!c) return CF_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    HIPCHK(c, hipStreamSynchronize(c->stream_in));
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    HIPCHK(c, hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));     // new ones first: the old ones still hold their queues
+    HIPCHK(c, hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2);
+    c->stream = s1; c->stream2 = s2;
+    c->dec_pending = false; c->main_dec_pending = false;               // everything was drained above
+    for (int i = 0; i < 2; ++i) c->slot_busy[i] = false;
     return CF_OK;
 }
 

@@ -71,6 +71,8 @@ def test_engine_ring_matches_single_engine_bitwise():
         want.append(ref.decode_topk(k))
     ref.close()
     ring = cfa.EngineRing(S, S, depth=2, max_batch=8, dtype="bf16")
+    # the two main streams must not sit on one hardware queue (their forwards would serialise); EngineRing re-rolls until they do not
+    assert not ring.engines[1].shares_queue_with(ring.engines[0])
     tickets = []
     for i, (x, k) in enumerate(zip(batches, ks)):
         tickets.append(ring.submit(x, K=k))
@@ -78,6 +80,14 @@ def test_engine_ring_matches_single_engine_bitwise():
             for j in (i, i - 1):
                 d, l, ind = ring.collect(tickets[j])
                 assert np.array_equal(d, want[j][0]) and np.array_equal(l, want[j][1]) and np.array_equal(ind, want[j][2]), j
+    # streams re-created after graphs were captured and results are in flight: everything still valid
+    t = ring.submit(batches[0], K=ks[0])
+    ring.engines[t[0]].reroll_streams()
+    d, l, ind = ring.collect(t)
+    assert np.array_equal(d, want[0][0]) and np.array_equal(ind, want[0][2])
+    t = ring.submit(batches[0], K=ks[0])
+    d, l, ind = ring.collect(t)
+    assert np.array_equal(d, want[0][0]) and np.array_equal(l, want[0][1]) and np.array_equal(ind, want[0][2])
     ring.close()
 
 
