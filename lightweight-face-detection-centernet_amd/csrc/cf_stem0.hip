@@ -403,21 +403,29 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
             const int cy = min(max(iy0 + rg + it * RG, 0), p.H - 1);
             v[it] = *reinterpret_cast<const uint32_t*>((const uint8_t*)p.x + ((size_t)b * p.H + cy) * p.W * 3 + cboff);
         }
+        // Interior tiles (81 % at 640x640: the whole patch inside the image) need no zero-padding selects.  Elements of the
+        // dword columns that lie outside the PATCH then hold neighbouring pixels instead of 0: nothing reads them except
+        // k-slots whose stem weight is zero (stem0px_pack), and they are finite.
+        const bool interior = iy0 >= 0 && iy0 + S0_PH <= p.H && ix0 * 3 - 2 >= 0 && ix0 * 3 - 2 + 4 * ND <= p.W * 3;
+        auto convert = [&](auto inside) {
 #pragma unroll
-        for (int it = 0; it < NITD; ++it) {
-            const int r = rg + it * RG, iy = iy0 + r;
-            const bool rowok = (unsigned)iy < (unsigned)p.H;
-            float f[4];
+            for (int it = 0; it < NITD; ++it) {
+                const int r = rg + it * RG, iy = iy0 + r;
+                const bool rowok = (unsigned)iy < (unsigned)p.H;
+                float f[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float u = (float)((v[it] >> (8 * i)) & 0xffu);                 // v_cvt_f32_ubyteN
-                f[i] = (rowok && bok[i]) ? fmaf(u, sc[i], sh[i]) : 0.0f;
+                for (int i = 0; i < 4; ++i) {
+                    const float u = (float)((v[it] >> (8 * i)) & 0xffu);             // v_cvt_f32_ubyteN
+                    const float nv = fmaf(u, sc[i], sh[i]);
+                    f[i] = (decltype(inside)::value || (rowok && bok[i])) ? nv : 0.0f;
+                }
+                if (tact && r < S0_PH) {
+                    u32x2 o; o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(Xs) + r * (S0P_PROW * 2) + d * 8) = o;
+                }
             }
-            if (tact && r < S0_PH) {
-                u32x2 o; o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
-                *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(Xs) + r * (S0P_PROW * 2) + d * 8) = o;
-            }
-        }
+        };
+        if (interior) convert(std::true_type{}); else convert(std::false_type{});
     } else {
         constexpr int ECOLS = S0_PW * 3, RSTEP = S0P_NT / ECOLS, NIT = (S0_PH + RSTEP - 1) / RSTEP;
         const int e = tid % ECOLS, r0 = tid / ECOLS;
@@ -450,6 +458,10 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
     for (int c = 0; c < 2; ++c) ws[c] = ld16((const char*)p.wstem + ((size_t)c * 64 + lane) * 16);
     constexpr int MAXB = (S0P_NIB + S0P_NW - 1) / S0P_NW;           // 3 halo pixel blocks per wave
     u32x4 xg[MAXB][2];
+    // tiles whose whole 18 x 18 halo lies inside the H/2 x W/2 map need no zero-padding selects either (the lanes past the
+    // halo in the last block then carry a copy of its last pixel: their results are never activated or stored)
+    const bool halo_inside = oy0 >= 1 && oy0 + S0_TOH + 1 <= Ho && ox0 >= 1 && ox0 + S0_TOW + 1 <= Wo;
+    auto gather = [&](auto inside) {
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
         const int ib = wave + S0P_NW * t;
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
         const int ty = ipc / S0_IW, tx = ipc - ty * S0_IW;
         const int y = oy0 - 1 + ty, x = ox0 - 1 + tx;
         // a halo pixel outside the map is the depthwise conv's zero padding: zero operand row -> swish(0) = 0
-        const bool inmap = ip < S0_IPX && (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo;
+        const bool inmap = decltype(inside)::value || (ip < S0_IPX && (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo);
         // eight aligned dword reads per lane, already in operand order (see stem0px_pack): no packing ops
         const char* xp = reinterpret_cast<const char*>(Xs) + ((2 * ty) * S0P_PROW + (2 * tx) * 3 + 2) * 2;
 #pragma unroll
@@ -474,6 +486,8 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
             xg[t][c].x = w4[0]; xg[t][c].y = w4[1]; xg[t][c].z = w4[2]; xg[t][c].w = w4[3];
         }
     }
+    };
+    if (halo_inside) gather(std::true_type{}); else gather(std::false_type{});
     __syncthreads();                                              // every wave has its operands: Xs may be overwritten
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
