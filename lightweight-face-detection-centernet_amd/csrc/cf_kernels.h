@@ -34,6 +34,9 @@ struct PwParams {
     // channel-addressed output (ShuffleV2 concat, model/blocks.py:47-54): y rows have ldy elements and this conv
     // writes channels [yoff, yoff + N) of them; ldy = 0 means a dense [M][N] output.  Plain pw_kernel only.
     int ldy, yoff;
+    // x in PIXEL-BLOCK order (bf16 only): [m / 32][K / 8][m % 32][8 channels], what expdw_px_kernel writes with
+    // MbParams::yblock -- the 32 lanes of a wave half then read one contiguous 512-byte run per k-step instead of 32 rows
+    int xblock;
 };
 // out[m][c] = x[m][2 c + phase], c < C: the pass-through half of channel_shuffle (model/blocks.py:56-62) written
 // straight into its slice of the block output (rows of ldy elements, channel offset yoff)
@@ -77,6 +80,7 @@ struct MbParams {
     size_t lds_bytes;
     int nw;               // mbconv_px_kernel: 1 = XCD-aware tile order (set by the launcher)
     int kind;             // MbGeom::kind
+    int yblock;           // expdw_px_kernel: write y in pixel-block order [m / 32][hid / 8][m % 32][8] (PwParams::xblock)
 };
 hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p);
 // cf_mbconv2.hip
@@ -232,6 +236,7 @@ hipError_t launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int
 // layout converters used by cf_get_heads and the per-op test entry points
 hipError_t launch_nchw_to_nhwc(hipStream_t s, int dtype, const float* src /*f32 NCHW*/, void* dst /*T NHWC*/,
                                int B, int C, int H, int W);
+hipError_t launch_blocked_to_nchw(hipStream_t s, const void* src /*bf16, pixel-block order*/, float* dst /*f32 NCHW*/, int B, int C, int H, int W);
 hipError_t launch_nhwc_to_nchw(hipStream_t s, int dtype, const void* src /*T NHWC*/, float* dst /*f32 NCHW*/,
                                int B, int C, int H, int W);
 

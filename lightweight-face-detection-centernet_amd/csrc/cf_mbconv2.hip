@@ -588,7 +588,11 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
     const char* eb0 = E + (unsigned)(((oy * S) * IWP + (ox * S - par)) / 2) * (unsigned)PITCH;
     const int gy = oy0 + oy, gx = ox0 + ox;
     const bool store = live && gy < p.Hout && gx < p.Wout;
-    char* out = (char*)p.y + ((((size_t)b * p.Hout + gy) * p.Wout + gx) * p.hid + (size_t)grp * HC) * 2;
+    // NHWC rows, or pixel-block order for the project GEMM that follows (PwParams::xblock): chunk stride 16 / 512 bytes
+    const size_t opix = ((size_t)b * p.Hout + gy) * p.Wout + gx;
+    const size_t ostep = p.yblock ? 512 : 16;
+    char* out = p.yblock ? (char*)p.y + ((opix >> 5) * (size_t)(p.hid / 8) * 32 + (opix & 31)) * 16 + (size_t)grp * (HC / 8) * 512
+                         : (char*)p.y + (opix * p.hid + (size_t)grp * HC) * 2;
     const CF_AS4 u32x8* wtab = (const CF_AS4 u32x8*)p.wdw;
 #pragma unroll
     for (int c = 0; c < HC / 8; ++c) {
@@ -623,7 +627,7 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
             const f32x2 y = swish2_prescaled(u) * kNegLn2;
             a8[i] = y.x; a8[i + 1] = y.y;
         }
-        if (store) st16(out + c * 16, pack16<bf16_t>(a8));
+        if (store) st16(out + c * ostep, pack16<bf16_t>(a8));
     }
 }
 

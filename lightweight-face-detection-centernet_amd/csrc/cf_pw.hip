@@ -98,7 +98,11 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
     const int NB = (p.N + 31) >> 5;
     const int nb0 = blockIdx.y * NBW;
 
-    const char* xrow = (const char*)p.x + (size_t)mr * p.K * sizeof(T) + (size_t)h * NCh * 16;
+    // x rows [m][K], or pixel-block order [m / 32][K / 8][m % 32][8] (xblock): consecutive 16-byte chunks of a pixel are then
+    // 512 bytes apart and the 32 lanes of a wave half read one contiguous 512-byte run
+    const size_t xs = p.xblock ? 512 : 16;
+    const char* xrow = p.xblock ? (const char*)p.x + (((size_t)pb * NC + (size_t)h * NCh) * 32 + pl) * 16
+                                : (const char*)p.x + (size_t)mr * p.K * sizeof(T) + (size_t)h * NCh * 16;
     const char* wbase = (const char*)p.wp + ((size_t)nb0 * NCh * 64 + lane) * 16;
     const int jmax = (h == 0) ? NCh : NC - NCh;               // valid chunks of this half
 
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + u < NCh ? j0 + u : NCh - 1;
-            xc[u] = ld16(xrow + (size_t)(j < jmax ? j : 0) * 16);
+            xc[u] = ld16(xrow + (size_t)(j < jmax ? j : 0) * xs);
 #pragma unroll
             for (int i = 0; i < NBW; ++i)
                 wc[u][i] = ld16(wbase + ((size_t)(i < nbv ? i : 0) * NCh + j) * 1024);
@@ -196,7 +200,10 @@ __global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
     const int NC = (int)((size_t)p.K * sizeof(T) / 16), NCh = (NC + 1) >> 1;
     const int NB = (p.N + 31) >> 5;
     const int nb0 = blockIdx.y * NBW;
-    const char* xrow = (const char*)p.x + (size_t)mr * p.K * sizeof(T) + (size_t)h * NCh * 16;
+    const size_t xs = p.xblock ? 512 : 16;                        // pixel-block order: see pw_kernel
+    const long long pbc = pb * 32 < p.M ? pb : (p.M - 1) / 32;    // waves past the last block read it again (results unused)
+    const char* xrow = p.xblock ? (const char*)p.x + (((size_t)pbc * NC + (size_t)h * NCh) * 32 + pl) * 16
+                                : (const char*)p.x + (size_t)mr * p.K * sizeof(T) + (size_t)h * NCh * 16;
     const int jmax = (h == 0) ? NCh : NC - NCh;
 
     f32x16 acc[NBW];
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
         // half's share is read from a clamped address and meets ZERO weights (pw_pack_weights leaves the
         // fragment of a missing chunk zero); whole k-steps past NCh are skipped at consumption
 #pragma unroll
-        for (int jj = 0; jj < KT; ++jj) xn[jj] = ld16(xrow + (size_t)(j0 + jj < jmax ? j0 + jj : 0) * 16);
+        for (int jj = 0; jj < KT; ++jj) xn[jj] = ld16(xrow + (size_t)(j0 + jj < jmax ? j0 + jj : 0) * xs);
     };
     const int nbv = NB - nb0 < NBW ? NB - nb0 : NBW;
     u32x4 xr[NST][KT];

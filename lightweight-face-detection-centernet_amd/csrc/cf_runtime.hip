@@ -58,6 +58,9 @@ struct Op {
     // IDAUp stage 3 fused into the head kernel (cf_uphead.hip): the OP_PW op keeps its weights but is not
     // launched (fused_away); the OP_HEAD op launches the fused kernel with its partner's operands
     bool fused_away = false; int partner = -1;
+    // expand+dw -> project pairs (bf16): the depthwise tensor between them is kept in pixel-block order
+    // [m / 32][hid / 8][m % 32][8] (MbParams::yblock / PwParams::xblock): the project GEMM's activation loads coalesce
+    bool blocked = false;
 };
 
 struct Buf { std::string name; size_t elems = 0; bool f32 = false; void* p = nullptr; };
@@ -187,6 +190,8 @@ void build_plan(cf_ctx* c) {
                 m.k = k; m.s = s; m.pad_lo = p / 2; m.geo = xg;
                 m.wkey = std::string(pre) + ".conv.0.1.weight"; m.wkey_dw = std::string(pre) + ".conv.1.1.weight";
                 m.macs = (double)curH * curW * cin * hid + (double)Ho * Wo * hid * k * k;
+                static const bool blk_off = getenv("CF_PW_XBLOCK") && atoi(getenv("CF_PW_XBLOCK")) == 0;      // A/B
+                m.blocked = !blk_off && hid <= 960;
                 push(m);
                 j = 1;
             } else {
@@ -204,6 +209,7 @@ void build_plan(cf_ctx* c) {
             push(d);
             }
             Op pr; pr.kind = OP_PW; pr.name = std::string(pre) + ".project"; pr.in = D; pr.out = dst;
+            pr.blocked = !c->ops.empty() && c->ops.back().kind == OP_EXPDW && c->ops.back().blocked;
             pr.res = residual ? cur : -1;
             pr.Hin = pr.Hout = Ho; pr.Win = pr.Wout = Wo; pr.Cin = hid; pr.Cout = cout; pr.act = 0;
             pr.wkey = std::string(pre) + ".conv." + std::to_string(j + 1) + ".weight";
@@ -408,7 +414,9 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
     c->buf_resized = add_buf(c, "input_resized", false);
     need(c, c->buf_resized, ((size_t)3 * H * W + elem_size(dtype) - 1) / elem_size(dtype));
     for (auto& b : c->bufs) {
-        size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256;
+        // + slack: kernels may over-read one 16-byte chunk; a tensor in pixel-block order is padded to whole 32-pixel blocks
+        // (at most 31 pixels x 960 channels x 2 bytes)
+        size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256 + (b.name == "depthwise" ? (size_t)32 * 960 * 2 : 0);
         if ((e = hipMalloc(&b.p, bytes)) != hipSuccess) return bail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "hipMalloc(activations)", e);
         // zero-initialised incl. the slack: kernels may over-read (never write) one 16-byte chunk
         if ((e = hipMemsetAsync(b.p, 0, bytes, c->stream)) != hipSuccess) return bail(CF_EHIP, "hipMemset(activations)", e);
@@ -646,6 +654,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
             PwParams p{}; p.x = bp(op.in); p.wp = op.wp; p.bias = op.bias; p.res = bp(op.res); p.y = bp(op.out);
             p.M = (long long)B * op.Hout * op.Wout; p.K = op.Cin; p.N = op.Cout; p.act = op.act;
             p.low = bp(op.low); p.upw = op.upw; p.upb = op.upb; p.Ho = op.Hout; p.Wo = op.Wout;
+            p.xblock = op.blocked ? 1 : 0;
             return launch_pw(c->stream, c->dtype, p);
         }
         case OP_STEM0: {
@@ -659,7 +668,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
             p.B = B; p.Hin = op.Hin; p.Win = op.Win; p.Hout = op.Hout; p.Wout = op.Wout; p.Cin = op.Cin; p.hid = op.hid; p.Cout = op.Cout;
             p.k = op.k; p.s = op.s; p.pad_lo = op.pad_lo; p.residual = op.residual ? 1 : 0;
             p.HC = op.geo.HC; p.nq = op.geo.nq; p.NBE = op.geo.NBE; p.JX = op.geo.JX; p.HALF = op.geo.HALF; p.rowb = op.geo.rowb;
-            p.lds_bytes = op.geo.lds_bytes; p.kind = op.geo.kind;
+            p.lds_bytes = op.geo.lds_bytes; p.kind = op.geo.kind; p.yblock = (op.kind == OP_EXPDW && op.blocked) ? 1 : 0;
             return launch_mbconv(c->stream, c->dtype, p);
         }
         case OP_HEAD: {
@@ -1169,7 +1178,9 @@ int cf_forward_trace(cf_ctx* c, const void* in, int in_format, int in_on_device,
     const size_t n = (size_t)B * C * op.Hout * op.Wout;
     float* tmp = nullptr;
     HIPCHK(c, hipMalloc((void**)&tmp, n * sizeof(float)));
-    hipError_t e = launch_nhwc_to_nchw(c->stream, head ? CF_F32 : c->dtype, c->bufs[op.out].p, tmp, B, C, op.Hout, op.Wout);
+    hipError_t e = (op.kind == OP_EXPDW && op.blocked)
+        ? launch_blocked_to_nchw(c->stream, c->bufs[op.out].p, tmp, B, C, op.Hout, op.Wout)
+        : launch_nhwc_to_nchw(c->stream, head ? CF_F32 : c->dtype, c->bufs[op.out].p, tmp, B, C, op.Hout, op.Wout);
     if (e == hipSuccess) e = hipMemcpyAsync(out_nchw, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
