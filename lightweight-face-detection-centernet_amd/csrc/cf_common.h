@@ -98,6 +98,10 @@ __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 __device__ __forceinline__ u32x4 zero16() { u32x4 z; z.x = z.y = z.z = z.w = 0u; return z; }
 
+// byte offset of the 16-byte chunk `chunk` (8 bf16 channels) of pixel m in pixel-block order [m / 32][nchunks][m % 32][8]
+__device__ __forceinline__ size_t blk_off(size_t m, int nchunks, int chunk) {
+    return ((m >> 5) * (size_t)nchunks + (size_t)chunk) * 512 + (m & 31) * 16;
+}
 typedef __attribute__((ext_vector_type(8))) uint32_t u32x8_t;
 // First tap of the eight accumulators: A[i] = w . e + 0 as the three-address VOP3P v_dot2_f32_f16 with an inline-constant
 // addend.  (The builtin selects the two-address v_dot2c_f32_f16 and has to zero the accumulator with a v_mov first:

@@ -37,6 +37,8 @@ struct PwParams {
     // x in PIXEL-BLOCK order (bf16 only): [m / 32][K / 8][m % 32][8 channels], what expdw_px_kernel writes with
     // MbParams::yblock -- the 32 lanes of a wave half then read one contiguous 512-byte run per k-step instead of 32 rows
     int xblock;
+    int yblock;           // y written in pixel-block order [m / 32][N / 8][m % 32][8] (bf16; dense output only)
+    int resblock;         // res read in pixel-block order
 };
 // out[m][c] = x[m][2 c + phase], c < C: the pass-through half of channel_shuffle (model/blocks.py:56-62) written
 // straight into its slice of the block output (rows of ldy elements, channel offset yoff)
@@ -80,7 +82,9 @@ struct MbParams {
     size_t lds_bytes;
     int nw;               // mbconv_px_kernel: 1 = XCD-aware tile order (set by the launcher)
     int kind;             // MbGeom::kind
-    int yblock;           // expdw_px_kernel: write y in pixel-block order [m / 32][hid / 8][m % 32][8] (PwParams::xblock)
+    int yblock;           // y (expdw: the depthwise tensor; mbconv_px: the block output) in pixel-block order
+                          // [m / 32][C / 8][m % 32][8], m = linear pixel index over the batch (PwParams::xblock)
+    int xblock;           // expdw_px_kernel: x in pixel-block order
 };
 hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p);
 // cf_mbconv2.hip

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = r[e] + v[e];
                 }
-                st16((char*)p.y + (opix * p.Cout + ch) * 2, pack16<bf16_t>(v));
+                st16((char*)p.y + (p.yblock ? blk_off(opix, p.Cout / 8, ch / 8) : (opix * p.Cout + ch) * 2), pack16<bf16_t>(v));
             }
         }
     }
@@ -523,9 +523,15 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
         const int iy = ipc / IWP, ix = ipc - iy * IWP;
         const int gy = oy0 * S - p.pad_lo + iy, gx = ox0 * S - p.pad_lo + ix;
         const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
-        const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
+        if (p.xblock) {        // pixel-block order: 32 neighbouring halo pixels read one 512-byte run per chunk
+            const char* xb = (const char*)p.x + blk_off(((size_t)b * p.Hin + cy) * p.Win + cx, p.Cin / 8, h * JX);
 #pragma unroll
-        for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
+            for (int j = 0; j < JX; ++j) xf[j] = ld16(xb + j * 512);
+        } else {
+            const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
+        }
         return ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
     };
     auto mask_x = [&](u32x4* xf, bool valid) {

@@ -60,7 +60,9 @@ struct Op {
     bool fused_away = false; int partner = -1;
     // expand+dw -> project pairs (bf16): the depthwise tensor between them is kept in pixel-block order
     // [m / 32][hid / 8][m % 32][8] (MbParams::yblock / PwParams::xblock): the project GEMM's activation loads coalesce
-    bool blocked = false;
+    // The same order for the block outputs of layer3.1 ... layer6.0 (layout_pass): in / out / res say which operands of
+    // this launch are in block order.
+    bool in_blk = false, out_blk = false, res_blk = false;
 };
 
 struct Buf { std::string name; size_t elems = 0; bool f32 = false; void* p = nullptr; };
@@ -120,6 +122,43 @@ int add_buf(cf_ctx* c, const char* name, bool f32 = false) {
     return (int)c->bufs.size() - 1;
 }
 void need(cf_ctx* c, int id, size_t elems) { if (c->bufs[id].elems < elems) c->bufs[id].elems = elems; }
+
+// Pixel-block order for block outputs: the input of an expand+depthwise kernel is read as MFMA operand fragments (lane =
+// halo pixel, 16 bytes per k-step) by EVERY hidden-chunk workgroup of the tile; from NHWC rows each such load touches 64
+// cache lines.  If the tensor's producer can write block order (a project GEMM or a bf16 fused MBConv kernel) and all of its
+// readers can read it (expand+dw input, GEMM input, GEMM residual), the tensor is kept in block order instead.
+void layout_pass(cf_ctx* c) {
+    static const bool off = getenv("CF_IN_XBLOCK") && atoi(getenv("CF_IN_XBLOCK")) == 0;      // A/B
+    if (off || c->dtype != CF_BF16) return;
+    auto& ops = c->ops;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        if (ops[i].kind != OP_EXPDW || !ops[i].out_blk || ops[i].in_blk || (ops[i].Cin % 8)) continue;
+        const int buf = ops[i].in;
+        int j = (int)i - 1;
+        while (j >= 0 && ops[j].out != buf) --j;
+        if (j < 0) continue;
+        Op& pr = ops[j];
+        const bool can_write = !pr.fused_away && pr.low < 0 &&
+                               ((pr.kind == OP_PW && pr.bnkey.empty()) || (pr.kind == OP_MB && pr.geo.kind == 1));
+        if (!can_write) continue;
+        bool ok = true;
+        size_t end = j + 1;
+        for (; end < ops.size() && ops[end].out != buf; ++end) {
+            const Op& r = ops[end];
+            if (r.low == buf) ok = false;
+            if (r.in == buf && !(r.kind == OP_EXPDW || r.kind == OP_PW) ) ok = false;
+            if (r.kind == OP_MB && r.in == buf) ok = false;
+            if (r.kind == OP_HEAD && r.partner >= 0 && (ops[r.partner].in == buf || ops[r.partner].low == buf)) ok = false;
+            if (r.fused_away && (r.in == buf || r.low == buf)) ok = false;          // read by the fused up3+heads kernel
+        }
+        if (!ok) continue;
+        pr.out_blk = true;
+        for (size_t k = j + 1; k < end; ++k) {
+            if (ops[k].in == buf) ops[k].in_blk = true;
+            if (ops[k].res == buf) ops[k].res_blk = true;
+        }
+    }
+}
 
 void build_plan(cf_ctx* c) {
     const int H = c->H, W = c->W;
@@ -191,7 +230,7 @@ void build_plan(cf_ctx* c) {
                 m.wkey = std::string(pre) + ".conv.0.1.weight"; m.wkey_dw = std::string(pre) + ".conv.1.1.weight";
                 m.macs = (double)curH * curW * cin * hid + (double)Ho * Wo * hid * k * k;
                 static const bool blk_off = getenv("CF_PW_XBLOCK") && atoi(getenv("CF_PW_XBLOCK")) == 0;      // A/B
-                m.blocked = !blk_off && hid <= 960;
+                m.out_blk = !blk_off && hid <= 960;
                 push(m);
                 j = 1;
             } else {
@@ -209,7 +248,7 @@ void build_plan(cf_ctx* c) {
             push(d);
             }
             Op pr; pr.kind = OP_PW; pr.name = std::string(pre) + ".project"; pr.in = D; pr.out = dst;
-            pr.blocked = !c->ops.empty() && c->ops.back().kind == OP_EXPDW && c->ops.back().blocked;
+            pr.in_blk = !c->ops.empty() && c->ops.back().kind == OP_EXPDW && c->ops.back().out_blk;
             pr.res = residual ? cur : -1;
             pr.Hin = pr.Hout = Ho; pr.Win = pr.Wout = Wo; pr.Cin = hid; pr.Cout = cout; pr.act = 0;
             pr.wkey = std::string(pre) + ".conv." + std::to_string(j + 1) + ".weight";
@@ -249,6 +288,7 @@ void build_plan(cf_ctx* c) {
         c->ops[ih].name = "up3+heads";
         c->ops[ih].macs += c->ops[iu].macs;
     }
+    layout_pass(c);
 }
 
 struct WeightSet {
@@ -416,7 +456,7 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
     for (auto& b : c->bufs) {
         // + slack: kernels may over-read one 16-byte chunk; a tensor in pixel-block order is padded to whole 32-pixel blocks
         // (at most 31 pixels x 960 channels x 2 bytes)
-        size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256 + (b.name == "depthwise" ? (size_t)32 * 960 * 2 : 0);
+        size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256 + (b.f32 ? 0 : (size_t)32 * 960 * 2);
         if ((e = hipMalloc(&b.p, bytes)) != hipSuccess) return bail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "hipMalloc(activations)", e);
         // zero-initialised incl. the slack: kernels may over-read (never write) one 16-byte chunk
         if ((e = hipMemsetAsync(b.p, 0, bytes, c->stream)) != hipSuccess) return bail(CF_EHIP, "hipMemset(activations)", e);
@@ -654,7 +694,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
             PwParams p{}; p.x = bp(op.in); p.wp = op.wp; p.bias = op.bias; p.res = bp(op.res); p.y = bp(op.out);
             p.M = (long long)B * op.Hout * op.Wout; p.K = op.Cin; p.N = op.Cout; p.act = op.act;
             p.low = bp(op.low); p.upw = op.upw; p.upb = op.upb; p.Ho = op.Hout; p.Wo = op.Wout;
-            p.xblock = op.blocked ? 1 : 0;
+            p.xblock = op.in_blk ? 1 : 0; p.yblock = op.out_blk ? 1 : 0; p.resblock = op.res_blk ? 1 : 0;
             return launch_pw(c->stream, c->dtype, p);
         }
         case OP_STEM0: {
@@ -668,7 +708,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
             p.B = B; p.Hin = op.Hin; p.Win = op.Win; p.Hout = op.Hout; p.Wout = op.Wout; p.Cin = op.Cin; p.hid = op.hid; p.Cout = op.Cout;
             p.k = op.k; p.s = op.s; p.pad_lo = op.pad_lo; p.residual = op.residual ? 1 : 0;
             p.HC = op.geo.HC; p.nq = op.geo.nq; p.NBE = op.geo.NBE; p.JX = op.geo.JX; p.HALF = op.geo.HALF; p.rowb = op.geo.rowb;
-            p.lds_bytes = op.geo.lds_bytes; p.kind = op.geo.kind; p.yblock = (op.kind == OP_EXPDW && op.blocked) ? 1 : 0;
+            p.lds_bytes = op.geo.lds_bytes; p.kind = op.geo.kind; p.yblock = op.out_blk ? 1 : 0; p.xblock = op.in_blk ? 1 : 0;
             return launch_mbconv(c->stream, c->dtype, p);
         }
         case OP_HEAD: {
@@ -1178,7 +1218,7 @@ int cf_forward_trace(cf_ctx* c, const void* in, int in_format, int in_on_device,
     const size_t n = (size_t)B * C * op.Hout * op.Wout;
     float* tmp = nullptr;
     HIPCHK(c, hipMalloc((void**)&tmp, n * sizeof(float)));
-    hipError_t e = (op.kind == OP_EXPDW && op.blocked)
+    hipError_t e = op.out_blk
         ? launch_blocked_to_nchw(c->stream, c->bufs[op.out].p, tmp, B, C, op.Hout, op.Wout)
         : launch_nhwc_to_nchw(c->stream, head ? CF_F32 : c->dtype, c->bufs[op.out].p, tmp, B, C, op.Hout, op.Wout);
     if (e == hipSuccess) e = hipMemcpyAsync(out_nchw, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
