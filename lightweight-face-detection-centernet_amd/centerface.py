@@ -301,7 +301,7 @@ class EngineRing(object):
     (HBM-bound, small grids), the up3+heads kernel (memory-latency-bound) and the decode -- leaves the VALU idle, while
     its front half (stem, layer1.x / 2.x: VALU-issue-bound on Swish) leaves HBM idle.  With two batches in flight on two
     contexts (each has its own main / copy / decode streams and buffers) the GPU overlaps the back half of batch i with
-    the front half of batch i+1: 42.2k -> 45.4k img/s at 64 x 640x640 bf16 (tools/dual_stream_probe.py; depth 3 adds
+    the front half of batch i+1: 44k -> 48k img/s at 64 x 640x640 bf16 (tools/dual_stream_probe.py; depth 3 adds
     nothing).  The reference has no counterpart (centerface.py:39-48 is one synchronous call per image); a C host does
     the same with two cf_ctx handles.  Contexts are independent: results of batch i are on context
     i % depth until batch i + depth is submitted.
