@@ -346,7 +346,9 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
         (void)wl_env;                          // NBW = 4 measured best of {4,5,6,8} on every late layer
         static const int nst_env = getenv("CF_PW_NST") ? atoi(getenv("CF_PW_NST")) : 0;       // A/B: ring depth 2..4
         static const int nbw_env = getenv("CF_PW_NBW") ? atoi(getenv("CF_PW_NBW")) : 0;
-        const int nbw = nbw_env ? nbw_env : (NB == 3 ? 3 : (NB % 5 == 0 ? 5 : 4));      // N = 160 / 320: five n-blocks per wave, activations read once / twice; N = 96: three
+        // N = 320: five n-blocks per wave (activations read twice); N = 160: 3 + 2 (two workgroup rows: 200 -> 400 workgroups on
+        // the 20x20 maps at B = 64, 16.7 -> 16.0 and 25.2 -> 23.1 us); N = 96: three
+        const int nbw = nbw_env ? nbw_env : (NB == 3 || NB == 5 ? 3 : (NB % 5 == 0 ? 5 : 4));
         dim3 grid((unsigned)gx, (unsigned)((NB + nbw - 1) / nbw));
         // ring depth: 3-4 stages (<= 64 KB of LDS) when the grid is at most half a workgroup per CU (small batches: the
         // K chain's latency is the kernel time), 2 stages (more workgroups per CU) otherwise -- measured
