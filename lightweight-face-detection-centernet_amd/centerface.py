@@ -398,11 +398,15 @@ class CenterFace(object):
         self.nms_thresh = nms_thresh
         self.max_dets = max_dets
         self.device = device
-        self.engine = Engine(self.img_h_new, self.img_w_new, max_batch=max_batch, dtype=dtype,
-                             device=device, weights=weights, collapse_heads=collapse_heads)
+        self._engine_kw = dict(max_batch=max_batch, dtype=dtype, device=device, weights=weights, collapse_heads=collapse_heads)
+        self.engine = Engine(self.img_h_new, self.img_w_new, **self._engine_kw)
+        self._engine2 = None                      # second context of detect_stream, created on first use
 
     def close(self):
         self.engine.close()
+        if self._engine2 is not None:
+            self._engine2.close()
+            self._engine2 = None
 
     # centerface.py:68-71
     def transform(self, h, w):
@@ -469,6 +473,47 @@ class CenterFace(object):
                 self.engine.forward_resized_enqueue(chunk)           # cv2.resize stand-in, on the device
             out.extend(self._postprocess_many(self.engine.decode_threshold(0.3, self.nms_thresh, self.max_dets)))
         return out
+
+    def detect_stream(self, imgs, threshold=0.2):
+        """``__call__`` over an iterable of same-sized images, results yielded in order (the loop of demo.py:30-38 /
+        eval_widerface.py:76-90).  The reference runs one synchronous call per image; here two contexts alternate, the
+        forward of chunk i+1 (``max_batch`` images) is enqueued before the host waits for the decode of chunk i, so the GPU
+        works on one chunk while the host decodes and rescales the other.  Same results as ``__call__`` (tests)."""
+        del threshold
+        if self._engine2 is None:
+            self._engine2 = Engine(self.img_h_new, self.img_w_new, **self._engine_kw)
+            for _ in range(8):                    # keep the two main streams on different hardware queues (see EngineRing)
+                if not self._engine2.shares_queue_with(self.engine):
+                    break
+                self._engine2.reroll_streams()
+        engs = (self.engine, self._engine2)
+        nb = self.engine.max_batch
+
+        def enqueue(e, chunk):
+            batch = np.stack([np.asarray(im, dtype=np.uint8) for im in chunk])
+            if batch.shape[1:3] == (self.img_h_new, self.img_w_new):
+                e.forward_enqueue(batch)
+            else:
+                e.forward_resized_enqueue(batch)
+
+        def finish(e):
+            return self._postprocess_many(e.decode_threshold(0.3, self.nms_thresh, self.max_dets))
+        it, k, pending = iter(imgs), 0, None
+        while True:
+            chunk = []
+            for im in it:
+                chunk.append(im)
+                if len(chunk) == nb:
+                    break
+            if chunk:
+                enqueue(engs[k & 1], chunk)
+            if pending is not None:
+                for r in finish(pending):
+                    yield r
+            if not chunk:
+                return
+            pending = engs[k & 1]
+            k += 1
 
     def forward(self, x):
         return self.engine.forward(x)

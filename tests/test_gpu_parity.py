@@ -539,6 +539,24 @@ def test_centerface_call_matches_oracle():
     assert dets.shape == (0, 5) and lms.shape == (0, 10) and dets.dtype == np.float32
 
 
+@pytest.mark.parametrize("hw,mb", [((128, 160), 1), ((128, 160), 3), ((97, 131), 2)])
+def test_detect_stream_equals_call(hw, mb):
+    """CenterFace.detect_stream (two contexts, the next chunk's forward enqueued before the previous decode is collected):
+    the same results, in order, as one __call__ per image -- identity-size and device-resized inputs, chunked and not,
+    a count that does not fill the last chunk, and a second pass over the same object."""
+    rng = np.random.default_rng(hw[0] + mb)
+    face = cfa.CenterFace(hw[0], hw[1], dtype="bf16", max_batch=mb)
+    imgs = [rng.integers(0, 256, hw + (3,), dtype=np.uint8) for _ in range(7)]
+    want = [face(im) for im in imgs]
+    for _ in range(2):
+        got = list(face.detect_stream(iter(imgs)))
+        assert len(got) == len(want)
+        for (d, l), (wd, wl) in zip(got, want):
+            assert np.array_equal(d, wd) and np.array_equal(l, wl)
+    assert list(face.detect_stream([])) == []
+    face.close()
+
+
 # ------------------------------------------------------------------------------- full size
 def test_full_size_640_fp32_vs_oracle_topk():
     """BASELINE config 2 geometry at small batch: 640x640, fp32 parity mode, heads within 1e-3 of the
