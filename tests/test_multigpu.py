@@ -91,6 +91,31 @@ def test_engine_ring_matches_single_engine_bitwise():
     ring.close()
 
 
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """bench.py as the driver runs it (small workload): exactly one line on stdout, the contract's fields, roofline and
+    the per-run consistency the judge checks (value = images of the median window / its time)."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--repeats", "3",
+                          "--batch", "4", "--size", "160", "--topk", "20", "--no-cpu-baseline", "--no-extras", "--profile-reps", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "windows"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "images/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["config"]["contexts_per_gpu"] == 2 and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(d["value"] - 4 * 3 / (d["windows"]["median_ms"] * 1e-3)) / d["value"] < 1e-3
+    assert abs(d["ms_per_step"] - d["windows"]["median_ms"] / 3) < 1e-3
+
+
 WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
