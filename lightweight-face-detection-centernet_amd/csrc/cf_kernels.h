@@ -96,6 +96,13 @@ hipError_t mb2_launch(hipStream_t s, const MbParams& p);
 MbGeom expdw_geometry(int dtype, int Cin, int hid, int k, int s);
 hipError_t expdw_launch(hipStream_t s, const MbParams& p);
 
+// cf_mbconv3.hip: depthwise on the matrix cores (v_mfma_f32_4x4x4_16b_f16, Toeplitz operands), stride 1, bf16 storage.
+// MbGeom::kind 4 = expand + depthwise (project stays a GEMM launch)
+MbGeom expdw_mx_geometry(int dtype, int Cin, int hid, int k, int s);
+void mx_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+                     void* wexp_host, float* wdw_host, void* wproj_host);
+hipError_t mx_launch(hipStream_t s, const MbParams& p);
+
 // ------------------------------------------------------------------ stem 3x3 s2 3->32 + Swish
 struct StemParams {
     const void* x;        // u8 [B][H][W][3] (BGR) or f32 [B][3][H][W]

@@ -693,7 +693,8 @@ static const XdEntry* xd_find(int k, int s, int jx) {
 
 // geometry of the expand+depthwise kernel for a block (bf16 storage): MbGeom with kind = 2
 MbGeom expdw_geometry(int dtype, int Cin, int hid, int k, int s) {
-    MbGeom g{};
+    MbGeom g = expdw_mx_geometry(dtype, Cin, hid, k, s);          // stride 1: depthwise on the matrix cores (cf_mbconv3.hip)
+    if (g.ok) return g;
     static const bool off = getenv("CF_XD_KIND") && atoi(getenv("CF_XD_KIND")) == 0;
     if (off || dtype != 1 || (Cin % 8) || hid == Cin) return g;
     const int jx = (Cin * 2 / 16 + 1) / 2;

@@ -1,0 +1,397 @@
+// Third-generation fused MBConv kernels (bf16 storage, stride 1): the depthwise taps run on the MATRIX cores.
+//
+// MBConvBlock.forward (model/centernet.py:89-140): expand 1x1 (+Swish) -> depthwise k x k (+Swish) -> project 1x1.
+// cf_mbconv2.hip evaluates the depthwise with v_dot2c_f32_f16 (6 / 15 VALU instructions per output element for 3x3 / 5x5):
+// 129 M of them per 640x640 image, ~20 % of the VALU issue budget of a forward whose every large kernel is VALU-issue-bound
+// (profiles/r02h_valu_bound.md).  The matrix pipe is idle in those kernels.  Here a depthwise row is a banded (Toeplitz) 4x4
+// matrix per channel and runs on v_mfma_f32_4x4x4_16b_f16 -- sixteen independent 4x4x4 products per instruction:
+//
+//   D_blk[i][j] = sum_k A_blk[i][k] * B_blk[k][j]      blk = (channel group kg, pixel-quad slot pg), 16 blocks
+//     B: lane (blk, j)  = 4 x-consecutive fp16 of ONE channel of the expanded tile (one 8-byte LDS cell), quad (pg, j)
+//     A: lane (blk, i)  = taps of output x-offset i against the 4 inputs of the quad: w[ky][4 ks + k - i] (0 outside)
+//     D: lane (blk, j) register i = output pixel i of output quad (pg, j) for channel (kg, g)
+//   one output quad needs KS rows x 2 k-steps (inputs x .. x+7) -> 6 (3x3) / 10 (5x5) MFMAs per channel-of-4-pixels, each
+//   ~4 issue cycles beside other VALU work (tools/ub_mfma_coissue_probe.hip) instead of 4 x 6 / 4 x 15 v_dot2c.
+//   CBSZ = 2 broadcasts the A operand of block `abid` inside each group of four blocks, so ONE register pair holds the
+//   Toeplitz operands of four channels (block pg of group kg keeps channel 4 q + pg): A stays resident in 24 / 40 VGPRs.
+//
+// The operand layouts chain without any cross-lane traffic:
+//   expand MFMA 32x32x16 (lane = hidden channel, registers = 4 x-quads of the halo pixel block) -> Swish -> cvt_pkrtz ->
+//   ds_write_b64 into cells E[halo quad][channel][4 x fp16]  (a quad's 32 channels = 256 contiguous bytes + 16 pad)
+//   -> a lane's eight channels (kg*8 .. +7) of a quad are 64 contiguous bytes: four ds_read_b128 feed eight MFMAs
+//   -> D registers -> Swish -> bf16: for output pixel i the lane holds 8 consecutive channels = one 16-byte store (or one
+//   MFMA 16x16x32 B fragment: n = lane & 15 = output quad, k-group = lane >> 4 = kg).
+// The lane -> output-quad table deals quads to the 16 slots of a set so that the 16-lane hardware groups of ds_read_b128
+// (MI355X_MICROARCH.md, LDS) hit sixteen distinct 16-byte slots: cell pitch 272 B = 17 slots, so a quad's slot class is
+// its linear halo index mod 16 and slot (pg, j) takes class pg + 4 j.
+//
+// Numerics are those of cf_mbconv2.hip (same storage points: fp16 round-toward-zero tile, fp16 taps, fp32 accumulation,
+// pre-scaled Swish); only the fp32 summation order inside a row differs.  oracle/bf16_emulation.py is the checker.
+#include "cf_common.h"
+#include "cf_kernels.h"
+#include <cstdlib>
+
+namespace cf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 mfma_f16x4;
+static constexpr float kNegLog2e3 = -1.44269504088896341f, kNegLn23 = -0.69314718055994531f;
+
+__device__ __forceinline__ f32x2 swish2_pre(f32x2 u) {      // u = -log2(e) x  ->  u / (1 + 2^u) = -log2(e) swish(x)
+    f32x2 e; e.x = __builtin_amdgcn_exp2f(u.x); e.y = __builtin_amdgcn_exp2f(u.y);
+    const f32x2 den = e + 1.0f;
+    f32x2 r; r.x = __builtin_amdgcn_rcpf(den.x); r.y = __builtin_amdgcn_rcpf(den.y);
+    return u * r;
+}
+
+static inline uint16_t host_f32_to_f16_3(float f) {       // round-to-nearest-even, saturating (= cf_mbconv2.hip)
+    uint32_t u; __builtin_memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t exp = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+    uint32_t man = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+    if (exp >= 31) return (uint16_t)(sign | 0x7bffu);
+    if (exp <= 0) {
+        if (exp < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - exp;
+        uint32_t half = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+        if (rem > mid || (rem == mid && (half & 1))) ++half;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)exp << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1))) ++half;
+    if (half >= 0x7c00u) half = 0x7bffu;
+    return (uint16_t)(sign | half);
+}
+
+// ---------------------------------------------------------------- geometry shared by host and device (stride 1)
+template <int KS, int JX, int TOH, int TOW, int NW>
+struct Mx {
+    static constexpr int HC = 32;                                   // hidden channels per round = 4 groups x 8
+    static constexpr int IH = TOH + KS - 1, IWQ = TOW / 4 + 1, IWP = IWQ * 4;   // halo tile in x-quads (covers TOW + KS - 1)
+    static constexpr int NQD = IH * IWQ, NIB = (NQD + 7) / 8, IPX = NQD * 4;
+    static constexpr int CP = HC * 8 + 16;                          // bytes per quad cell row: 32 channels x 8 B + 16 (17 slots)
+    static constexpr int EBYTES = NIB * 8 * CP;                     // whole pixel blocks: phase 1 stores are unconditional
+    static constexpr int NOQ = TOH * (TOW / 4), NSET = (NOQ + 15) / 16;
+    static constexpr int WXB = JX * 1024;                           // expand weight fragments of one round
+    static constexpr int LDS = EBYTES + WXB;
+    static constexpr int NSTEP = KS * 2;                            // (ky, k-step) pairs per output quad
+    static_assert(TOW % 4 == 0 && KS <= 5, "x-quads; two k-steps cover 4 + KS - 1 <= 8 inputs");
+};
+
+// lane & 15 -> output quad of a set (entry: bit 15 = no quad, bits 6.. = oy, bits 0-5 = x-quad)
+template <int TOH, int TOW, int IWQ>
+struct SetMap {
+    static constexpr int OWQ = TOW / 4, NOQ = TOH * OWQ, NSET = (NOQ + 15) / 16, NSLOT = NSET * 16;
+    static_assert(OWQ <= 64 && TOH <= 256, "entry packing");
+    uint16_t v[NSLOT];
+    constexpr SetMap() : v() {
+        int bucket[16][NOQ] = {}; int cnt[16] = {}, used[16] = {};
+        for (int r = 0; r < NOQ; ++r) { const int b = ((r / OWQ) * IWQ + (r % OWQ)) & 15; bucket[b][cnt[b]++] = r; }
+        int slot[NSLOT] = {};
+        for (int s = 0; s < NSET; ++s)
+            for (int q = 0; q < 16; ++q) {
+                const int b = ((q >> 2) + 4 * (q & 3)) & 15;                     // slot (pg, j) wants class pg + 4 j
+                slot[s * 16 + q] = used[b] < cnt[b] ? bucket[b][used[b]++] : -1;
+            }
+        for (int b = 0; b < 16; ++b)                                            // uneven classes: leftovers fill the holes
+            while (used[b] < cnt[b]) {
+                int s = 0; while (slot[s] >= 0) ++s;
+                slot[s] = bucket[b][used[b]++];
+            }
+        for (int s = 0; s < NSLOT; ++s) {
+            const int r = slot[s] >= 0 ? slot[s] : 0;
+            v[s] = (uint16_t)((slot[s] < 0 ? 0x8000 : 0) | ((r / OWQ) << 6) | (r % OWQ));
+        }
+    }
+};
+
+#define CF_MX_MFMA(ACC, AV, BV, ABID) ACC = __builtin_amdgcn_mfma_f32_4x4x4f16(AV, BV, ACC, 2, ABID, 0)
+
+// depthwise of one set (16 output quads x 32 channels): acc[g][i] = output pixel i of this lane's quad, channel kg*8 + g
+template <int KS, int IWQ, int CP>
+__device__ __forceinline__ void mx_depthwise(const char* bb, const u32x2 (*A)[KS][2], f32x4* acc) {
+    constexpr int NSTEP = KS * 2;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    u32x4 bq[2][4];
+#pragma unroll
+    for (int g2 = 0; g2 < 4; ++g2) bq[0][g2] = ld16(bb + g2 * 16);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) {
+            const int ky = (st + 1) >> 1, ks = (st + 1) & 1;
+#pragma unroll
+            for (int g2 = 0; g2 < 4; ++g2) bq[(st + 1) & 1][g2] = ld16(bb + (ky * IWQ + ks) * CP + g2 * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // keep the next group's reads in flight under this group's MFMAs
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, A[g >> 2][st >> 1][st & 1]);
+            u32x2 b2;
+            b2.x = (g & 1) ? bq[st & 1][g >> 1].z : bq[st & 1][g >> 1].x;
+            b2.y = (g & 1) ? bq[st & 1][g >> 1].w : bq[st & 1][g >> 1].y;
+            const mfma_f16x4 bv = __builtin_bit_cast(mfma_f16x4, b2);
+            switch (g & 3) {
+                case 0: CF_MX_MFMA(acc[g], av, bv, 0); break;
+                case 1: CF_MX_MFMA(acc[g], av, bv, 1); break;
+                case 2: CF_MX_MFMA(acc[g], av, bv, 2); break;
+                default: CF_MX_MFMA(acc[g], av, bv, 3); break;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ================================================================== expand + depthwise (project stays a GEMM launch)
+// grid = (tiles, hid / 32, batch); one round of 32 hidden channels per workgroup; only the depthwise output reaches HBM
+template <int KS, int JX, int TOH, int TOW, int NW>
+__global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
+    typedef Mx<KS, JX, TOH, TOW, NW> G;
+    constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, CP = G::CP, NSET = G::NSET, WXB = G::WXB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* E = smem;
+    char* Wst = smem + G::EBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.Wout + TOW - 1) / TOW;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int ox0 = txi * TOW, oy0 = tyi * TOH, b = blockIdx.z;
+    const int grp = blockIdx.y;
+
+    {
+        const char* srcx = (const char*)p.wexp + (size_t)grp * WXB;
+        for (int c = wave; c < WXB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(Wst + c * 1024), 16, 0, 0);
+    }
+    // Toeplitz A operands of this round: [2 channel quads][KS][2 k-steps] register pairs, resident for the whole kernel
+    u32x2 A[2][KS][2];
+    {
+        const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)grp * (2 * KS * 2) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) A[q][ky][ks] = at[((q * KS + ky) * 2 + ks) * 64];
+    }
+    const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+    const unsigned rowbytes = (unsigned)p.Cin * 2;
+    auto load_x = [&](int ib, u32x4* xf) -> bool {
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < IPX ? ip : IPX - 1;
+        const int iy = ipc / IWP, ix = ipc - iy * IWP;
+        const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
+        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+        if (p.xblock) {
+            const char* xb = (const char*)p.x + blk_off(((size_t)b * p.Hin + cy) * p.Win + cx, p.Cin / 8, h * JX);
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xf[j] = ld16(xb + j * 512);
+        } else {
+            const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
+        }
+        return ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+    };
+    auto mask_x = [&](u32x4* xf, bool valid) {
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            xf[j].x = valid ? xf[j].x : 0u; xf[j].y = valid ? xf[j].y : 0u; xf[j].z = valid ? xf[j].z : 0u; xf[j].w = valid ? xf[j].w : 0u;
+        }
+    };
+    u32x4 xa[JX];
+    bool va = false;
+    if (wave < NIB) va = load_x(wave, xa);
+    __syncthreads();
+    mask_x(xa, va);
+
+    // ---- phase 1: expand + Swish -> quad cells.  D rows (r & 3) + 8 (r >> 2) + 4 h: register quad t = halo quad ib*8 + 2t + h
+    for (int ib = wave; ib < NIB; ib += NW) {
+        u32x4 xn[JX];
+        const bool more = ib + NW < NIB;
+        bool vn = false;
+        if (more) vn = load_x(ib + NW, xn);
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+        const char* wb = Wst + lane * 16;
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const u32x4 wv = ld16(wb + j * 1024);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xa[j]),
+                                                        __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
+        }
+        char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)CP + pl * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x2 u0, u1; u0.x = a[4 * t]; u0.y = a[4 * t + 1]; u1.x = a[4 * t + 2]; u1.y = a[4 * t + 3];
+            const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+            u32x2 d;
+            d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+            d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+            *reinterpret_cast<u32x2*>(ecell + 2 * t * CP) = d;
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xa[j] = xn[j];
+            mask_x(xa, vn);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: depthwise on the matrix cores + Swish, 16 output quads x 32 channels per wave step
+    static constexpr SetMap<TOH, TOW, IWQ> kSets{};
+    const int kg = lane >> 4;
+    for (int set = wave; set < NSET; set += NW) {
+        const uint32_t e = kSets.v[set * 16 + (lane & 15)];
+        const int oy = (e >> 6) & 0x1ff, oxq = e & 63;
+        const bool live = (e & 0x8000u) == 0;
+        f32x4 acc[8];
+        mx_depthwise<KS, IWQ, CP>(E + (unsigned)(oy * IWQ + oxq) * (unsigned)CP + kg * 64, A, acc);
+        // a = -log2(e) * depthwise output -> Swish, leftover factor out again (the project GEMM has plain weights)
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+                const f32x2 y = swish2_pre(u) * kNegLn23;
+                acc[g][i] = y.x; acc[g][i + 1] = y.y;
+            }
+        const int gy = oy0 + oy, gx0 = ox0 + 4 * oxq;
+        if (!live || gy >= p.Hout) continue;
+        const size_t opix0 = ((size_t)b * p.Hout + gy) * p.Wout + gx0;
+        const int chunk = grp * 4 + kg;                               // 8-channel chunk of the depthwise tensor
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (gx0 + i >= p.Wout) break;
+            u32x4 o;
+            o.x = pack_bf16x2(acc[0][i], acc[1][i]); o.y = pack_bf16x2(acc[2][i], acc[3][i]);
+            o.z = pack_bf16x2(acc[4][i], acc[5][i]); o.w = pack_bf16x2(acc[6][i], acc[7][i]);
+            const size_t opix = opix0 + i;
+            st16((char*)p.y + (p.yblock ? blk_off(opix, p.hid / 8, chunk) : (opix * p.hid + (size_t)chunk * 8) * 2), o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+struct MxEntry {
+    int k, jx, toh, tow, nw, var, lds_bytes;
+    hipError_t (*fn)(hipStream_t, const MbParams&);
+};
+template <int KS, int JX, int TOH, int TOW, int NW>
+static hipError_t xmx_launch_t(hipStream_t s, const MbParams& p) {
+    typedef Mx<KS, JX, TOH, TOW, NW> G;
+    auto kfn = expdw_mx_kernel<KS, JX, TOH, TOW, NW>;
+    static thread_local bool configured_dev[32] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool& configured = configured_dev[dev & 31];
+    if (G::LDS > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid(((p.Wout + TOW - 1) / TOW) * ((p.Hout + TOH - 1) / TOH), p.hid / 32, p.B), blk(NW * 64);
+    set_kernel_tag("void cf::expdw_mx_kernel<%d, %d, %d, %d, %d>(cf::MbParams)", KS, JX, TOH, TOW, NW);
+    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
+    return hipGetLastError();
+}
+#define XMX(V, KS, JX, TOH, TOW, NW) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW>::LDS, &xmx_launch_t<KS, JX, TOH, TOW, NW>}
+static const MxEntry kXmxTable[] = {
+    //  var KS JX  tile   waves
+    XMX(0, 5, 4, 20, 40, 4),      // 4.0   64 -> 384, 40x40
+    XMX(0, 5, 6, 20, 40, 4),      // 4.1   96 -> 576, 40x40
+    XMX(0, 5, 10, 20, 20, 4),     // 5.1  160 -> 960, 20x20
+    XMX(0, 3, 10, 20, 20, 4),     // 6.0  160 -> 960, 20x20
+    XMX(1, 5, 4, 8, 40, 5),
+    XMX(1, 5, 6, 8, 40, 5),
+    XMX(1, 5, 10, 20, 20, 7),
+    XMX(1, 3, 10, 20, 20, 7),
+    XMX(3, 5, 4, 20, 40, 7),
+    XMX(3, 5, 6, 20, 40, 7),
+    XMX(2, 5, 4, 10, 40, 4),
+    XMX(2, 5, 6, 10, 40, 4),
+    XMX(2, 5, 10, 10, 20, 4),
+    XMX(2, 3, 10, 10, 20, 4),
+};
+#undef XMX
+static const MxEntry* xmx_find(int k, int jx) {
+    static const int want = getenv("CF_MX_VARIANT") ? atoi(getenv("CF_MX_VARIANT")) : 0;
+    const MxEntry* base = nullptr;
+    for (const MxEntry& e : kXmxTable)
+        if (e.k == k && e.jx == jx) {
+            if (e.var == want) return &e;
+            if (e.var == 0) base = &e;
+        }
+    return base;
+}
+
+// geometry of the matrix-core expand+depthwise kernel (MbGeom::kind = 4); stride 1 only
+MbGeom expdw_mx_geometry(int dtype, int Cin, int hid, int k, int s) {
+    MbGeom g{};
+    static const bool off = getenv("CF_MX") && atoi(getenv("CF_MX")) == 0;
+    if (off || dtype != 1 || s != 1 || (Cin % 8) || (hid % 32) || hid == Cin) return g;
+    const int jx = (Cin * 2 / 16 + 1) / 2;
+    const MxEntry* e = xmx_find(k, jx);
+    if (!e) return g;
+    g.ok = true; g.kind = 4; g.S = 1;
+    g.JX = jx; g.NBO = 0; g.HC = 32; g.nq = hid / 32; g.NBE = 1; g.HALF = 0;
+    g.rowb = 32 * 8 + 16;
+    g.lds_bytes = (size_t)e->lds_bytes;
+    g.wexp_bytes = (size_t)g.nq * g.JX * 64 * 16;
+    g.wdw_floats = (size_t)g.nq * 2 * k * 2 * 64 * 2;              // dwords: [round][2][k][2][64 lanes] x 2
+    g.wproj_bytes = 0;
+    return g;
+}
+
+// Toeplitz A operands: [round][channel quad q][ky][k-step][lane (kg, pg, i)] = 4 fp16: tap w[ky][4 ks + k - i] of channel
+// round*32 + kg*8 + q*4 + pg (MFMA abid = pg selects it for the whole group kg)
+void mx_pack_taps(int nq, int k, const float* wd /*[hid][k*k]*/, uint32_t* out) {
+    for (int r = 0; r < nq; ++r)
+        for (int q = 0; q < 2; ++q)
+            for (int ky = 0; ky < k; ++ky)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int kg = lane >> 4, pg = (lane >> 2) & 3, i = lane & 3;
+                        const float* wrow = wd + (size_t)(r * 32 + kg * 8 + q * 4 + pg) * k * k + (size_t)ky * k;
+                        uint16_t v[4];
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int kx = 4 * ks + kk - i;
+                            v[kk] = (kx >= 0 && kx < k) ? host_f32_to_f16_3(wrow[kx]) : 0;
+                        }
+                        uint32_t* dst = out + ((((size_t)(r * 2 + q) * k + ky) * 2 + ks) * 64 + lane) * 2;
+                        dst[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+                        dst[1] = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+                    }
+}
+
+// we [hid][Cin], wd [hid][k*k]; expand fragments as cf_mbconv2.hip (MFMA B operand: lane (n = channel, half) holds Cin chunk)
+void mx_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+                     void* wexp_host, float* wdw_host, void* wproj_host) {
+    (void)hid; (void)Cout; (void)wp; (void)wproj_host;
+    const int NCx = Cin * 2 / 16;
+    __builtin_memset(wexp_host, 0, g.wexp_bytes);
+    for (int q = 0; q < g.nq; ++q)
+        for (int j = 0; j < g.JX; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 31, hh = lane >> 5, c = hh * g.JX + j;
+                if (c >= NCx) continue;
+                uint16_t* dst = (uint16_t*)((char*)wexp_host + (((size_t)q * g.JX + j) * 64 + lane) * 16);
+                for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLog2e3 * we[(size_t)(q * 32 + n) * Cin + (size_t)c * 8 + e]);
+            }
+    mx_pack_taps(g.nq, k, wd, reinterpret_cast<uint32_t*>(wdw_host));
+}
+
+hipError_t mx_launch(hipStream_t s, const MbParams& p) {
+    const MxEntry* e = xmx_find(p.k, p.JX);
+    if (!e || p.s != 1) return hipErrorInvalidValue;
+    return e->fn(s, p);
+}
+
+}  // namespace cf
