@@ -102,6 +102,11 @@ MbGeom expdw_mx_geometry(int dtype, int Cin, int hid, int k, int s);
 void mx_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
                      void* wexp_host, float* wdw_host, void* wproj_host);
 hipError_t mx_launch(hipStream_t s, const MbParams& p);
+// MbGeom::kind 5 = fully fused block (expand -> matrix-core depthwise -> project (+residual)), MbGeom::HALF = 1: last round of 16
+bool mx_fused_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s);
+void mx_fused_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+                           void* wexp_host, float* wdw_host, void* wproj_host);
+hipError_t mx_fused_launch(hipStream_t s, const MbParams& p);
 
 // ------------------------------------------------------------------ stem 3x3 s2 3->32 + Swish
 struct StemParams {

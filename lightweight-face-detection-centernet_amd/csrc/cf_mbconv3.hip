@@ -280,6 +280,268 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
     }
 }
 
+// ================================================================== fully fused block: expand -> depthwise -> project (+residual)
+// One workgroup per output tile; the hidden channels go through the tile in rounds of 32 (+ an optional last round of 16:
+// hid = 144): expand the halo for the round -> quad cells in LDS -> matrix-core depthwise -> Swish -> the lane's eight (four)
+// channels of output pixel i are the B fragment of v_mfma_f32_16x16x32_bf16 (16x16x16 for the 16-channel round) whose n index
+// is the lane's quad slot: project accumulators D[out channel][quad slot] per pixel i, in registers across the rounds.
+// MFMA row m <-> output channel 32 (mb >> 1) + 8 (m >> 2) + 4 (mb & 1) + (m & 3): lane group kq = lane >> 4 ends up with the
+// eight consecutive channels 8 kq .. 8 kq + 7 (+32 for the second pair of M blocks) of its pixels = 16-byte stores.
+template <int KS, int JX, int NMB, int TOH, int TOW, int NW, bool TAIL16>
+struct Fx {
+    static constexpr int IH = TOH + KS - 1, IWQ = TOW / 4 + 1, IWP = IWQ * 4;
+    static constexpr int NQD = IH * IWQ, NIB = (NQD + 7) / 8, IPX = NQD * 4, MAXI = (NIB + NW - 1) / NW;
+    static constexpr int CP8 = 32 * 8 + 16, CP4 = 16 * 8 + 16;
+    static constexpr int EBYTES = NIB * 8 * CP8;
+    static constexpr int NOQ = TOH * (TOW / 4), NSET = (NOQ + 15) / 16, SPW = NSET / NW;
+    static constexpr int WXB = JX * 1024;
+    static constexpr int LDS = EBYTES + 2 * WXB;
+    static_assert(NSET % NW == 0, "every wave owns SPW whole sets (project accumulators live in registers)");
+    static_assert(TOW % 4 == 0 && KS <= 5 && (NMB == 2 || NMB == 4), "geometry");
+    static_assert(!TAIL16 || JX <= 2, "16-channel round: one 16x16x32 expand MFMA, Cin <= 32");
+};
+
+template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16>
+__global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
+    typedef Fx<KS, JX, NMB, TOH, TOW, NW, TAIL16> G;
+    constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, MAXI = G::MAXI, CP8 = G::CP8, CP4 = G::CP4;
+    constexpr int SPW = G::SPW, WXB = G::WXB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* E = smem;
+    char* Wst = smem + G::EBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5, kg = lane >> 4;
+    const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH, b = blockIdx.z;
+    const int nq = p.nq;                                            // full rounds of 32 hidden channels
+
+    const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+    const unsigned rowbytes = (unsigned)p.Cin * 2;
+
+    auto stage_weights = [&](int q) {
+        char* dst = Wst + (q & 1) * WXB;
+        const char* srcx = (const char*)p.wexp + (size_t)q * WXB;
+        for (int c = wave; c < WXB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+    };
+
+    // X fragments of this wave's halo pixel blocks (MFMA A operand: lane = pixel, 8 contiguous Cin per half), resident;
+    // clamped address + zero select = ZeroPad2d without predicated loads
+    u32x4 xf[MAXI][JX];
+#pragma unroll
+    for (int t = 0; t < MAXI; ++t) {
+        const int ib = wave + NW * t;
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < IPX ? ip : IPX - 1;
+        const int iy = ipc / IWP, ix = ipc - iy * IWP;
+        const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
+        const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+        const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const u32x4 v = ld16(xbase + off + j * 16);
+            xf[t][j].x = valid ? v.x : 0u; xf[t][j].y = valid ? v.y : 0u;
+            xf[t][j].z = valid ? v.z : 0u; xf[t][j].w = valid ? v.w : 0u;
+        }
+    }
+
+    // this wave's output quads: one per (set, lane & 15)
+    static constexpr SetMap<TOH, TOW, IWQ> kSets{};
+    unsigned qcell[SPW];                     // linear halo-quad index of the output quad's top-left input quad
+#pragma unroll
+    for (int sw = 0; sw < SPW; ++sw) {
+        const uint32_t e = kSets.v[(wave * SPW + sw) * 16 + (lane & 15)];
+        qcell[sw] = ((e >> 6) & 0x1ff) * IWQ + (e & 63);
+    }
+
+    f32x4 pacc[SPW][4][NMB];
+#pragma unroll
+    for (int sw = 0; sw < SPW; ++sw)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb) pacc[sw][i][mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    stage_weights(0);
+    for (int q = 0; q < nq; ++q) {
+        // Toeplitz operands + project fragments of this round: requested before the expand phase, used after it
+        u32x2 A[2][KS][2];
+        {
+            const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)q * (2 * KS * 2) * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) A[a][ky][ks] = at[((a * KS + ky) * 2 + ks) * 64];
+        }
+        u32x4 wpc[NMB];
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) wpc[mb] = ld16((const char*)p.wproj + (((size_t)q * NMB + mb) * 64 + lane) * 16);
+        const char* wx = Wst + (q & 1) * WXB;
+        __syncthreads();      // previous round's depthwise done with E; this round's expand weights landed
+
+        // ---- phase 1: expand + Swish -> quad cells
+#pragma unroll
+        for (int t = 0; t < MAXI; ++t) {
+            const int ib = wave + NW * t;
+            if (ib >= NIB) break;
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < JX; ++j) {
+                const u32x4 wv = ld16(wx + (j * 64 + lane) * 16);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xf[t][j]),
+                                                            __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
+            }
+            char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)CP8 + pl * 8;
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                f32x2 u0, u1; u0.x = a[4 * tq]; u0.y = a[4 * tq + 1]; u1.x = a[4 * tq + 2]; u1.y = a[4 * tq + 3];
+                const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+                u32x2 d;
+                d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+                d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+                *reinterpret_cast<u32x2*>(ecell + 2 * tq * CP8) = d;
+            }
+        }
+        __syncthreads();
+        if (q + 1 < nq) stage_weights(q + 1);
+
+        // ---- phase 2: depthwise (matrix cores) + Swish + project
+#pragma unroll
+        for (int sw = 0; sw < SPW; ++sw) {
+            f32x4 acc[8];
+            mx_depthwise<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, A, acc);
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+                    const f32x2 y = swish2_pre(u);
+                    acc[g][i] = y.x; acc[g][i + 1] = y.y;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4 d;
+                d.x = pack_bf16x2(acc[0][i], acc[1][i]); d.y = pack_bf16x2(acc[2][i], acc[3][i]);
+                d.z = pack_bf16x2(acc[4][i], acc[5][i]); d.w = pack_bf16x2(acc[6][i], acc[7][i]);
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb)
+                    pacc[sw][i][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wpc[mb]),
+                                                                             __builtin_bit_cast(mfma_bf16x8, d), pacc[sw][i][mb], 0, 0, 0);
+            }
+        }
+    }
+
+    if constexpr (TAIL16) {
+        // ---- last round: 16 hidden channels (4 groups x 4).  Expand on v_mfma_f32_16x16x32_bf16: D[16 pixels][16 channels],
+        // lane (n = channel, qd = lane >> 4) holds quad qd of the 16-pixel group -> one 8-byte cell; cell row 144 B
+        typedef __attribute__((ext_vector_type(4))) __bf16 mfma_bf16x4;
+        const u32x4 wv = ld16((const char*)p.wexp + (size_t)nq * WXB + lane * 16);
+        u32x2 A4[KS][2];
+        {
+            const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)nq * (2 * KS * 2) * 64 + lane;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) A4[ky][ks] = at[(ky * 2 + ks) * 64];
+        }
+        u32x2 wp4[NMB];
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+            wp4[mb] = *reinterpret_cast<const u32x2*>((const char*)p.wproj + (size_t)nq * NMB * 1024 + ((size_t)mb * 64 + lane) * 8);
+        __syncthreads();
+        for (int sb = wave; sb < NIB * 2; sb += NW) {               // 16-pixel sub-blocks = 4 quads each
+            const int ip = sb * 16 + (lane & 15), kc = lane >> 4;   // A operand: lane (pixel, Cin chunk)
+            const int ipc = ip < IPX ? ip : IPX - 1;
+            const int iy = ipc / IWP, ix = ipc - iy * IWP;
+            const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
+            const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win && kc * 8 < p.Cin;
+            const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+            u32x4 xv = ld16(xbase + ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(min(kc * 8, p.Cin - 8) * 2));
+            xv.x = valid ? xv.x : 0u; xv.y = valid ? xv.y : 0u; xv.z = valid ? xv.z : 0u; xv.w = valid ? xv.w : 0u;
+            f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, xv), __builtin_bit_cast(mfma_bf16x8, wv), a4, 0, 0, 0);
+            f32x2 u0, u1; u0.x = a4[0]; u0.y = a4[1]; u1.x = a4[2]; u1.y = a4[3];
+            const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+            u32x2 d;
+            d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+            d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+            *reinterpret_cast<u32x2*>(E + (unsigned)(sb * 4 + kc) * (unsigned)CP4 + (lane & 15) * 8) = d;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sw = 0; sw < SPW; ++sw) {
+            const char* bb = E + qcell[sw] * (unsigned)CP4 + kg * 32;
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int st = 0; st < KS * 2; ++st) {
+                const char* bs = bb + ((st >> 1) * IWQ + (st & 1)) * CP4;
+                const u32x4 b0 = ld16(bs), b1 = ld16(bs + 16);
+                const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, A4[st >> 1][st & 1]);
+                u32x2 t0, t1, t2, t3; t0.x = b0.x; t0.y = b0.y; t1.x = b0.z; t1.y = b0.w; t2.x = b1.x; t2.y = b1.y; t3.x = b1.z; t3.y = b1.w;
+                CF_MX_MFMA(acc[0], av, __builtin_bit_cast(mfma_f16x4, t0), 0);
+                CF_MX_MFMA(acc[1], av, __builtin_bit_cast(mfma_f16x4, t1), 1);
+                CF_MX_MFMA(acc[2], av, __builtin_bit_cast(mfma_f16x4, t2), 2);
+                CF_MX_MFMA(acc[3], av, __builtin_bit_cast(mfma_f16x4, t3), 3);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+                    const f32x2 y = swish2_pre(u);
+                    acc[g][i] = y.x; acc[g][i + 1] = y.y;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x2 d; d.x = pack_bf16x2(acc[0][i], acc[1][i]); d.y = pack_bf16x2(acc[2][i], acc[3][i]);
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb)
+                    pacc[sw][i][mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mfma_bf16x4, wp4[mb]),
+                                                                                __builtin_bit_cast(mfma_bf16x4, d), pacc[sw][i][mb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane (kq = lane >> 4, quad slot): channels 8 kq .. + 7 (+ 32) of the four pixels of its quad
+#pragma unroll
+    for (int sw = 0; sw < SPW; ++sw) {
+        const uint32_t e = kSets.v[(wave * SPW + sw) * 16 + (lane & 15)];
+        const int oy = (e >> 6) & 0x1ff, oxq = e & 63;
+        const int gy = oy0 + oy, gx0 = ox0 + 4 * oxq;
+        if ((e & 0x8000u) || gy >= p.Hout) continue;
+        const size_t opix0 = ((size_t)b * p.Hout + gy) * p.Wout + gx0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (gx0 + i >= p.Wout) break;
+            const size_t opix = opix0 + i;
+#pragma unroll
+            for (int mp = 0; mp < NMB / 2; ++mp) {
+                const int ch = mp * 32 + kg * 8;
+                if (ch >= p.Cout) break;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = pacc[sw][i][2 * mp][r]; v[4 + r] = pacc[sw][i][2 * mp + 1][r]; }
+                if constexpr (RESID) {
+                    float rr[8];
+                    unpack16<bf16_t>(ld16((const char*)p.x + (opix * p.Cin + ch) * 2), rr);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = rr[r] + v[r];
+                }
+                st16((char*)p.y + (p.yblock ? blk_off(opix, p.Cout / 8, ch / 8) : (opix * p.Cout + ch) * 2), pack16<bf16_t>(v));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side
 struct MxEntry {
     int k, jx, toh, tow, nw, var, lds_bytes;
@@ -390,6 +652,136 @@ void mx_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const f
 
 hipError_t mx_launch(hipStream_t s, const MbParams& p) {
     const MxEntry* e = xmx_find(p.k, p.JX);
+    if (!e || p.s != 1) return hipErrorInvalidValue;
+    return e->fn(s, p);
+}
+
+
+// ---------------------------------------------------------------- fused block, host side (MbGeom::kind = 5)
+struct FxEntry {
+    int k, jx, nmb, res, tail, toh, tow, nw, var, lds_bytes;
+    hipError_t (*fn)(hipStream_t, const MbParams&);
+};
+template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16>
+static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
+    typedef Fx<KS, JX, NMB, TOH, TOW, NW, TAIL16> G;
+    auto kfn = mbconv_mx_kernel<KS, JX, NMB, RESID, TOH, TOW, NW, TAIL16>;
+    static thread_local bool configured_dev[32] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool& configured = configured_dev[dev & 31];
+    if (G::LDS > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
+    set_kernel_tag("void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false",
+                   TOH, TOW, NW, TAIL16 ? "true" : "false");
+    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
+    return hipGetLastError();
+}
+#define FXE(V, KS, JX, NMB, RES, TAIL, TOH, TOW, NW) \
+    {KS, JX, NMB, RES, TAIL, TOH, TOW, NW, V, Fx<KS, JX, NMB, TOH, TOW, NW, (TAIL != 0)>::LDS, &fx_launch_t<KS, JX, NMB, (RES != 0), TOH, TOW, NW, (TAIL != 0)>}
+static const FxEntry kFxTable[] = {
+    //  var KS JX NMB res tail  tile   waves
+    FXE(0, 3, 2, 2, 1, 1, 16, 20, 5),     // 1.1  24 -> 144 -> 24 (+res), 160x160: four rounds of 32 + one of 16
+    FXE(0, 5, 2, 2, 1, 0, 16, 20, 5),     // 2.1  32 -> 192 -> 32 (+res), 80x80
+    FXE(0, 3, 4, 4, 1, 0, 8, 40, 5),      // 3.1  64 -> 384 -> 64 (+res), 40x40
+    FXE(1, 3, 2, 2, 1, 1, 16, 16, 4),
+    FXE(1, 5, 2, 2, 1, 0, 16, 16, 4),
+    FXE(1, 3, 4, 4, 1, 0, 16, 16, 4),
+    FXE(2, 3, 2, 2, 1, 1, 32, 16, 4),
+    FXE(2, 5, 2, 2, 1, 0, 16, 40, 5),
+};
+#undef FXE
+static const FxEntry* fx_find(int k, int jx, int nmb, int res, int tail) {
+    static const int want = getenv("CF_FX_VARIANT") ? atoi(getenv("CF_FX_VARIANT")) : 0;
+    const FxEntry* base = nullptr;
+    for (const FxEntry& e : kFxTable)
+        if (e.k == k && e.jx == jx && e.nmb == nmb && e.res == res && e.tail == tail) {
+            if (e.var == want) return &e;
+            if (e.var == 0) base = &e;
+        }
+    return base;
+}
+
+bool mx_fused_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
+    static const bool off = getenv("CF_FX") && atoi(getenv("CF_FX")) == 0;
+    if (off || s != 1 || (Cin % 8) || (Cout % 8) || Cout > 64 || (hid % 16) || hid == Cin) return false;
+    const int jx = (Cin * 2 / 16 + 1) / 2, nmb = Cout <= 32 ? 2 : 4, tail = (hid % 32) ? 1 : 0;
+    const FxEntry* e = fx_find(k, jx, nmb, (Cin == Cout) ? 1 : 0, tail);
+    if (!e) return false;
+    g = MbGeom{};
+    g.ok = true; g.kind = 5; g.S = 1;
+    g.JX = jx; g.NBO = nmb; g.HC = 32; g.nq = hid / 32; g.NBE = 1; g.HALF = tail;
+    g.rowb = 32 * 8 + 16;
+    g.lds_bytes = (size_t)e->lds_bytes;
+    g.wexp_bytes = (size_t)g.nq * g.JX * 1024 + (tail ? 1024 : 0);
+    g.wdw_floats = ((size_t)g.nq * 2 + (tail ? 1 : 0)) * k * 2 * 64 * 2;
+    g.wproj_bytes = (size_t)g.nq * nmb * 1024 + (tail ? (size_t)nmb * 512 : 0);
+    return true;
+}
+
+static inline int fx_out_channel(int mb, int m) { return 32 * (mb >> 1) + 8 * (m >> 2) + 4 * (mb & 1) + (m & 3); }
+
+void mx_fused_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+                           void* wexp_host, float* wdw_host, void* wproj_host) {
+    const int NCx = Cin * 2 / 16, nq = g.nq, tail = g.HALF, nmb = g.NBO;
+    __builtin_memset(wexp_host, 0, g.wexp_bytes);
+    __builtin_memset(wproj_host, 0, g.wproj_bytes);
+    for (int q = 0; q < nq; ++q)
+        for (int j = 0; j < g.JX; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 31, hh = lane >> 5, c = hh * g.JX + j;
+                if (c >= NCx) continue;
+                uint16_t* dst = (uint16_t*)((char*)wexp_host + (((size_t)q * g.JX + j) * 64 + lane) * 16);
+                for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLog2e3 * we[(size_t)(q * 32 + n) * Cin + (size_t)c * 8 + e]);
+            }
+    uint32_t* wt = reinterpret_cast<uint32_t*>(wdw_host);
+    mx_pack_taps(nq, k, wd, wt);
+    for (int q = 0; q < nq; ++q)
+        for (int mb = 0; mb < nmb; ++mb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = fx_out_channel(mb, lane & 15), kc = lane >> 4;
+                if (co >= Cout) continue;
+                uint16_t* dst = (uint16_t*)((char*)wproj_host + (((size_t)q * nmb + mb) * 64 + lane) * 16);
+                for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLn23 * wp[(size_t)co * hid + q * 32 + kc * 8 + e]);
+            }
+    if (tail) {
+        const int c0 = nq * 32;
+        for (int lane = 0; lane < 64; ++lane) {                     // expand B fragment of 16x16x32: lane (n = channel, Cin chunk)
+            const int n = lane & 15, kc = lane >> 4;
+            if (kc >= NCx) continue;
+            uint16_t* dst = (uint16_t*)((char*)wexp_host + (size_t)nq * g.JX * 1024 + (size_t)lane * 16);
+            for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLog2e3 * we[(size_t)(c0 + n) * Cin + (size_t)kc * 8 + e]);
+        }
+        uint32_t* tt = wt + (size_t)nq * 2 * k * 2 * 64 * 2;        // Toeplitz operands: channel c0 + kg*4 + pg
+        for (int ky = 0; ky < k; ++ky)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int kgq = lane >> 4, pg = (lane >> 2) & 3, i = lane & 3;
+                    const float* wrow = wd + (size_t)(c0 + kgq * 4 + pg) * k * k + (size_t)ky * k;
+                    uint16_t v[4];
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int kx = 4 * ks + kk - i;
+                        v[kk] = (kx >= 0 && kx < k) ? host_f32_to_f16_3(wrow[kx]) : 0;
+                    }
+                    uint32_t* dst = tt + (((size_t)ky * 2 + ks) * 64 + lane) * 2;
+                    dst[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+                    dst[1] = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+                }
+        for (int mb = 0; mb < nmb; ++mb)                             // project A fragment of 16x16x16: lane (m, 4 channels)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = fx_out_channel(mb, lane & 15), kc = lane >> 4;
+                if (co >= Cout) continue;
+                uint16_t* dst = (uint16_t*)((char*)wproj_host + (size_t)nq * nmb * 1024 + ((size_t)mb * 64 + lane) * 8);
+                for (int e = 0; e < 4; ++e) dst[e] = host_f32_to_bf16(kNegLn23 * wp[(size_t)co * hid + c0 + kc * 4 + e]);
+            }
+    }
+}
+
+hipError_t mx_fused_launch(hipStream_t s, const MbParams& p) {
+    const FxEntry* e = fx_find(p.k, p.JX, p.Cout <= 32 ? 2 : 4, p.residual ? 1 : 0, (p.hid % 32) ? 1 : 0);
     if (!e || p.s != 1) return hipErrorInvalidValue;
     return e->fn(s, p);
 }

@@ -289,8 +289,15 @@ def check_blockwise(sd, g, rel=2.0 ** -7, flip=2.0 ** -8, detail=False):
         if prefix == "layer0.0":
             continue
         we, wd, wp = (sd["%s.conv.%s.weight" % (prefix, j)] for j in ("0.1", "1.1", "2"))
-        fn = mbconv_split if prefix in SPLIT_BLOCKS else mbconv_fused
-        y = fn(rec(prev), we.reshape(we.shape[0], -1), wd, wp.reshape(wp.shape[0], -1), k, s, cin == cout and s == 1)
+        we2, wp2, res = we.reshape(we.shape[0], -1), wp.reshape(wp.shape[0], -1), cin == cout and s == 1
+        if prefix in SPLIT_BLOCKS and (prefix + ".dw") in g:
+            # the record holds the depthwise tensor between the two launches of a split block: teacher-force each launch
+            # on its own (expand+depthwise on the block input, project GEMM on the RECORD's depthwise tensor)
+            worst[prefix + ".dw"] = ratio(expand_dw(rec(prev), we2, wd, k, s, out_scaled=False), rec(prefix + ".dw"))
+            y = pw_op(rec(prefix + ".dw"), wp2, residual=rec(prev) if res else None)
+        else:
+            fn = mbconv_split if prefix in SPLIT_BLOCKS else mbconv_fused
+            y = fn(rec(prev), we2, wd, wp2, k, s, res)
         worst[prefix] = ratio(y, rec(prefix))
         prev = prefix
     worst["conv_last"] = ratio(conv_last(rec("layer6.0"), sd), rec("conv_last"))

@@ -128,6 +128,8 @@ def _engine_record(eng, x):
             g["layer0.0"] = v
         elif name.endswith(".mbconv") or name.endswith(".project"):
             g[name.rsplit(".", 1)[0]] = v
+        elif name.endswith(".expand+dw"):
+            g[name.rsplit(".", 1)[0] + ".dw"] = v
         elif name in ("conv_last", "up1", "up2", "up3"):
             g[name] = v
         elif name in ("up3+heads", "heads"):
@@ -148,7 +150,7 @@ def test_bf16_engine_layer_by_layer_teacher_forced(size, B):
     eng = cfa.Engine(H, W, max_batch=B, dtype="bf16")
     g, rec = _engine_record(eng, x)
     stats = E.check_blockwise(SD, g, detail=True)
-    assert len(stats) == 11 + 1 + 3 + 4 + (1 if "up3" in g else 0), sorted(stats)
+    assert len(stats) == 11 + 1 + 3 + 4 + (1 if "up3" in g else 0) + sum(k.endswith(".dw") for k in g), sorted(stats)
     bad = {k: v for k, v in stats.items() if not E.accept(v, bf16_output=not k.startswith("head."))}
     assert not bad, bad
     # the split blocks' expand+depthwise launches (their output is an engine buffer too)
