@@ -37,6 +37,18 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 mfma_f16x4;
 static constexpr float kNegLog2e3 = -1.44269504088896341f, kNegLn23 = -0.69314718055994531f;
 
+// two fp32 -> packed bf16x2 (RNE) through the compiler's own v_cvt_pk_bf16_f32 selection, NOT the inline-asm pack_bf16x2 of
+// cf_common.h: here the packed dwords are MFMA operands a few instructions later, and hipcc pads no VALU-write -> MFMA-read
+// wait states for a register written inside an asm statement (seen as stale project operands on ~half the waves)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_v;
+__device__ __forceinline__ uint32_t packb(float lo, float hi) {
+    f32x2 v; v.x = lo; v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_v));
+}
+__device__ __forceinline__ u32x4 pack16b(const float* f) {
+    u32x4 c; c.x = packb(f[0], f[1]); c.y = packb(f[2], f[3]); c.z = packb(f[4], f[5]); c.w = packb(f[6], f[7]); return c;
+}
+
 __device__ __forceinline__ f32x2 swish2_pre(f32x2 u) {      // u = -log2(e) x  ->  u / (1 + 2^u) = -log2(e) swish(x)
     f32x2 e; e.x = __builtin_amdgcn_exp2f(u.x); e.y = __builtin_amdgcn_exp2f(u.y);
     const f32x2 den = e + 1.0f;
@@ -68,7 +80,7 @@ static inline uint16_t host_f32_to_f16_3(float f) {       // round-to-nearest-ev
 }
 
 // ---------------------------------------------------------------- geometry shared by host and device (stride 1)
-template <int KS, int JX, int TOH, int TOW, int NW>
+template <int KS, int JX, int TOH, int TOW, int NW, bool ALDS = true>
 struct Mx {
     static constexpr int HC = 32;                                   // hidden channels per round = 4 groups x 8
     static constexpr int IH = TOH + KS - 1, IWQ = TOW / 4 + 1, IWP = IWQ * 4;   // halo tile in x-quads (covers TOW + KS - 1)
@@ -77,8 +89,9 @@ struct Mx {
     static constexpr int EBYTES = NIB * 8 * CP;                     // whole pixel blocks: phase 1 stores are unconditional
     static constexpr int NOQ = TOH * (TOW / 4), NSET = (NOQ + 15) / 16;
     static constexpr int WXB = JX * 1024;                           // expand weight fragments of one round
-    static constexpr int LDS = EBYTES + WXB;
     static constexpr int NSTEP = KS * 2;                            // (ky, k-step) pairs per output quad
+    static constexpr int ATB = 2 * NSTEP * 512;                     // Toeplitz operand table of one round
+    static constexpr int LDS = EBYTES + WXB + (ALDS ? ATB : 0);
     static_assert(TOW % 4 == 0 && KS <= 5, "x-quads; two k-steps cover 4 + KS - 1 <= 8 inputs");
 };
 
@@ -146,11 +159,52 @@ __device__ __forceinline__ void mx_depthwise(const char* bb, const u32x2 (*A)[KS
     }
 }
 
+// the same with the Toeplitz operands read from an LDS copy of the round's table ([2][KS][2][64 lanes] x 8 B) one step ahead
+// instead of living in 24 / 40 VGPRs for the whole kernel
+template <int KS, int IWQ, int CP>
+__device__ __forceinline__ void mx_depthwise_lds(const char* bb, const char* at /* table + lane * 8 */, f32x4* acc) {
+    constexpr int NSTEP = KS * 2;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    u32x4 bq[2][4];
+    u32x2 aq[2][2];
+#pragma unroll
+    for (int g2 = 0; g2 < 4; ++g2) bq[0][g2] = ld16(bb + g2 * 16);
+    aq[0][0] = *reinterpret_cast<const u32x2*>(at);
+    aq[0][1] = *reinterpret_cast<const u32x2*>(at + NSTEP * 512);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) {
+            const int ky = (st + 1) >> 1, ks = (st + 1) & 1;
+#pragma unroll
+            for (int g2 = 0; g2 < 4; ++g2) bq[(st + 1) & 1][g2] = ld16(bb + (ky * IWQ + ks) * CP + g2 * 16);
+            aq[(st + 1) & 1][0] = *reinterpret_cast<const u32x2*>(at + (st + 1) * 512);
+            aq[(st + 1) & 1][1] = *reinterpret_cast<const u32x2*>(at + (NSTEP + st + 1) * 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, aq[st & 1][g >> 2]);
+            u32x2 b2;
+            b2.x = (g & 1) ? bq[st & 1][g >> 1].z : bq[st & 1][g >> 1].x;
+            b2.y = (g & 1) ? bq[st & 1][g >> 1].w : bq[st & 1][g >> 1].y;
+            const mfma_f16x4 bv = __builtin_bit_cast(mfma_f16x4, b2);
+            switch (g & 3) {
+                case 0: CF_MX_MFMA(acc[g], av, bv, 0); break;
+                case 1: CF_MX_MFMA(acc[g], av, bv, 1); break;
+                case 2: CF_MX_MFMA(acc[g], av, bv, 2); break;
+                default: CF_MX_MFMA(acc[g], av, bv, 3); break;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ================================================================== expand + depthwise (project stays a GEMM launch)
 // grid = (tiles, hid / 32, batch); one round of 32 hidden channels per workgroup; only the depthwise output reaches HBM
-template <int KS, int JX, int TOH, int TOW, int NW>
+template <int KS, int JX, int TOH, int TOW, int NW, bool ALDS>
 __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
-    typedef Mx<KS, JX, TOH, TOW, NW> G;
+    typedef Mx<KS, JX, TOH, TOW, NW, ALDS> G;
     constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, CP = G::CP, NSET = G::NSET, WXB = G::WXB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* E = smem;
@@ -170,9 +224,16 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void*)(Wst + c * 1024), 16, 0, 0);
     }
-    // Toeplitz A operands of this round: [2 channel quads][KS][2 k-steps] register pairs, resident for the whole kernel
-    u32x2 A[2][KS][2];
-    {
+    // Toeplitz A operands of this round ([2 channel quads][KS][2 k-steps][lane] x 8 B): an LDS copy next to the expand
+    // weights (ALDS: 81-110 VGPRs, + 6 / 10 KB of LDS) or resident register pairs (132-148 VGPRs)
+    char* Ats = Wst + WXB;
+    u32x2 A[ALDS ? 1 : 2][ALDS ? 1 : KS][2];
+    if constexpr (ALDS) {
+        const char* srca = (const char*)p.wdw + (size_t)grp * G::ATB;
+        for (int c = wave; c < G::ATB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
+    } else {
         const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)grp * (2 * KS * 2) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -206,6 +267,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
             xf[j].x = valid ? xf[j].x : 0u; xf[j].y = valid ? xf[j].y : 0u; xf[j].z = valid ? xf[j].z : 0u; xf[j].w = valid ? xf[j].w : 0u;
         }
     };
+    const int abl = p.nw;            // timing experiments only (CF_MX_ABL): 1 no depthwise MFMAs, 2 no output Swish, 4 no expand Swish, 8 one X load, 16 no stores
     u32x4 xa[JX];
     bool va = false;
     if (wave < NIB) va = load_x(wave, xa);
@@ -217,7 +279,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
         u32x4 xn[JX];
         const bool more = ib + NW < NIB;
         bool vn = false;
-        if (more) vn = load_x(ib + NW, xn);
+        if (more) { if (abl & 8) { for (int j = 0; j < JX; ++j) xn[j] = xa[j]; vn = va; } else vn = load_x(ib + NW, xn); }
         f32x16 a;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.0f;
@@ -232,7 +294,8 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x2 u0, u1; u0.x = a[4 * t]; u0.y = a[4 * t + 1]; u1.x = a[4 * t + 2]; u1.y = a[4 * t + 3];
-            const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+            f32x2 y0 = u0, y1 = u1;
+            if (!(abl & 4)) { y0 = swish2_pre(u0); y1 = swish2_pre(u1); }
             u32x2 d;
             d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
             d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
@@ -254,8 +317,16 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
         const int oy = (e >> 6) & 0x1ff, oxq = e & 63;
         const bool live = (e & 0x8000u) == 0;
         f32x4 acc[8];
-        mx_depthwise<KS, IWQ, CP>(E + (unsigned)(oy * IWQ + oxq) * (unsigned)CP + kg * 64, A, acc);
+        const char* bb = E + (unsigned)(oy * IWQ + oxq) * (unsigned)CP + kg * 64;
+        if (abl & 1) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) acc[g] = f32x4{(float)oy, (float)oxq, (float)g, 1.0f};
+        } else {
+        if constexpr (ALDS) mx_depthwise_lds<KS, IWQ, CP>(bb, Ats + lane * 8, acc);
+        else mx_depthwise<KS, IWQ, CP>(bb, reinterpret_cast<const u32x2 (*)[KS][2]>(A), acc);
+        }
         // a = -log2(e) * depthwise output -> Swish, leftover factor out again (the project GEMM has plain weights)
+        if (!(abl & 2))
 #pragma unroll
         for (int g = 0; g < 8; ++g)
 #pragma unroll
@@ -265,15 +336,15 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
                 acc[g][i] = y.x; acc[g][i + 1] = y.y;
             }
         const int gy = oy0 + oy, gx0 = ox0 + 4 * oxq;
-        if (!live || gy >= p.Hout) continue;
+        if (!live || gy >= p.Hout || ((abl & 16) && acc[0][0] != 123.0f)) continue;
         const size_t opix0 = ((size_t)b * p.Hout + gy) * p.Wout + gx0;
         const int chunk = grp * 4 + kg;                               // 8-channel chunk of the depthwise tensor
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (gx0 + i >= p.Wout) break;
             u32x4 o;
-            o.x = pack_bf16x2(acc[0][i], acc[1][i]); o.y = pack_bf16x2(acc[2][i], acc[3][i]);
-            o.z = pack_bf16x2(acc[4][i], acc[5][i]); o.w = pack_bf16x2(acc[6][i], acc[7][i]);
+            o.x = packb(acc[0][i], acc[1][i]); o.y = packb(acc[2][i], acc[3][i]);
+            o.z = packb(acc[4][i], acc[5][i]); o.w = packb(acc[6][i], acc[7][i]);
             const size_t opix = opix0 + i;
             st16((char*)p.y + (p.yblock ? blk_off(opix, p.hid / 8, chunk) : (opix * p.hid + (size_t)chunk * 8) * 2), o);
         }
@@ -287,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
 // is the lane's quad slot: project accumulators D[out channel][quad slot] per pixel i, in registers across the rounds.
 // MFMA row m <-> output channel 32 (mb >> 1) + 8 (m >> 2) + 4 (mb & 1) + (m & 3): lane group kq = lane >> 4 ends up with the
 // eight consecutive channels 8 kq .. 8 kq + 7 (+32 for the second pair of M blocks) of its pixels = 16-byte stores.
-template <int KS, int JX, int NMB, int TOH, int TOW, int NW, bool TAIL16>
+template <int KS, int JX, int NMB, int TOH, int TOW, int NW, bool TAIL16, bool ALDS = false>
 struct Fx {
     static constexpr int IH = TOH + KS - 1, IWQ = TOW / 4 + 1, IWP = IWQ * 4;
     static constexpr int NQD = IH * IWQ, NIB = (NQD + 7) / 8, IPX = NQD * 4, MAXI = (NIB + NW - 1) / NW;
@@ -295,20 +366,22 @@ struct Fx {
     static constexpr int EBYTES = NIB * 8 * CP8;
     static constexpr int NOQ = TOH * (TOW / 4), NSET = (NOQ + 15) / 16, SPW = NSET / NW;
     static constexpr int WXB = JX * 1024;
-    static constexpr int LDS = EBYTES + 2 * WXB;
+    static constexpr int ATB = 2 * KS * 2 * 512;                    // Toeplitz operand table of one round (LDS copy when ALDS)
+    static constexpr int LDS = EBYTES + 2 * WXB + (ALDS ? ATB : 0);
     static_assert(NSET % NW == 0, "every wave owns SPW whole sets (project accumulators live in registers)");
-    static_assert(TOW % 4 == 0 && KS <= 5 && (NMB == 2 || NMB == 4), "geometry");
+    static_assert(TOW % 4 == 0 && KS <= 5 && (NMB == 2 || NMB == 4 || NMB == 6), "geometry");
     static_assert(!TAIL16 || JX <= 2, "16-channel round: one 16x16x32 expand MFMA, Cin <= 32");
 };
 
-template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16>
+template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16, bool XRELOAD, bool ALDS>
 __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
-    typedef Fx<KS, JX, NMB, TOH, TOW, NW, TAIL16> G;
+    typedef Fx<KS, JX, NMB, TOH, TOW, NW, TAIL16, ALDS> G;
     constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, MAXI = G::MAXI, CP8 = G::CP8, CP4 = G::CP4;
     constexpr int SPW = G::SPW, WXB = G::WXB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* E = smem;
     char* Wst = smem + G::EBYTES;
+    char* Ats = Wst + 2 * G::WXB;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -327,9 +400,10 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
                                              (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
     };
 
-    // X fragments of this wave's halo pixel blocks (MFMA A operand: lane = pixel, 8 contiguous Cin per half), resident;
-    // clamped address + zero select = ZeroPad2d without predicated loads
+    // X fragments of this wave's halo pixel blocks (MFMA A operand: lane = pixel, 8 contiguous Cin per half): resident, or
+    // (XRELOAD) fetched again from L2 at the top of every round; clamped address + zero select = ZeroPad2d
     u32x4 xf[MAXI][JX];
+    auto load_x = [&]() {
 #pragma unroll
     for (int t = 0; t < MAXI; ++t) {
         const int ib = wave + NW * t;
@@ -347,6 +421,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
             xf[t][j].z = valid ? v.z : 0u; xf[t][j].w = valid ? v.w : 0u;
         }
     }
+    };
+    if constexpr (!XRELOAD) load_x();
 
     // this wave's output quads: one per (set, lane & 15)
     static constexpr SetMap<TOH, TOW, IWQ> kSets{};
@@ -368,8 +444,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
     stage_weights(0);
     for (int q = 0; q < nq; ++q) {
         // Toeplitz operands + project fragments of this round: requested before the expand phase, used after it
-        u32x2 A[2][KS][2];
-        {
+        u32x2 A[ALDS ? 1 : 2][ALDS ? 1 : KS][2];
+        if constexpr (!ALDS) {
             const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)q * (2 * KS * 2) * 64 + lane;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -382,7 +458,14 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb) wpc[mb] = ld16((const char*)p.wproj + (((size_t)q * NMB + mb) * 64 + lane) * 16);
         const char* wx = Wst + (q & 1) * WXB;
-        __syncthreads();      // previous round's depthwise done with E; this round's expand weights landed
+        if constexpr (XRELOAD) load_x();
+        __syncthreads();      // previous round's depthwise done with E (and the operand table); this round's expand weights landed
+        if constexpr (ALDS) {      // this round's Toeplitz table -> LDS under the expand phase (the next barrier drains it)
+            const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
+            for (int c = wave; c < G::ATB / 1024; c += NW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
+        }
 
         // ---- phase 1: expand + Swish -> quad cells
 #pragma unroll
@@ -416,7 +499,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
 #pragma unroll
         for (int sw = 0; sw < SPW; ++sw) {
             f32x4 acc[8];
-            mx_depthwise<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, A, acc);
+            if constexpr (ALDS) mx_depthwise_lds<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, Ats + lane * 8, acc);
+            else mx_depthwise<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, reinterpret_cast<const u32x2 (*)[KS][2]>(A), acc);
 #pragma unroll
             for (int g = 0; g < 8; ++g)
 #pragma unroll
@@ -428,8 +512,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 u32x4 d;
-                d.x = pack_bf16x2(acc[0][i], acc[1][i]); d.y = pack_bf16x2(acc[2][i], acc[3][i]);
-                d.z = pack_bf16x2(acc[4][i], acc[5][i]); d.w = pack_bf16x2(acc[6][i], acc[7][i]);
+                d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
+                d.z = packb(acc[4][i], acc[5][i]); d.w = packb(acc[6][i], acc[7][i]);
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb)
                     pacc[sw][i][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wpc[mb]),
@@ -502,7 +586,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
                 }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                u32x2 d; d.x = pack_bf16x2(acc[0][i], acc[1][i]); d.y = pack_bf16x2(acc[2][i], acc[3][i]);
+                u32x2 d; d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb)
                     pacc[sw][i][mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mfma_bf16x4, wp4[mb]),
@@ -536,7 +620,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = rr[r] + v[r];
                 }
-                st16((char*)p.y + (p.yblock ? blk_off(opix, p.Cout / 8, ch / 8) : (opix * p.Cout + ch) * 2), pack16<bf16_t>(v));
+                st16((char*)p.y + (p.yblock ? blk_off(opix, p.Cout / 8, ch / 8) : (opix * p.Cout + ch) * 2), pack16b(v));
             }
         }
     }
@@ -547,10 +631,10 @@ struct MxEntry {
     int k, jx, toh, tow, nw, var, lds_bytes;
     hipError_t (*fn)(hipStream_t, const MbParams&);
 };
-template <int KS, int JX, int TOH, int TOW, int NW>
+template <int KS, int JX, int TOH, int TOW, int NW, bool ALDS>
 static hipError_t xmx_launch_t(hipStream_t s, const MbParams& p) {
-    typedef Mx<KS, JX, TOH, TOW, NW> G;
-    auto kfn = expdw_mx_kernel<KS, JX, TOH, TOW, NW>;
+    typedef Mx<KS, JX, TOH, TOW, NW, ALDS> G;
+    auto kfn = expdw_mx_kernel<KS, JX, TOH, TOW, NW, ALDS>;
     static thread_local bool configured_dev[32] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     bool& configured = configured_dev[dev & 31];
@@ -560,27 +644,34 @@ static hipError_t xmx_launch_t(hipStream_t s, const MbParams& p) {
         configured = true;
     }
     dim3 grid(((p.Wout + TOW - 1) / TOW) * ((p.Hout + TOH - 1) / TOH), p.hid / 32, p.B), blk(NW * 64);
-    set_kernel_tag("void cf::expdw_mx_kernel<%d, %d, %d, %d, %d>(cf::MbParams)", KS, JX, TOH, TOW, NW);
-    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
+    set_kernel_tag("void cf::expdw_mx_kernel<%d, %d, %d, %d, %d, %s>(cf::MbParams)", KS, JX, TOH, TOW, NW, ALDS ? "true" : "false");
+    static const int abl = getenv("CF_MX_ABL") ? atoi(getenv("CF_MX_ABL")) : 0;      // timing experiments only: results invalid
+    MbParams q = p; q.nw = abl;
+    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, q);
     return hipGetLastError();
 }
-#define XMX(V, KS, JX, TOH, TOW, NW) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW>::LDS, &xmx_launch_t<KS, JX, TOH, TOW, NW>}
+#define XMX(V, KS, JX, TOH, TOW, NW, AL) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, (AL != 0)>::LDS, &xmx_launch_t<KS, JX, TOH, TOW, NW, (AL != 0)>}
 static const MxEntry kXmxTable[] = {
-    //  var KS JX  tile   waves
-    XMX(0, 5, 4, 20, 40, 4),      // 4.0   64 -> 384, 40x40
-    XMX(0, 5, 6, 20, 40, 4),      // 4.1   96 -> 576, 40x40
-    XMX(0, 5, 10, 20, 20, 4),     // 5.1  160 -> 960, 20x20
-    XMX(0, 3, 10, 20, 20, 4),     // 6.0  160 -> 960, 20x20
-    XMX(1, 5, 4, 8, 40, 5),
-    XMX(1, 5, 6, 8, 40, 5),
-    XMX(1, 5, 10, 20, 20, 7),
-    XMX(1, 3, 10, 20, 20, 7),
-    XMX(3, 5, 4, 20, 40, 7),
-    XMX(3, 5, 6, 20, 40, 7),
-    XMX(2, 5, 4, 10, 40, 4),
-    XMX(2, 5, 6, 10, 40, 4),
-    XMX(2, 5, 10, 10, 20, 4),
-    XMX(2, 3, 10, 10, 20, 4),
+    //  var KS JX  tile   waves  A in LDS          (B = 64, 640x640, HIP events; expdw_px_kernel of the layer in brackets)
+    XMX(0, 5, 4, 10, 40, 8, 1),      // 4.0   64 -> 384, 40x40: 0.055 ms [0.066]
+    XMX(0, 5, 6, 10, 40, 8, 1),      // 4.1   96 -> 576, 40x40: 0.083 ms [0.101]
+    XMX(0, 5, 10, 20, 20, 4, 0),     // 5.1  160 -> 960, 20x20: 0.047 ms [0.057]
+    XMX(0, 3, 10, 10, 20, 4, 1),     // 6.0  160 -> 960, 20x20: 0.042 ms [0.044]
+    // variants for A/B runs (CF_MX_VARIANT=n): all within +-8 % of the above
+    XMX(1, 5, 4, 8, 40, 5, 1),
+    XMX(1, 5, 6, 8, 40, 5, 1),
+    XMX(1, 5, 10, 20, 20, 7, 1),
+    XMX(1, 3, 10, 20, 20, 7, 1),
+    XMX(2, 5, 4, 20, 40, 4, 0),
+    XMX(2, 5, 6, 20, 40, 4, 0),
+    XMX(2, 5, 10, 20, 20, 4, 1),
+    XMX(2, 3, 10, 20, 20, 4, 1),
+    XMX(3, 5, 4, 10, 40, 4, 0),
+    XMX(3, 5, 6, 10, 40, 4, 0),
+    XMX(3, 5, 10, 10, 20, 4, 1),
+    XMX(3, 3, 10, 20, 20, 4, 0),
+    XMX(4, 5, 4, 20, 40, 7, 0),
+    XMX(4, 5, 6, 20, 40, 7, 0),
 };
 #undef XMX
 static const MxEntry* xmx_find(int k, int jx) {
@@ -662,10 +753,10 @@ struct FxEntry {
     int k, jx, nmb, res, tail, toh, tow, nw, var, lds_bytes;
     hipError_t (*fn)(hipStream_t, const MbParams&);
 };
-template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16>
+template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16, bool XRELOAD, bool ALDS>
 static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
-    typedef Fx<KS, JX, NMB, TOH, TOW, NW, TAIL16> G;
-    auto kfn = mbconv_mx_kernel<KS, JX, NMB, RESID, TOH, TOW, NW, TAIL16>;
+    typedef Fx<KS, JX, NMB, TOH, TOW, NW, TAIL16, ALDS> G;
+    auto kfn = mbconv_mx_kernel<KS, JX, NMB, RESID, TOH, TOW, NW, TAIL16, XRELOAD, ALDS>;
     static thread_local bool configured_dev[32] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     bool& configured = configured_dev[dev & 31];
@@ -675,23 +766,28 @@ static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
         configured = true;
     }
     dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
-    set_kernel_tag("void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false",
-                   TOH, TOW, NW, TAIL16 ? "true" : "false");
+    set_kernel_tag("void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false",
+                   TOH, TOW, NW, TAIL16 ? "true" : "false", XRELOAD ? "true" : "false", ALDS ? "true" : "false");
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
     return hipGetLastError();
 }
-#define FXE(V, KS, JX, NMB, RES, TAIL, TOH, TOW, NW) \
-    {KS, JX, NMB, RES, TAIL, TOH, TOW, NW, V, Fx<KS, JX, NMB, TOH, TOW, NW, (TAIL != 0)>::LDS, &fx_launch_t<KS, JX, NMB, (RES != 0), TOH, TOW, NW, (TAIL != 0)>}
+#define FXE(V, KS, JX, NMB, RES, TAIL, TOH, TOW, NW, XR, AL) \
+    {KS, JX, NMB, RES, TAIL, TOH, TOW, NW, V, Fx<KS, JX, NMB, TOH, TOW, NW, (TAIL != 0), (AL != 0)>::LDS, \
+     &fx_launch_t<KS, JX, NMB, (RES != 0), TOH, TOW, NW, (TAIL != 0), (XR != 0), (AL != 0)>}
 static const FxEntry kFxTable[] = {
-    //  var KS JX NMB res tail  tile   waves
-    FXE(0, 3, 2, 2, 1, 1, 16, 20, 5),     // 1.1  24 -> 144 -> 24 (+res), 160x160: four rounds of 32 + one of 16
-    FXE(0, 5, 2, 2, 1, 0, 16, 20, 5),     // 2.1  32 -> 192 -> 32 (+res), 80x80
-    FXE(0, 3, 4, 4, 1, 0, 8, 40, 5),      // 3.1  64 -> 384 -> 64 (+res), 40x40
-    FXE(1, 3, 2, 2, 1, 1, 16, 16, 4),
-    FXE(1, 5, 2, 2, 1, 0, 16, 16, 4),
-    FXE(1, 3, 4, 4, 1, 0, 16, 16, 4),
-    FXE(2, 3, 2, 2, 1, 1, 32, 16, 4),
-    FXE(2, 5, 2, 2, 1, 0, 16, 40, 5),
+    //  var KS JX NMB res tail  tile   waves  X reload  A in LDS        (B = 64, 640x640, HIP events; cf_mbconv2.hip kernel of the layer in brackets)
+    FXE(0, 5, 2, 2, 1, 0, 16, 16, 4, 0, 1),     // 2.1  32 -> 192 -> 32 (+res), 80x80: 0.076 ms [0.120]
+    FXE(0, 3, 2, 2, 1, 1, 16, 16, 4, 0, 1),     // 1.1  24 -> 144 -> 24 (+res), 160x160, four rounds of 32 + one of 16: 0.175 ms [0.205]
+    // variants for A/B runs (CF_FX_VARIANT=n); 3.1 (64 -> 384 -> 64, 40x40) stays on cf_mbconv2.hip: 0.097-0.106 ms here against 0.063,
+    // and the Cout = 96 blocks (4.0 / 4.1) stay split (fused here: 0.115 / 0.210 ms against 0.082 / 0.120 for the two launches)
+    FXE(1, 5, 2, 2, 1, 0, 16, 16, 4, 1, 1),
+    FXE(2, 5, 2, 2, 1, 0, 16, 16, 4, 0, 0),
+    FXE(3, 5, 2, 2, 1, 0, 16, 20, 5, 0, 1),
+    FXE(1, 3, 2, 2, 1, 1, 16, 16, 4, 1, 1),
+    FXE(2, 3, 2, 2, 1, 1, 16, 20, 5, 0, 1),
+    FXE(3, 3, 2, 2, 1, 1, 32, 16, 4, 1, 1),
+    FXE(1, 3, 4, 4, 1, 0, 16, 16, 4, 1, 1),
+    FXE(2, 3, 4, 4, 1, 0, 8, 40, 5, 1, 1),
 };
 #undef FXE
 static const FxEntry* fx_find(int k, int jx, int nmb, int res, int tail) {
@@ -707,8 +803,8 @@ static const FxEntry* fx_find(int k, int jx, int nmb, int res, int tail) {
 
 bool mx_fused_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
     static const bool off = getenv("CF_FX") && atoi(getenv("CF_FX")) == 0;
-    if (off || s != 1 || (Cin % 8) || (Cout % 8) || Cout > 64 || (hid % 16) || hid == Cin) return false;
-    const int jx = (Cin * 2 / 16 + 1) / 2, nmb = Cout <= 32 ? 2 : 4, tail = (hid % 32) ? 1 : 0;
+    if (off || s != 1 || (Cin % 8) || (Cout % 8) || Cout > 96 || (hid % 16) || hid == Cin) return false;
+    const int jx = (Cin * 2 / 16 + 1) / 2, nmb = 2 * ((Cout + 31) / 32), tail = (hid % 32) ? 1 : 0;
     const FxEntry* e = fx_find(k, jx, nmb, (Cin == Cout) ? 1 : 0, tail);
     if (!e) return false;
     g = MbGeom{};
@@ -781,7 +877,7 @@ void mx_fused_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, c
 }
 
 hipError_t mx_fused_launch(hipStream_t s, const MbParams& p) {
-    const FxEntry* e = fx_find(p.k, p.JX, p.Cout <= 32 ? 2 : 4, p.residual ? 1 : 0, (p.hid % 32) ? 1 : 0);
+    const FxEntry* e = fx_find(p.k, p.JX, 2 * ((p.Cout + 31) / 32), p.residual ? 1 : 0, (p.hid % 32) ? 1 : 0);
     if (!e || p.s != 1) return hipErrorInvalidValue;
     return e->fn(s, p);
 }
