@@ -64,6 +64,9 @@ def parse(argv=None):
     ap.add_argument("--gather", default="auto", choices=["auto", "cf", "torch"],
                     help="N > 1 gather of the final boxes: cf = cf_gather_topk (C ABI, RCCL), torch = torch.distributed; "
                          "auto = cf, falling back to torch if the communicator cannot be created")
+    ap.add_argument("--gather-timeout", type=float, default=60.0,
+                    help="seconds the first (warm-up) RCCL gather may take; on expiry on ANY rank every rank aborts its communicator "
+                         "and the run continues with --gather torch --depth 1 (agreed over the TCP store, not over NCCL)")
     ap.add_argument("--exercise-gather-path", action="store_true",
                     help="run the N>1 step (decode-stream gather, identity at world 1) on one GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -133,16 +136,16 @@ def flush_c_stdio():
 def make_step(cfa, engs, d_in_ptr, B, K, outs, gather="none", comms=None):
     """One benchmark step as a closure: forward + top-K decode (+ gather) of one batch.
 
-    ``engs`` / ``outs`` / ``comms``: one Engine / output dict / Comm, or lists of ``depth`` of them -- step k then runs
-    on context k % depth (cfa.EngineRing's schedule: two batches in flight, the back half of one forward under the front
+    ``engs`` / ``outs``: one Engine / output dict, or lists of ``depth`` of them -- step k then runs on context k % depth;
+    ``comms``: the rank's ONE Comm (every context gathers through it, on its single gather stream, in step order)
+    -- (cfa.EngineRing's schedule: two batches in flight, the back half of one forward under the front
     half of the next).  ``out``: dict of device tensors dets/lms/inds and ``all`` (the gathered records).
     gather: none | cf (cf_gather_topk on the decode stream) | torch (torch.distributed)."""
     import torch
     fmt = cfa._lib.CF_IN_U8_HWC_BGR
     if not isinstance(engs, (list, tuple)):
-        engs, outs, comms = [engs], [outs], [comms]
-    if comms is None:
-        comms = [None] * len(engs)
+        engs, outs = [engs], [outs]
+    comm = comms[0] if isinstance(comms, (list, tuple)) else comms       # ONE communicator per rank, shared by its contexts
     depth, k = len(engs), [0]
     if gather == "torch":
         # the decode stream of the context and torch's stream (pack + all-gather) are chained with stream waits,
@@ -155,7 +158,7 @@ def make_step(cfa, engs, d_in_ptr, B, K, outs, gather="none", comms=None):
         eng, out = engs[i], outs[i]
         eng.forward_enqueue(d_in_ptr, on_device=True, B=B, in_format=fmt)
         if gather == "cf":
-            comms[i].gather_topk_device(K, out["all"].data_ptr())
+            comm.gather_topk_device(K, out["all"].data_ptr(), engine=eng)
             return out["all"]
         if gather == "torch":
             dec_streams[i].wait_stream(torch.cuda.current_stream())      # this slot's last pack has consumed dets / lms
@@ -271,34 +274,52 @@ def main():
         for cm in comms:
             cm.close()
         del comms[:]
+    fallback = None
     if world > 1 or args.exercise_gather_path:
         gather = "torch" if args.gather == "torch" else "cf"
         if gather == "cf":
-            # rendezvous over the torch.distributed store (one RCCL communicator per context, created in the same order on
-            # every rank); every rank learns whether ALL ranks got their communicators
+            # ONE RCCL communicator per rank (rendezvous of the 128-byte id over the torch.distributed store), shared by the
+            # rank's contexts.  Creation and the first gather are checked against a deadline, and the verdict is agreed over
+            # the TCP store -- never over NCCL, which is the thing under suspicion.
             ok = 1
-            uids = [cfa.distributed.broadcast_unique_id() if world > 1 else cfa.distributed.unique_id() for _ in engs]
             try:
-                for e, uid in zip(engs, uids):
-                    comms.append(cfa.distributed.Comm(e, rank, world, uid))
+                uid = cfa.distributed.broadcast_unique_id() if world > 1 else cfa.distributed.unique_id()
+                comms.append(cfa.distributed.Comm(engs[0], rank, world, uid))
             except Exception as exc:                                   # noqa: BLE001
                 ok = 0
                 print("rank %d: cf_comm_create failed (%s)" % (rank, exc), file=sys.stderr)
-            if world > 1:
-                t = torch.tensor([ok], dtype=torch.int32, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                ok = int(t.item())
-            if not ok:
+            if not cfa.distributed.agree(ok, rank, world, "cf_comm_created"):
+                fallback = "cf_comm_create failed on some rank"
+            else:
+                try:
+                    for e, o in zip(engs, outs):               # warm-up gather of every context, in step order
+                        e.forward_enqueue(d_in.data_ptr(), on_device=True, B=B, in_format=cfa._lib.CF_IN_U8_HWC_BGR)
+                        comms[0].gather_topk_device(K, o["all"].data_ptr(), engine=e)
+                    ok = 1 if (args.gather_timeout >= 0 and comms[0].wait(args.gather_timeout)) else 0      # < 0: forced fallback (tests)
+                except Exception as exc:                                   # noqa: BLE001
+                    ok = 0
+                    print("rank %d: first cf_gather_topk failed (%s)" % (rank, exc), file=sys.stderr)
+                if not cfa.distributed.agree(ok, rank, world, "cf_first_gather"):
+                    fallback = "first RCCL gather did not complete within %.0f s on some rank" % args.gather_timeout
+            if fallback:
                 if args.gather == "cf":
+                    print("rank %d: %s" % (rank, fallback), file=sys.stderr)
                     sys.exit(4)
-                close_comms()
+                for cm in comms:
+                    cm.abort()
+                del comms[:]
                 gather = "torch"
+                for e in engs[1:]:                                         # the fallback is the conservative schedule: one context
+                    e.close()
+                engs, outs, D = engs[:1], outs[:1], 1
     step = make_step(cfa, engs, d_in.data_ptr(), B, K, outs, gather, comms if gather == "cf" else None)
     flush_c_stdio()          # librccl prints a version banner through C stdio when a communicator is created: get it out now
 
     def fence():
         for e in engs:
             e.synchronize()
+        for cm in comms:
+            cm.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -344,11 +365,43 @@ def main():
         for a in agg.values():
             k = kinds.setdefault(a["kind"], dict(ms=0.0, bytes=0.0))
             k["ms"] += a["ms"] / args.profile_reps; k["bytes"] += a["bytes"] / args.profile_reps
+        # ---- the roof that actually binds the fused kernels: VALU instruction issue.  Dynamic instruction counts per launch
+        # (rocprofv3 --pmc SQ_INSTS_*, committed as profiles/*_valu_counts.json by tools/valu_bound.py for THIS workload) x the
+        # committed issue costs, against this run's launch durations (HIP events) and the committed rocprofv3 durations.
+        valu_issue = None
+        try:
+            import glob
+            vj = sorted(glob.glob(os.path.join(REPO, "profiles", "*_valu_counts.json")))[-1]
+            vc = json.load(open(vj))
+            if (B, S, args.dtype) == (64, 640, "bf16"):
+                per, sb, sm, sr = [], 0.0, 0.0, 0.0
+                for name, a in agg.items():
+                    kc = vc["kernels"].get(name)
+                    if kc is None:
+                        continue
+                    n = a["launches"] // args.profile_reps
+                    ms = a["ms"] / args.profile_reps
+                    sb += kc["bound_us"] * n * 1e-3; sm += ms; sr += kc["rocprof_avg_us"] * n * 1e-3
+                    per.append({"kernel": name, "launches": n, "bound_ms": round(kc["bound_us"] * n * 1e-3, 4), "measured_ms": round(ms, 4),
+                                "rocprof_ms": round(kc["rocprof_avg_us"] * n * 1e-3, 4), "frac": round(kc["bound_us"] * n * 1e-3 / ms, 3) if ms > 0 else None})
+                per.sort(key=lambda r: -r["measured_ms"])
+                valu_issue = {"bound_ms": round(sb, 4), "measured_ms": round(sm, 4), "rocprof_ms": round(sr, 4),
+                              "frac": round(sb / sm, 4) if sm > 0 else None, "frac_vs_rocprof": round(sb / sr, 4) if sr > 0 else None,
+                              "counts": os.path.basename(vj), "per_kernel": per[:12],
+                              "note": "sum over the forward's kernels of (wave-instruction counts x issue cost) / 1024 SIMDs / 2.4 GHz; measured = HIP events "
+                                      "of this run (one context), rocprof = committed rocprofv3 --kernel-trace averages of the same kernels"}
+        except Exception:                                   # noqa: BLE001
+            valu_issue = None
+        dom_valu = None
+        if valu_issue:
+            dom_valu = next((r["frac"] for r in valu_issue["per_kernel"] if r["kernel"] == dom_name), None)
+        hbm_frac = achieved / HBM_PEAK_GBS
         roofline = {
-            "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "bound": "valu_issue" if (dom_valu is not None and dom_valu > hbm_frac) else "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": avg_bytes,
             "launches_per_forward": dom["launches"] // args.profile_reps, "layers": sorted(dom["layers"]),
+            "valu_issue_frac": dom_valu, "valu_issue": valu_issue,
             "forward_ms_sum_of_kernels": round(tot_ms, 3),
             # the fused kernels are VALU-issue bound (Swish: two transcendentals per expanded element), not HBM- or
             # MFMA-bound: DESIGN.md section 4, profiles/r01_valu_microbench.md; whole-forward algorithmic rate:
@@ -370,9 +423,10 @@ def main():
                                       B, S, S, args.dtype, K, " + RCCL all-gather of boxes" if world > 1 else "", D, D),
                        "batch_per_gpu": B, "global_batch": B * world, "image": [S, S], "topk": K,
                        "parallelism": "dp%d" % world,
-                       "contexts_per_gpu": D,
-                       "gather": {"none": None, "cf": "cf_gather_topk (C ABI, ncclAllGather on the decode stream)",
-                                  "torch": "torch.distributed.all_gather_into_tensor"}[gather]},
+                       "contexts_per_gpu": len(engs),
+                       "gather": {"none": None, "cf": "cf_gather_topk (C ABI: decode on the context's decode stream, ncclAllGather on the rank's one gather stream / one communicator)",
+                                  "torch": "torch.distributed.all_gather_into_tensor"}[gather],
+                       "gather_fallback": fallback},
             "windows": {"n": len(wins), "steps_each": args.steps, "median_ms": round(1e3 * med, 3),
                         "min_ms": round(1e3 * min(wins), 3), "max_ms": round(1e3 * max(wins), 3),
                         "value_min": round(world * B * args.steps / max(wins), 1), "value_max": round(world * B * args.steps / min(wins), 1)},

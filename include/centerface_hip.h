@@ -9,8 +9,9 @@
  *   - plain C types only; no torch / HIP types cross the boundary (device pointers travel as void*).
  *   - every function returns 0 (CF_OK) or a negative CF_E* code; cf_last_error(ctx) gives the text.
  *     The library never aborts and never falls back to a CPU path.
- *   - one cf_ctx = one GPU + one HIP stream; calls on a ctx are serialised by the caller; different
- *     ctxs may be driven from different threads / processes (one process per GPU for multi-GPU).
+ *   - one cf_ctx = one GPU + its own HIP streams (forward, decode, input copy), buffers and graphs; calls on a ctx are
+ *     serialised by the caller; different ctxs may be driven from different threads / processes (one process per GPU
+ *     for multi-GPU; two ctxs on one GPU used alternately keep two batches in flight).
  *   - host outputs are written into CALLER-ALLOCATED buffers; nothing allocated here crosses back.
  *   - activations live in HBM as NHWC (channels contiguous), fp32 or bf16 storage, fp32 accumulate.
  */
@@ -166,12 +167,28 @@ int cf_detect_topk(cf_ctx* ctx, const void* in, int in_format, int in_on_device,
 #define CF_COMM_ID_BYTES 128
 typedef struct cf_comm cf_comm;
 int cf_comm_unique_id(void* id, int bytes);
+/* ONE communicator per rank (= per GPU), whatever the number of contexts on that GPU: it owns the rank's single gather
+ * stream, and every all-gather of every context of the rank is enqueued there in call order -- all ranks then see the same
+ * collective order as long as they call cf_gather_topk in the same order (concurrent communicators on free-running streams
+ * have no such guarantee and may deadlock).  `ctx` only names the device. */
 int cf_comm_create(cf_ctx* ctx, int rank, int world, const void* id, cf_comm** out);
+/* Single process / single thread that owns one context per GPU: the n ncclCommInitRank calls inside one
+ * ncclGroupStart/End (un-grouped, the first call would block forever waiting for the others).  out[i] = rank i = ctxs[i]. */
+int cf_comm_create_all(cf_ctx** ctxs, int n, cf_comm** out);
 int cf_comm_destroy(cf_comm* comm);
+/* Give up on a communicator whose collective does not complete (ncclCommAbort: in-flight RCCL kernels exit), then release
+ * it.  cf_comm_query: 0 = every enqueued gather has completed, 1 = still running (never blocks) -- a host polls it
+ * against its own deadline and aborts instead of hanging in a synchronize. */
+int cf_comm_abort(cf_comm* comm);
+int cf_comm_query(cf_comm* comm);
+int cf_comm_synchronize(cf_comm* comm);
+void* cf_comm_stream(cf_comm* comm);                    /* the gather stream (hipStream_t) */
 /* D3 decode of the last forward (as cf_decode_topk) followed by the all-gather: records [world * B, K, 16] =
- * x1,y1,x2,y2,score,cls,lm0..lm9 per detection, rank-major = exactly the batch order of the unsharded run (every
- * rank must pass the same B and K).  Runs on the decode stream underneath the next forward.  out_on_device = 1:
- * `records` is a device buffer, the call is asynchronous (cf_synchronize before reading it); 0: host buffer, blocking. */
+ * x1,y1,x2,y2,score,cls,lm0..lm9 per detection, rank-major = exactly the batch order of the unsharded run.  Every rank
+ * must pass the same B and K: the first gather at a new B checks it with one extra small collective and fails with
+ * CF_EINVAL on a mismatch instead of hanging.  The decode runs on the context's decode stream, the all-gather on the
+ * communicator's stream behind it, both underneath the next forward.  out_on_device = 1: `records` is a device buffer,
+ * the call is asynchronous (cf_synchronize / cf_comm_synchronize before reading it); 0: host buffer, blocking. */
 int cf_gather_topk(cf_ctx* ctx, cf_comm* comm, int K, int use_reg, float* records, int out_on_device);
 
 /* ---- stream / timing plumbing -------------------------------------------------------------- */

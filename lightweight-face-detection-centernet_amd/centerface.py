@@ -275,6 +275,20 @@ class Engine(object):
         buf = (C.c_char * max(n, 1)).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def pinned_raw(self, nbytes):
+        """(pointer, capacity) of a fresh page-locked host buffer owned by the engine (freed at close or by pinned_free)."""
+        p = C.c_void_p()
+        self._chk(self._L.cf_host_alloc(self._h, max(int(nbytes), 1), C.byref(p)))
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(p)
+        return p, int(nbytes)
+
+    def pinned_free(self, p):
+        """Release one buffer of pinned_array / pinned_raw now (no copy from it may be in flight)."""
+        self._pinned = [q for q in getattr(self, "_pinned", []) if q.value != p.value]
+        self._L.cf_host_free(self._h, p)
+
     def device_alloc(self, nbytes):
         p = C.c_void_p()
         self._chk(self._L.cf_device_alloc(self._h, int(nbytes), C.byref(p)))
@@ -591,12 +605,20 @@ class CenterFaceBuckets(object):
         return eng
 
     def _staging(self, eng, n, h, w):
-        """Page-locked staging array [n, h, w, 3] of an engine (one per raw size and chunk length, reused)."""
-        cache = eng.__dict__.setdefault("_staging", {})
-        key = (n, h, w)
-        if key not in cache:
-            cache[key] = eng.pinned_array((n, h, w, 3), np.uint8)
-        return cache[key]
+        """Page-locked staging view [n, h, w, 3] into the engine's ONE grow-only pinned buffer (sized to the largest
+        n * h * w * 3 seen).  A WIDER-style run has hundreds of distinct raw sizes and tail lengths: one pinned array per
+        (n, h, w) would pile up GBs of page-locked memory, each allocation a device-synchronising hipHostMalloc.  Reuse
+        is safe: an engine stages one chunk per round and the round ends with its decode_threshold (a synchronise)."""
+        need = int(n) * int(h) * int(w) * 3
+        st = eng.__dict__.get("_stage")
+        if st is None or st[1] < need:
+            if st is not None:
+                eng.synchronize()
+                eng.pinned_free(st[0])
+            cap = max(need, int(1.25 * st[1]) if st is not None else need)
+            eng.__dict__["_stage"] = st = eng.pinned_raw(cap)
+        buf = (C.c_char * need).from_address(st[0].value)
+        return np.frombuffer(buf, dtype=np.uint8, count=need).reshape(n, h, w, 3)
 
     def detect(self, imgs, threshold=0.2):
         del threshold                                              # ignored by the reference's decode (centerface.py:77)

@@ -123,6 +123,15 @@ __device__ __forceinline__ void dot8_first(float* A, const u32x8_t& W, const u32
           "v"(E0.x), "v"(E0.y), "v"(E0.z), "v"(E0.w), "v"(E1.x), "v"(E1.y), "v"(E1.z), "v"(E1.w));
 }
 
+// Publish LDS-DMA data (__builtin_amdgcn_global_load_lds) to the other waves of the workgroup.  The compiler makes the
+// ISSUING wave wait (vmcnt) before its own reads of that LDS range, but those come after the barrier: the s_barrier itself
+// gets no vmcnt wait, so another wave can pass it and read the range before the DMA has landed (seen as rare garbage expand
+// weights with two contexts sharing the chip).  Every wave drains its own DMAs, THEN the barrier.
+__device__ __forceinline__ void cf_sync_lds_dma() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // Lane -> output pixel map of the depthwise phase (pixel-pair tile kernels: cf_mbconv2.hip, cf_stem0.hip).
 //
 // A lane reads its pixel's pixel-pair rows from the LDS tile with ds_read_b128 at  e * PITCH + const, PITCH / 16 odd,

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(DwParams p, DwLdsGeom g) {
         const int t = i / (g.Cc / 4), c4 = i - t * (g.Cc / 4);
         st16(wl + t * g.Cc + c4 * 4, ld16(p.w + (size_t)t * p.C + c0 + c4 * 4));
     }
-    __syncthreads();                                              // waits for the DMA (vmcnt) too
+    cf_sync_lds_dma();                                            // every wave drains its DMAs (vmcnt), then the barrier
 
     // ---- compute: output vector v -> (pixel, channel group)
     const int nvec = TH * TW * g.cpp;

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
     for (int q = 0; q < nq; ++q) {
         const char* wx = Wst + (q & 1) * WSTAGE;
         const char* wdq = wx + WXB;
-        __syncthreads();      // previous chunk's phase 2 done with E; this stage's weights landed
+        cf_sync_lds_dma();    // previous chunk's phase 2 done with E; this stage's weights (LDS-DMA) landed for every wave
 
         // ---- phase 1: expand + Swish -> E (X fragments are register-resident)
 #pragma unroll

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     for (int q = 0; q < nq; ++q) {
         const char* wx = G::WDIRECT ? (const char*)p.wexp + (size_t)q * WXB : Wst + (q & 1) * WXB;
         if constexpr (XRELOAD) load_x();
-        __syncthreads();      // previous chunk's depthwise done with E; this stage's expand weights landed
+        cf_sync_lds_dma();    // previous chunk's depthwise done with E; this stage's expand weights (LDS-DMA) landed for every wave
 
 #pragma unroll
         for (int t = 0; t < MAXI; ++t) {
@@ -543,7 +543,7 @@ __global__ __launch_bounds__((Xd<KS, S, HC, TOH, TOW, JX>::NW) * 64) void expdw_
     u32x4 xa[JX];
     bool va = false;
     if (wave < NIB) va = load_x(wave, xa);
-    __syncthreads();
+    cf_sync_lds_dma();        // the expand weights (LDS-DMA) landed for every wave
     mask_x(xa, va);
 
     // ---- phase 1: expand + Swish -> pixel-pair tile

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
     u32x4 xa[JX];
     bool va = false;
     if (wave < NIB) va = load_x(wave, xa);
-    __syncthreads();
+    cf_sync_lds_dma();               // expand weights and the operand table have landed for every wave
     mask_x(xa, va);
 
     // ---- phase 1: expand + Swish -> quad cells.  D rows (r & 3) + 8 (r >> 2) + 4 h: register quad t = halo quad ib*8 + 2t + h
@@ -443,9 +443,16 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
 
     stage_weights(0);
     for (int q = 0; q < nq; ++q) {
+        const char* wx = Wst + (q & 1) * WXB;
+        cf_sync_lds_dma();    // previous round's depthwise done with E (and the operand table); this round's expand weights (DMA) landed
         // Toeplitz operands + project fragments of this round: requested before the expand phase, used after it
         u32x2 A[ALDS ? 1 : 2][ALDS ? 1 : KS][2];
-        if constexpr (!ALDS) {
+        if constexpr (ALDS) {      // this round's Toeplitz table -> LDS under the expand phase (drained before the next barrier)
+            const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
+            for (int c = wave; c < G::ATB / 1024; c += NW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
+        } else {
             const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)q * (2 * KS * 2) * 64 + lane;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -457,15 +464,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
         u32x4 wpc[NMB];
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb) wpc[mb] = ld16((const char*)p.wproj + (((size_t)q * NMB + mb) * 64 + lane) * 16);
-        const char* wx = Wst + (q & 1) * WXB;
         if constexpr (XRELOAD) load_x();
-        __syncthreads();      // previous round's depthwise done with E (and the operand table); this round's expand weights landed
-        if constexpr (ALDS) {      // this round's Toeplitz table -> LDS under the expand phase (the next barrier drains it)
-            const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
-            for (int c = wave; c < G::ATB / 1024; c += NW)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
-        }
 
         // ---- phase 1: expand + Swish -> quad cells
 #pragma unroll
@@ -492,7 +491,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
                 *reinterpret_cast<u32x2*>(ecell + 2 * tq * CP8) = d;
             }
         }
-        __syncthreads();
+        cf_sync_lds_dma();          // E complete; the operand table (DMA) landed
         if (q + 1 < nq) stage_weights(q + 1);
 
         // ---- phase 2: depthwise (matrix cores) + Swish + project

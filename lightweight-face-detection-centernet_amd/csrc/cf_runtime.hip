@@ -91,9 +91,10 @@ struct cf_ctx {
     // decode workspaces (lazy)
     unsigned long long* keys = nullptr; int* key_count = nullptr; unsigned long long* big = nullptr; size_t big_stride = 0; float* d_rec = nullptr;
     hipEvent_t ev_main_dec = nullptr; bool main_dec_pending = false;
+    hipEvent_t ev_gather = nullptr; bool gather_pending = false;       // the last all-gather still reads d_rec (communicator's stream)
     float* hm_plane = nullptr; double* d_trans = nullptr; uint8_t* src_stage = nullptr; size_t src_stage_bytes = 0;
     float* d_dets = nullptr; float* d_lms = nullptr; long long* d_inds = nullptr; int decK = 0;
-    float* t_cand = nullptr; int* t_count = nullptr; int* t_order = nullptr; unsigned long long* t_mask = nullptr;
+    float* t_cand = nullptr; int* t_count = nullptr; int* t_order = nullptr; unsigned long long* t_mask = nullptr; int t_B = 0;
     float* t_dets = nullptr; float* t_lms = nullptr; int* t_counts = nullptr; int* t_overflow = nullptr;
     int t_cap = 0, t_maxout = 0;
     // hipGraph replay of the backbone + neck launches, one executable graph per (input pointer,
@@ -477,6 +478,7 @@ int cf_destroy(cf_ctx* c) {
     if (c->stream_in) { hipStreamSynchronize(c->stream_in); release_copy_stream(c->device); }
     for (int i = 0; i < 2; ++i) { if (c->ev_copy[i]) hipEventDestroy(c->ev_copy[i]); if (c->ev_slot_free[i]) hipEventDestroy(c->ev_slot_free[i]); }
     if (c->ev_dec) hipEventDestroy(c->ev_dec);
+    if (c->ev_gather) { hipEventSynchronize(c->ev_gather); hipEventDestroy(c->ev_gather); }
     if (c->ev_main_dec) hipEventDestroy(c->ev_main_dec);
     for (auto& b : c->bufs) if (b.p) hipFree(b.p);
     for (void* p : c->owned) hipFree(p);
@@ -807,6 +809,7 @@ int ensure_topk_ws(cf_ctx* c, int K) {
     if (c->decK < K) {
         HIPCHK(c, hipStreamSynchronize(c->stream));           // a decode in flight may still write the old buffers
         HIPCHK(c, hipStreamSynchronize(c->stream2));
+        if (c->gather_pending) { HIPCHK(c, hipEventSynchronize(c->ev_gather)); c->gather_pending = false; }   // ... and a gather may still read d_rec
         for (void* p : {(void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->d_rec, (void*)c->big}) if (p) hipFree(p);
         c->d_dets = nullptr; c->d_lms = nullptr; c->d_inds = nullptr; c->d_rec = nullptr; c->big = nullptr; c->big_stride = 0;
         HIPCHK(c, hipMalloc((void**)&c->d_dets, (size_t)c->max_batch * K * 6 * sizeof(float)));
@@ -952,6 +955,7 @@ int cf_synchronize(cf_ctx* c) {
     if (!c) return CF_EINVAL;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->gather_pending) { HIPCHK(c, hipEventSynchronize(c->ev_gather)); c->gather_pending = false; }   // the communicator's stream
     return CF_OK;
 }
 
@@ -1037,13 +1041,23 @@ int cf_detect_topk(cf_ctx* c, const void* in, int in_format, int in_on_device, i
     return cf_decode_topk(c, K, 1, dets, lms, inds, out_on_device);
 }
 
-static int ensure_thresh_ws(cf_ctx* c, int max_out, int cap) {
-    if (c->t_cap < cap) {
-        for (void* p : {(void*)c->t_cand, (void*)c->t_count, (void*)c->t_order, (void*)c->t_mask, (void*)c->t_counts, (void*)c->t_overflow})
-            if (p) hipFree(p);
-        c->t_cand = nullptr; c->t_count = nullptr; c->t_order = nullptr; c->t_mask = nullptr; c->t_counts = nullptr; c->t_overflow = nullptr;
-        c->t_cap = 0;
-        const size_t mb = c->max_batch, words = (cap + 63) / 64;
+static void free_thresh_ws(cf_ctx* c) {
+    for (void* p : {(void*)c->t_cand, (void*)c->t_count, (void*)c->t_order, (void*)c->t_mask, (void*)c->t_counts, (void*)c->t_overflow})
+        if (p) hipFree(p);
+    c->t_cand = nullptr; c->t_count = nullptr; c->t_order = nullptr; c->t_mask = nullptr; c->t_counts = nullptr; c->t_overflow = nullptr;
+    c->t_cap = 0; c->t_B = 0;
+}
+// The suppression matrix is dense: cap x cap / 64 words per image.  The workspace is sized for the batch of the CURRENT call
+// (not max_batch) and for the candidate count seen; a decode that needed more than kThreshKeepBytes of it (one noisy batch,
+// e.g. untrained weights: 1.3 GB per image at 1280x1280 when every cell passes) releases it again afterwards instead of
+// pinning GBs of HBM for the life of the context.  Practical limit: cap^2 / 8 bytes x B must fit the free HBM.
+static constexpr size_t kThreshKeepBytes = (size_t)512 << 20;
+static size_t thresh_mask_bytes(int B, int cap) { return (size_t)B * cap * ((cap + 63) / 64) * sizeof(unsigned long long); }
+static int ensure_thresh_ws(cf_ctx* c, int max_out, int cap, int B) {
+    if (c->t_cap < cap || c->t_B < B) {
+        cap = std::max(cap, c->t_cap); B = std::max(B, c->t_B);
+        free_thresh_ws(c);
+        const size_t mb = B, words = (cap + 63) / 64;
         hipError_t e = hipMalloc((void**)&c->t_cand, mb * cap * 16 * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&c->t_count, mb * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void**)&c->t_order, mb * cap * sizeof(int));
@@ -1052,10 +1066,11 @@ static int ensure_thresh_ws(cf_ctx* c, int max_out, int cap) {
         if (e == hipSuccess) e = hipMalloc((void**)&c->t_overflow, sizeof(int));
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            return c->fail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "threshold-decode workspace for %d candidates per image x %d images: %s",
-                           cap, c->max_batch, hipGetErrorString(e));
+            free_thresh_ws(c);
+            return c->fail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "threshold-decode workspace for %d candidates per image x %d images (%.1f MB of suppression bits): %s",
+                           cap, B, thresh_mask_bytes(B, cap) / 1e6, hipGetErrorString(e));
         }
-        c->t_cap = cap;
+        c->t_cap = cap; c->t_B = B;
     }
     if (c->t_maxout < max_out) {
         if (c->t_dets) hipFree(c->t_dets);
@@ -1090,7 +1105,7 @@ int cf_decode_threshold_sized(cf_ctx* c, int mode, float score_thresh, float nms
     // count, the workspace is reallocated and the decode reruns
     int cap = c->t_cap > 0 ? c->t_cap : (HW < 4096 ? (HW + 63) / 64 * 64 : 4096);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        int r = ensure_thresh_ws(c, max_out, cap); if (r) return r;
+        int r = ensure_thresh_ws(c, max_out, cap, B); if (r) return r;
         ThreshParams p{};
         p.heads = (const float*)c->bufs[c->buf_heads].p; p.hm_plane = c->hm_plane; p.B = B; p.h = c->H / 4; p.w = c->W / 4;
         p.img_h = img_h; p.img_w = img_w; p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = c->t_cap; p.mode = mode;
@@ -1109,6 +1124,7 @@ int cf_decode_threshold_sized(cf_ctx* c, int mode, float score_thresh, float nms
     if (lms) HIPCHK(c, hipMemcpyAsync(lms, c->t_lms, (size_t)B * max_out * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(counts, c->t_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (thresh_mask_bytes(c->t_B, c->t_cap) > kThreshKeepBytes) free_thresh_ws(c);      // an oversized decode does not keep its workspace
     return CF_OK;
 }
 
@@ -1283,21 +1299,32 @@ int cf_streams_share_queue(cf_ctx* a, cf_ctx* b, int* shared) {
     HIPCHK(a, hipSetDevice(a->device));
     HIPCHK(a, hipStreamSynchronize(a->stream));
     HIPCHK(a, hipStreamSynchronize(b->stream));
-    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
-    HIPCHK(a, hipEventCreate(&e0)); HIPCHK(a, hipEventCreate(&ea)); HIPCHK(a, hipEventCreate(&eb));
-    // ~0.3 ms spin on a's main stream, then an empty kernel on b's: on one hardware queue the second waits for the first
-    HIPCHK(a, hipEventRecord(e0, a->stream));
-    hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, a->stream, (long long)30000);
-    HIPCHK(a, hipEventRecord(ea, a->stream));
-    hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, b->stream, (long long)0);
-    HIPCHK(a, hipEventRecord(eb, b->stream));
-    HIPCHK(a, hipStreamSynchronize(a->stream));
-    HIPCHK(a, hipStreamSynchronize(b->stream));
-    float ta = 0.0f, tb = 0.0f;
-    HIPCHK(a, hipEventElapsedTime(&ta, e0, ea));
-    HIPCHK(a, hipEventElapsedTime(&tb, e0, eb));
-    hipEventDestroy(e0); hipEventDestroy(ea); hipEventDestroy(eb);
-    *shared = tb > 0.5f * ta ? 1 : 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < 3 && err == hipSuccess; ++i) err = hipEventCreate(&ev[i]);
+    // ~0.3 ms spin on a's main stream, then an empty kernel on b's: on one hardware queue the second waits for the first.
+    // One timing sample can be fooled by anything else using the GPU: three probes, majority decides.
+    int votes = 0;
+    for (int rep = 0; rep < 3 && err == hipSuccess; ++rep) {
+        auto step = [&](hipError_t e) { if (err == hipSuccess) err = e; };
+        step(hipEventRecord(ev[0], a->stream));
+        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, a->stream, (long long)30000);
+        step(hipGetLastError());
+        step(hipEventRecord(ev[1], a->stream));
+        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, b->stream, (long long)0);
+        step(hipGetLastError());
+        step(hipEventRecord(ev[2], b->stream));
+        step(hipStreamSynchronize(a->stream));
+        step(hipStreamSynchronize(b->stream));
+        float ta = 0.0f, tb = 0.0f;
+        step(hipEventElapsedTime(&ta, ev[0], ev[1]));
+        step(hipEventElapsedTime(&tb, ev[0], ev[2]));
+        if (err == hipSuccess && tb > 0.5f * ta) ++votes;
+        if (rep == 1 && (votes == 0 || votes == 2)) break;        // decided after two agreeing probes
+    }
+    for (hipEvent_t e : ev) if (e) hipEventDestroy(e);          // on every path
+    if (err != hipSuccess) return a->fail(CF_EHIP, "cf_streams_share_queue: %s", hipGetErrorString(err));
+    *shared = votes >= 2 ? 1 : 0;
     return CF_OK;
 }
 
@@ -1372,7 +1399,11 @@ int cf_memcpy_d2h(cf_ctx* c, void* dst, const void* src, uint64_t bytes) {
 struct cf_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;                       // THE gather stream of this rank: every all-gather of every context goes here, in call order
+    hipEvent_t ev_done = nullptr;                       // recorded after the last enqueued all-gather (cf_comm_query / _synchronize)
     float* recv = nullptr; size_t recv_elems = 0;       // staging for host destinations
+    int* d_chk = nullptr; int checked_B = -1;           // batch-size agreement check (one int per rank), last B verified
+    std::string err;
 };
 
 namespace {
@@ -1382,28 +1413,45 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
 
+// librccl is loaded once, by whichever thread gets here first (std::call_once: a second thread blocks until the table is
+// complete instead of seeing a half-filled one); any missing symbol is an error before the first call through the table
 RcclApi* rccl() {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return &api;
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (api.handle) break;
-    }
-    if (!api.handle) { api.err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found"); return &api; }
-    auto sym = [&](const char* n) { void* p = dlsym(api.handle, n); if (!p && api.err.empty()) api.err = std::string("librccl lacks ") + n; return p; };
-    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
-    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
-    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
-    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
-    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) { const char* de = dlerror(); api.err = std::string("dlopen(librccl): ") + (de ? de : "not found"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(api.handle, n); if (!p && api.err.empty()) api.err = std::string("librccl lacks ") + n; return p; };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    });
     return &api;
+}
+
+// stream + event + check buffer of a new communicator
+int comm_resources(cf_ctx* c, cf_comm* m) {
+    HIPCHK(c, hipSetDevice(m->device));
+    HIPCHK(c, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
+    HIPCHK(c, hipMalloc((void**)&m->d_chk, (size_t)(m->world + 1) * sizeof(int)));
+    return CF_OK;
 }
 
 }  // namespace
@@ -1433,31 +1481,115 @@ int cf_comm_create(cf_ctx* c, int rank, int world, const void* id, cf_comm** out
     m->rank = rank; m->world = world; m->device = c->device;
     ncclResult_t e = r->CommInitRank(&m->comm, world, u, rank);
     if (e != ncclSuccess) { delete m; return c->fail(CF_EHIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, r->GetErrorString(e)); }
+    int rr = comm_resources(c, m);
+    if (rr) { cf_comm_destroy(m); return rr; }
     *out = m;
+    return CF_OK;
+}
+
+// One process, one thread, n GPUs: rank i = ctxs[i]'s device.  ncclCommInitRank blocks until every rank has joined, so a
+// host that owns all the contexts must issue the n calls inside one ncclGroupStart / ncclGroupEnd.
+int cf_comm_create_all(cf_ctx** ctxs, int n, cf_comm** out) {
+    if (!ctxs || !out || n < 1) return CF_EINVAL;
+    for (int i = 0; i < n; ++i) { if (!ctxs[i]) return CF_EINVAL; out[i] = nullptr; }
+    cf_ctx* c0 = ctxs[0];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (ctxs[i]->device == ctxs[j]->device) return c0->fail(CF_EINVAL, "cf_comm_create_all: contexts %d and %d share device %d (one rank per GPU)", j, i, ctxs[i]->device);
+    RcclApi* r = rccl();
+    if (!r->err.empty()) return c0->fail(CF_EHIP, "%s", r->err.c_str());
+    ncclUniqueId u;
+    ncclResult_t e = r->GetUniqueId(&u);
+    if (e != ncclSuccess) return c0->fail(CF_EHIP, "ncclGetUniqueId: %s", r->GetErrorString(e));
+    std::vector<cf_comm*> ms(n, nullptr);
+    for (int i = 0; i < n; ++i) { ms[i] = new cf_comm(); ms[i]->rank = i; ms[i]->world = n; ms[i]->device = ctxs[i]->device; }
+    e = r->GroupStart();
+    for (int i = 0; i < n && e == ncclSuccess; ++i) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) { e = ncclUnhandledCudaError; break; }
+        e = r->CommInitRank(&ms[i]->comm, n, u, i);
+    }
+    ncclResult_t e2 = r->GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    int rr = CF_OK;
+    if (e != ncclSuccess) rr = c0->fail(CF_EHIP, "ncclCommInitRank (grouped, %d ranks): %s", n, r->GetErrorString(e));
+    for (int i = 0; i < n && !rr; ++i) rr = comm_resources(ctxs[i], ms[i]);
+    if (rr) { for (cf_comm* m : ms) cf_comm_destroy(m); return rr; }
+    for (int i = 0; i < n; ++i) out[i] = ms[i];
     return CF_OK;
 }
 
 int cf_comm_destroy(cf_comm* m) {
     if (!m) return CF_OK;
     hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
     if (m->recv) hipFree(m->recv);
+    if (m->d_chk) hipFree(m->d_chk);
     if (m->comm) rccl()->CommDestroy(m->comm);
+    if (m->ev_done) hipEventDestroy(m->ev_done);
+    if (m->stream) hipStreamDestroy(m->stream);
     delete m;
     return CF_OK;
 }
 
+// Give up on a communicator whose collective does not complete (a peer died, a first-run deadlock): ncclCommAbort makes the
+// in-flight RCCL kernels exit, the gather stream drains, every resource is released.  The handle is dead afterwards.
+int cf_comm_abort(cf_comm* m) {
+    if (!m) return CF_OK;
+    hipSetDevice(m->device);
+    if (m->comm) { rccl()->CommAbort(m->comm); m->comm = nullptr; }
+    return cf_comm_destroy(m);
+}
+
+// 0: every enqueued gather has completed, 1: still running, < 0: error.  Never blocks.
+int cf_comm_query(cf_comm* m) {
+    if (!m) return CF_EINVAL;
+    hipSetDevice(m->device);
+    hipError_t e = hipStreamQuery(m->stream);
+    if (e == hipSuccess) return 0;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
+    m->err = std::string("hipStreamQuery: ") + hipGetErrorString(e);
+    return CF_EHIP;
+}
+
+int cf_comm_synchronize(cf_comm* m) {
+    if (!m) return CF_EINVAL;
+    hipSetDevice(m->device);
+    hipError_t e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) { m->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); return CF_EHIP; }
+    return CF_OK;
+}
+
+void* cf_comm_stream(cf_comm* m) { return m ? (void*)m->stream : nullptr; }
+
 int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, int out_on_device) {
     if (!c || !m || !records) return CF_EINVAL;
     if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_gather_topk before cf_forward");
+    if (!m->comm) return c->fail(CF_ESTATE, "communicator was aborted");
     if (m->device != c->device) return c->fail(CF_EINVAL, "communicator was created for device %d, context runs on %d", m->device, c->device);
     const int B = c->last_B, HW = (c->H / 4) * (c->W / 4);
     if (K < 1 || K > HW) return c->fail(CF_EINVAL, "K=%d must be in [1, %d]", K, HW);
     HIPCHK(c, hipSetDevice(c->device));
     int r = ensure_topk_ws(c, K); if (r) return r;
+    if (!c->ev_gather) HIPCHK(c, hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
+    // ncclAllGather takes ONE count for all ranks: ranks with different batch sizes would hang or mis-place records without
+    // any error.  The first gather at a new B all-gathers the B of every rank and compares (one extra small collective + sync).
+    if (m->checked_B != B) {
+        std::vector<int> hb(m->world + 1, 0);
+        hb[m->world] = B;
+        HIPCHK(c, hipMemcpyAsync(m->d_chk + m->world, &hb[m->world], sizeof(int), hipMemcpyHostToDevice, m->stream));
+        ncclResult_t e = rccl()->AllGather(m->d_chk + m->world, m->d_chk, 1, ncclInt32, m->comm, m->stream);
+        if (e != ncclSuccess) return c->fail(CF_EHIP, "ncclAllGather (batch-size check): %s", rccl()->GetErrorString(e));
+        HIPCHK(c, hipMemcpyAsync(hb.data(), m->d_chk, (size_t)m->world * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(c, hipStreamSynchronize(m->stream));
+        for (int i = 0; i < m->world; ++i)
+            if (hb[i] != B) return c->fail(CF_EINVAL, "cf_gather_topk: rank %d has batch %d, rank %d has %d -- the gather needs equal shards (pad the last one)", m->rank, B, i, hb[i]);
+        m->checked_B = B;
+    }
     const size_t n = (size_t)B * K * 16;
     float* dst = records;
     if (!out_on_device) {
         if (m->recv_elems < n * m->world) {
+            HIPCHK(c, hipStreamSynchronize(m->stream));
             if (m->recv) HIPCHK(c, hipFree(m->recv));
             m->recv = nullptr; m->recv_elems = 0;
             HIPCHK(c, hipMalloc((void**)&m->recv, n * m->world * sizeof(float)));
@@ -1465,17 +1597,25 @@ int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, in
         }
         dst = m->recv;
     }
-    // decode stream: [wait forward] decode -> records -> [event: heads / scratch free again] -> all-gather (-> D2H)
+    // decode stream of the context: [wait forward] [wait the previous gather: it reads d_rec] decode -> records -> event
+    // gather stream of the communicator (one per rank, shared by all its contexts): [wait that event] all-gather (-> D2H)
+    // With ONE communicator and ONE stream per rank every rank enqueues its collectives in the same order as long as it
+    // calls cf_gather_topk in the same order -- no cross-communicator ordering to get wrong.
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
+    if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_gather, 0));
     r = enqueue_topk(c, B, K, use_reg, nullptr, nullptr, nullptr, nullptr, c->stream2, c->d_rec);
     if (r) return r;
     HIPCHK(c, hipEventRecord(c->ev_dec, c->stream2));
     c->dec_pending = true;
-    ncclResult_t e = rccl()->AllGather(c->d_rec, dst, n, ncclFloat, m->comm, c->stream2);
+    HIPCHK(c, hipStreamWaitEvent(m->stream, c->ev_dec, 0));
+    ncclResult_t e = rccl()->AllGather(c->d_rec, dst, n, ncclFloat, m->comm, m->stream);
     if (e != ncclSuccess) return c->fail(CF_EHIP, "ncclAllGather: %s", rccl()->GetErrorString(e));
+    HIPCHK(c, hipEventRecord(c->ev_gather, m->stream));
+    c->gather_pending = true;
     if (!out_on_device) {
-        HIPCHK(c, hipMemcpyAsync(records, dst, n * m->world * sizeof(float), hipMemcpyDeviceToHost, c->stream2));
-        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        HIPCHK(c, hipMemcpyAsync(records, dst, n * m->world * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(c, hipStreamSynchronize(m->stream));
+        c->gather_pending = false;
     }
     return CF_OK;
 }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
             st16(T3 + ip * UH_PIT + ch * 2, o);
         }
     }
-    __syncthreads();
+    cf_sync_lds_dma();            // the tile is complete and the head weights (LDS-DMA) have landed for every wave
 
     // ---- phase B: collapsed 3x3 head conv from the LDS tile (cf_head.hip: kernel row dy = 72 contiguous
     // elements = 9 chunks; lane half 0 owns chunks 0-4, half 1 chunks 5-8)

@@ -74,27 +74,77 @@ def broadcast_unique_id(src=0, group=None):
 
 
 class Comm(object):
-    """RCCL communicator bound to one Engine (one GPU): ``cf_comm_create`` / ``cf_gather_topk``."""
+    """The RCCL communicator of this rank (= this GPU): ``cf_comm_create`` / ``cf_gather_topk``.
 
-    def __init__(self, engine, rank, world, uid):
+    ONE per rank, shared by every Engine (context) the rank drives on that GPU: the communicator owns the rank's single
+    gather stream and all-gathers are enqueued there in call order, so all ranks see the same collective order as long as
+    they call ``gather_topk*`` in the same order.  ``engine`` names the device at creation and is the default context of
+    the gather calls; pass ``engine=`` to gather another context's decode through the same communicator."""
+
+    def __init__(self, engine, rank, world, uid, _handle=None):
+        self.engine, self.rank, self.world = engine, int(rank), int(world)
+        if _handle is not None:
+            self._h = _handle
+            return
         if len(uid) != COMM_ID_BYTES:
             raise ValueError("RCCL unique id must be %d bytes" % COMM_ID_BYTES)
-        self.engine, self.rank, self.world = engine, int(rank), int(world)
         h = C.c_void_p()
         _lib.check(_lib.lib().cf_comm_create(engine._h, self.rank, self.world, C.c_char_p(uid), C.byref(h)), engine._h)
         self._h = h
 
-    def gather_topk(self, K=100, use_reg=True):
+    @classmethod
+    def create_all(cls, engines):
+        """One process that owns one Engine per GPU: all communicators in one grouped call (``cf_comm_create_all``);
+        rank i = engines[i]."""
+        n = len(engines)
+        ctxs = (C.c_void_p * n)(*[e._h for e in engines])
+        outs = (C.c_void_p * n)()
+        _lib.check(_lib.lib().cf_comm_create_all(ctxs, n, outs), engines[0]._h)
+        return [cls(e, i, n, None, _handle=C.c_void_p(outs[i])) for i, e in enumerate(engines)]
+
+    def gather_topk(self, K=100, use_reg=True, engine=None):
         """Decode the engine's last forward and all-gather: float32 [world * B, K, 16] (host, blocking)."""
-        B = self.engine.last_B
-        out = np.empty((self.world * B, int(K), REC), np.float32)
-        _lib.check(_lib.lib().cf_gather_topk(self.engine._h, self._h, int(K), 1 if use_reg else 0, _lib.ptr(out), 0), self.engine._h)
+        eng = engine or self.engine
+        out = np.empty((self.world * eng.last_B, int(K), REC), np.float32)
+        _lib.check(_lib.lib().cf_gather_topk(eng._h, self._h, int(K), 1 if use_reg else 0, _lib.ptr(out), 0), eng._h)
         return out
 
-    def gather_topk_device(self, K, records_ptr, use_reg=True):
-        """Same into a caller-owned DEVICE buffer [world * B, K, 16] (asynchronous, decode stream)."""
-        _lib.check(_lib.lib().cf_gather_topk(self.engine._h, self._h, int(K), 1 if use_reg else 0, C.c_void_p(int(records_ptr)), 1),
-                   self.engine._h)
+    def gather_topk_device(self, K, records_ptr, use_reg=True, engine=None):
+        """Same into a caller-owned DEVICE buffer [world * B, K, 16] (asynchronous: decode stream of the engine, then the
+        communicator's gather stream; ``synchronize()`` or ``engine.synchronize()`` before reading)."""
+        eng = engine or self.engine
+        _lib.check(_lib.lib().cf_gather_topk(eng._h, self._h, int(K), 1 if use_reg else 0, C.c_void_p(int(records_ptr)), 1), eng._h)
+
+    def query(self):
+        """True while an enqueued gather is still running (never blocks)."""
+        r = _lib.lib().cf_comm_query(self._h)
+        if r < 0:
+            raise RuntimeError("cf_comm_query failed (%d)" % r)
+        return r == 1
+
+    def wait(self, timeout_s, poll_s=0.002):
+        """Poll ``query`` until the gather stream is idle; False if it is still busy after ``timeout_s`` seconds
+        (a collective that does not complete: abort() instead of hanging in a synchronize)."""
+        import time
+        t0 = time.perf_counter()
+        while self.query():
+            if time.perf_counter() - t0 > timeout_s:
+                return False
+            time.sleep(poll_s)
+        return True
+
+    def synchronize(self):
+        if _lib.lib().cf_comm_synchronize(self._h) != 0:
+            raise RuntimeError("cf_comm_synchronize failed")
+
+    def stream(self):
+        return int(_lib.lib().cf_comm_stream(self._h) or 0)
+
+    def abort(self):
+        """ncclCommAbort + release: for a communicator whose collective hangs.  The object is dead afterwards."""
+        if getattr(self, "_h", None):
+            _lib.lib().cf_comm_abort(self._h)
+            self._h = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -106,3 +156,14 @@ class Comm(object):
             self.close()
         except Exception:
             pass
+
+
+def agree(ok, rank, world, key, store=None):
+    """Every rank publishes ``ok`` under ``key`` in the torch.distributed key-value store (TCP, NOT a NCCL collective: it
+    works while a RCCL collective is hung) and reads everybody's: True only if all ranks said ok."""
+    if world == 1:
+        return bool(ok)
+    import torch.distributed as dist
+    store = store or dist.distributed_c10d._get_default_store()
+    store.set("%s/%d" % (key, rank), b"1" if ok else b"0")
+    return all(store.get("%s/%d" % (key, r)) == b"1" for r in range(world))

@@ -38,23 +38,97 @@ def test_bench_multi_gpu_step_on_one_gpu(gather, depth):
              "inds": torch.empty((B, K), dtype=torch.int64, device=dev), "all": torch.zeros((B, K, 16), dtype=torch.float32, device=dev)}
             for _ in range(depth)]
     engs = [cfa.Engine(S, S, max_batch=B, dtype="bf16") for _ in range(depth)]
-    comms = [cfa.distributed.Comm(e, 0, 1, cfa.distributed.unique_id()) for e in engs] if gather == "cf" else None
+    # ONE communicator per rank, shared by the rank's contexts (its single gather stream orders the collectives)
+    comms = [cfa.distributed.Comm(engs[0], 0, 1, cfa.distributed.unique_id())] if gather == "cf" else None
     step = bench.make_step(cfa, engs, d_in.data_ptr(), B, K, outs, gather, comms)
     got = [step() for _ in range(4 * depth)]             # per context: eager, capture, replay, replay; gathers overlap the next forward
     for e in engs:
         e.synchronize()
+    if comms is not None:
+        assert comms[0].wait(30.0) and not comms[0].query()
     torch.cuda.synchronize()
     got = [g.cpu().numpy() for g in got[-depth:]]        # the last result of every context
     engs[0].forward_enqueue(imgs)
     want = _records(engs[0], K)
     for g in got:
         assert np.array_equal(g, want)
-    if comms is not None:                                # host-destination variant of the same entry point
-        assert np.array_equal(comms[0].gather_topk(K), want)
+    if comms is not None:                                # host-destination variant of the same entry point, through every context
+        for e in engs:
+            e.forward_enqueue(imgs)
+            assert np.array_equal(comms[0].gather_topk(K, engine=e), want)
         for cm in comms:
             cm.close()
     for e in engs:
         e.close()
+
+
+def test_bench_step_configs4_shard_two_contexts_one_communicator():
+    """The BASELINE configs[4] per-GPU shard (1280x1280, top-1000, B = 4: the `topk_select_kernel<1024, *>` + gather-record
+    path) through bench.py's N > 1 step: two contexts sharing the rank's one communicator / gather stream."""
+    import torch
+    import bench
+    B, S, K, depth = 4, 1280, 1000, 2
+    dev = torch.device("cuda", 0)
+    imgs = np.random.default_rng(12).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    d_in = torch.from_numpy(imgs).to(dev)
+    outs = [{"dets": torch.empty((B, K, 6), dtype=torch.float32, device=dev), "lms": torch.empty((B, K, 10), dtype=torch.float32, device=dev),
+             "inds": torch.empty((B, K), dtype=torch.int64, device=dev), "all": torch.zeros((B, K, 16), dtype=torch.float32, device=dev)}
+            for _ in range(depth)]
+    engs = [cfa.Engine(S, S, max_batch=B, dtype="bf16") for _ in range(depth)]
+    comm = cfa.distributed.Comm(engs[0], 0, 1, cfa.distributed.unique_id())
+    step = bench.make_step(cfa, engs, d_in.data_ptr(), B, K, outs, "cf", [comm])
+    got = [step() for _ in range(3 * depth)]
+    assert comm.wait(60.0)
+    for e in engs:
+        e.synchronize()
+    got = [g.cpu().numpy() for g in got[-depth:]]
+    engs[0].forward_enqueue(imgs)
+    want = _records(engs[0], K)
+    for g in got:
+        assert np.array_equal(g, want)
+    comm.close()
+    for e in engs:
+        e.close()
+
+
+def test_comm_create_all_grouped_and_abort():
+    """cf_comm_create_all (the single-process host: n ncclCommInitRank calls inside one ncclGroupStart/End) at n = 1, its
+    gather, and cf_comm_abort on a live communicator; two contexts on one device are refused (one rank per GPU)."""
+    S, B, K = 96, 3, 20
+    imgs = np.random.default_rng(13).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    eng = cfa.Engine(S, S, max_batch=B, dtype="fp32")
+    comms = cfa.distributed.Comm.create_all([eng])
+    assert len(comms) == 1 and comms[0].world == 1 and comms[0].stream() != 0
+    eng.forward_enqueue(imgs)
+    rec = comms[0].gather_topk(K)
+    eng.forward_enqueue(imgs)
+    assert np.array_equal(rec, _records(eng, K))
+    comms[0].abort()
+    comms[0].abort()                                     # idempotent
+    eng2 = cfa.Engine(S, S, max_batch=B, dtype="fp32")
+    with pytest.raises((RuntimeError, ValueError)):
+        cfa.distributed.Comm.create_all([eng, eng2])
+    eng.close(); eng2.close()
+
+
+def test_bench_gather_fallback_records_the_path():
+    """bench.py --exercise-gather-path with a zero gather deadline: the warm-up gather "times out", the communicator is
+    aborted, the run continues on the torch.distributed path with one context and the JSON line says so."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--repeats", "2",
+                          "--batch", "4", "--size", "160", "--topk", "20", "--no-cpu-baseline", "--no-extras", "--profile-reps", "1",
+                          "--exercise-gather-path", "--gather-timeout", "-1"],
+                         capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["config"]["gather_fallback"] and "torch.distributed" in d["config"]["gather"] and d["config"]["contexts_per_gpu"] == 1
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--repeats", "2",
+                          "--batch", "4", "--size", "160", "--topk", "20", "--no-cpu-baseline", "--no-extras", "--profile-reps", "1",
+                          "--exercise-gather-path"],
+                         capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["config"]["gather_fallback"] is None and "cf_gather_topk" in d["config"]["gather"] and d["config"]["contexts_per_gpu"] == 2
 
 
 def test_engine_ring_matches_single_engine_bitwise():
@@ -111,7 +185,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["bound"] in ("hbm", "mfma", "valu_issue") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(d["value"] - 4 * 3 / (d["windows"]["median_ms"] * 1e-3)) / d["value"] < 1e-3
     assert abs(d["ms_per_step"] - d["windows"]["median_ms"] / 3) < 1e-3
 
