@@ -223,8 +223,10 @@ def parity_block(cfa, eng16, host_imgs, d_in_ptr, B, S, K, dev_index):
             "same_index_same_rank": int((i16[0] == ei[0]).sum()),
             "hm_logit_mean_abs_diff_over_rms": round(float(np.abs(h16["hm"][0] - emu["hm"].numpy()[0]).mean()) / rms, 5),
             "max_abs_score_diff": round(float(np.abs(h16["hm_sigmoid"][0] - sg[0]).max()), 5),
-            "note": "kernel-level agreement (99.75-99.99 % of outputs bit-identical, layer by layer) is asserted in "
-                    "tests/test_bf16_parity.py; end to end two bf16 pipelines drift apart through 1-ulp rounding flips"},
+            "note": "image 0 of the timed batch only (the CPU emulation of all 64 takes minutes; tests/test_bf16_parity.py::"
+                    "test_batch64_end_to_end_vs_emulation emulates 4 of the 64); kernel-level agreement (99.75-99.99 % of outputs "
+                    "bit-identical, layer by layer) is asserted in tests/test_bf16_parity.py; end to end two bf16 pipelines drift apart "
+                    "through 1-ulp rounding flips"},
     }
 
 
@@ -461,17 +463,26 @@ def main():
         for e in engs:
             e.close()
         eng_closed = True
-        e32 = cfa.Engine(S, S, max_batch=B, dtype="fp32", device=local_rank)
-        st32 = make_step(cfa, e32, d_in.data_ptr(), B, K, out)
+        r32 = cfa.EngineRing(S, S, depth=D, max_batch=B, dtype="fp32", device=local_rank)      # the same two-batches-in-flight schedule
+        o32 = outs if len(outs) == len(r32.engines) else [outs[0]] * len(r32.engines)
+        st32 = make_step(cfa, r32.engines, d_in.data_ptr(), B, K, o32)
 
         def fence32():
-            e32.synchronize(); torch.cuda.synchronize()
+            for e in r32.engines:
+                e.synchronize()
+            torch.cuda.synchronize()
         for _ in range(3):
             st32()
-        w32 = time_windows(st32, fence32, 5, 7)
-        result["fp32_parity_mode"] = {"value": round(B * 5 / float(np.median(w32)), 1), "unit": "images/s", "batch": B,
-                                      "note": "fp32 storage + exact-fp32 MFMA (heads within 1e-3 of the reference); median of 7 windows of 5 steps"}
-        e32.close()
+        w32 = time_windows(st32, fence32, 6, 7)
+        st32b = make_step(cfa, r32.engines[0], d_in.data_ptr(), B, K, out)
+        for _ in range(2):
+            st32b()
+        w32b = time_windows(st32b, fence32, 5, 5)
+        result["fp32_parity_mode"] = {"value": round(B * 6 / float(np.median(w32)), 1), "unit": "images/s", "batch": B,
+                                      "value_one_context": round(B * 5 / float(np.median(w32b)), 1),
+                                      "note": "fp32 storage + exact-fp32 MFMA (heads within 1e-3 of the reference); %d context(s) "
+                                              "round-robin like the headline; median of 7 windows of 6 steps" % len(r32.engines)}
+        r32.close()
     if not eng_closed:
         close_comms()
         for e in engs:

@@ -136,6 +136,8 @@ size_t stem0px_wstem_bytes();
 size_t stem0px_wdw_dwords();
 void stem0px_pack(const float* ws /*[32][3][3][3]*/, const float* wd /*[32][9]*/, const float* wp /*[16][32]*/,
                   void* wstem_out, uint32_t* wdw_out, void* wproj_out);
+size_t stem0mx_wdw_dwords();
+void stem0mx_pack(const float* ws, const float* wd, const float* wp, void* wstem_out, uint32_t* wdw_out, void* wproj_out);     // Stem0Params::kind bit 2
 void stem0_lut(float* lut /*[3][256]*/);
 size_t stem0_proj_bytes(int dtype);
 void stem0_pack_proj(int dtype, const float* wp /*[16][32]*/, void* out_host);

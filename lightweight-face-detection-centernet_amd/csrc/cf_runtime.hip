@@ -580,10 +580,14 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
             // benchmarked schedule) there is no difference (44.8k img/s either way) and the fabric traffic is a third: on by
             // default, CF_XCD_ORDER=0 switches it off
             static const bool swz_on = !getenv("CF_XCD_ORDER") || atoi(getenv("CF_XCD_ORDER")) >= 1;
-            op.geo.kind = px ? (swz_on ? 3 : 1) : 0;
+            static const bool mx_off = getenv("CF_STEM_MX") && atoi(getenv("CF_STEM_MX")) == 0;      // A/B: depthwise on the matrix cores
+            const bool mx = px && !mx_off;
+            op.geo.kind = px ? ((swz_on ? 3 : 1) | (mx ? 4 : 0)) : 0;
             std::vector<char> w(px ? stem0px_wstem_bytes() : stem_packed_bytes(dt)), wp(stem0_proj_bytes(dt));
-            std::vector<float> wd(px ? stem0px_wdw_dwords() : 9 * 32), lut(768);
-            if (px) {
+            std::vector<float> wd(mx ? stem0mx_wdw_dwords() : px ? stem0px_wdw_dwords() : 9 * 32), lut(768);
+            if (mx) {
+                stem0mx_pack(ws.f(op.wkey), ws.f(op.wkey_dw), ws.f(op.wkey_proj), w.data(), reinterpret_cast<uint32_t*>(wd.data()), wp.data());
+            } else if (px) {
                 stem0px_pack(ws.f(op.wkey), ws.f(op.wkey_dw), ws.f(op.wkey_proj), w.data(), reinterpret_cast<uint32_t*>(wd.data()), wp.data());
             } else {
                 stem_pack_weights(dt, ws.f(op.wkey), w.data());

@@ -19,6 +19,8 @@
 #include <type_traits>
 #include "cf_common.h"
 #include "cf_kernels.h"
+#include "cf_mx.h"
+#include <vector>
 #include "centerface_hip.h"
 
 namespace cf {
@@ -594,9 +596,240 @@ __global__ __launch_bounds__(S0P_NT) void stem0_px_kernel(Stem0Params p) {
     }
 }
 
+// ---- third generation: the 3x3 depthwise on the matrix cores (cf_mx.h, cf_mbconv3.hip) ----
+constexpr int S0M_IWQ = S0_TOW / 4 + 1, S0M_IWP = 4 * S0M_IWQ;      // halo rows of 5 x-quads (20 columns, 18 used)
+constexpr int S0M_IPX = S0_IH * S0M_IWP, S0M_NIB = (S0_IH * S0M_IWQ + 7) / 8, S0M_CP = 32 * 8 + 16;
+size_t stem0mx_wdw_dwords() { return 2 * 3 * 2 * 64 * 2; }
+// stem weights as stem0px_pack; Toeplitz depthwise operands (mx_pack_taps, one round of 32 channels); project 32 -> 16 as
+// the A fragment of v_mfma_f32_16x16x32_bf16 (lane: row m = output channel, k-group lane >> 4 = 8 hidden channels), x -ln 2
+void stem0mx_pack(const float* ws, const float* wd, const float* wp, void* wstem_out, uint32_t* wdw_out, void* wproj_out) {
+    std::vector<uint32_t> scratch(stem0px_wdw_dwords());
+    std::vector<char> pscratch(stem0_proj_bytes(1));
+    stem0px_pack(ws, wd, wp, wstem_out, scratch.data(), pscratch.data());
+    mx_pack_taps(1, 3, wd, wdw_out);
+    __builtin_memset(wproj_out, 0, stem0_proj_bytes(1));
+    for (int lane = 0; lane < 64; ++lane) {
+        const int co = lane & 15, kc = lane >> 4;
+        uint16_t* dst = (uint16_t*)((char*)wproj_out + (size_t)lane * 16);
+        for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kS0NegLn2 * wp[co * 32 + kc * 8 + e]);
+    }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(S0P_NT) void stem0_mx_kernel(Stem0Params p) {
+    typedef bf16_t T;
+    // The normalised patch Xs is dead once every wave has gathered its MFMA operands, so it shares the
+    // LDS bytes of the tile E that phase 1 then writes: 25 KB per workgroup instead of 34 (6 instead of 4
+    // workgroups per CU).
+    __shared__ __attribute__((aligned(16))) char E[S0M_NIB * 8 * S0M_CP];
+    static_assert(S0_PH * S0P_PROW * 2 <= S0M_NIB * 8 * S0M_CP, "patch must fit under the tile");
+    T* Xs = reinterpret_cast<T*>(E);                                     // patch row: 2 pad elements, then e = col*3 + ci
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    unsigned tbx = blockIdx.x, tby = blockIdx.y, tbz = blockIdx.z;
+    if (p.kind & 2) xcd_tile_order(tbx, tby, tbz);
+    const int ox0 = tbx * S0_TOW, oy0 = tby * S0_TOH, b = tbz;
+
+    // ---- stage the normalised image patch
+    const int iy0 = 2 * (oy0 - 1), ix0 = 2 * (ox0 - 1);
+    if constexpr (FMT == CF_IN_U8_HWC_BGR) {
+        // uint8 input: DWORD loads.  The patch row starts 6 (ox0 - 1) bytes into the image row, i.e. 2 bytes
+        // past a dword boundary (ox0 is a multiple of 16, W of 32), so the row is read as 29 aligned
+        // dwords starting 2 bytes early, and a dword lies entirely inside or entirely outside the image row.
+        // Thread = one dword column (fixed channel phase, fixed column validity) walking down the rows;
+        // normalisation is (u/255 - mean)/std as one fma per byte (1 ulp from the reference's two
+        // divisions, far below the bf16 rounding that follows); outside the image: exact 0 (ZeroPad2d).
+        constexpr int ND = S0P_ND, RG = S0P_NT / ND, NITD = (S0_PH + RG - 1) / RG;
+        const int d = tid % ND, rg = tid / ND;
+        const bool tact = rg < RG;
+        const int boff = ix0 * 3 - 2 + 4 * d;
+        const bool din = tact && boff >= 0 && boff + 4 <= p.W * 3;
+        const int cboff = min(max(boff, 0), p.W * 3 - 4);
+        float sc[4], sh[4]; bool bok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * d - 2 + i;                         // element of the patch row, e = col*3 + ci
+            bok[i] = din && e >= 0 && e < S0_PW * 3;
+            const int ci = (e + 3) % 3;
+            // centerface.py:12-15 (BGR): mean 0.408 0.447 0.470, std 0.289 0.274 0.278
+            sc[i] = ci == 0 ? 1.0f / (255.0f * 0.289f) : ci == 1 ? 1.0f / (255.0f * 0.274f) : 1.0f / (255.0f * 0.278f);
+            sh[i] = ci == 0 ? -0.408f / 0.289f : ci == 1 ? -0.447f / 0.274f : -0.470f / 0.278f;
+        }
+        uint32_t v[NITD];
+#pragma unroll
+        for (int it = 0; it < NITD; ++it) {
+            const int cy = min(max(iy0 + rg + it * RG, 0), p.H - 1);
+            v[it] = *reinterpret_cast<const uint32_t*>((const uint8_t*)p.x + ((size_t)b * p.H + cy) * p.W * 3 + cboff);
+        }
+        // Interior tiles (81 % at 640x640: the whole patch inside the image) need no zero-padding selects.  Elements of the
+        // dword columns that lie outside the PATCH then hold neighbouring pixels instead of 0: nothing reads them except
+        // k-slots whose stem weight is zero (stem0px_pack), and they are finite.
+        const bool interior = iy0 >= 0 && iy0 + S0_PH <= p.H && ix0 * 3 - 2 >= 0 && ix0 * 3 - 2 + 4 * ND <= p.W * 3;
+        auto convert = [&](auto inside) {
+#pragma unroll
+            for (int it = 0; it < NITD; ++it) {
+                const int r = rg + it * RG, iy = iy0 + r;
+                const bool rowok = (unsigned)iy < (unsigned)p.H;
+                float f[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float u = (float)((v[it] >> (8 * i)) & 0xffu);             // v_cvt_f32_ubyteN
+                    const float nv = fmaf(u, sc[i], sh[i]);
+                    f[i] = (decltype(inside)::value || (rowok && bok[i])) ? nv : 0.0f;
+                }
+                if (tact && r < S0_PH) {
+                    u32x2 o; o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(Xs) + r * (S0P_PROW * 2) + d * 8) = o;
+                }
+            }
+        };
+        if (interior) convert(std::true_type{}); else convert(std::false_type{});
+    } else {
+        constexpr int ECOLS = S0_PW * 3, RSTEP = S0P_NT / ECOLS, NIT = (S0_PH + RSTEP - 1) / RSTEP;
+        const int e = tid % ECOLS, r0 = tid / ECOLS;
+        const bool tact = r0 < RSTEP;
+        const int col = e / 3, ci = e - col * 3;
+        const int ix = ix0 + col;
+        const bool xok = tact && (unsigned)ix < (unsigned)p.W;
+        const int cx = min(max(ix, 0), p.W - 1);
+        float v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = r0 + it * RSTEP;
+            const int iy = iy0 + r;
+            const bool ok = xok && r < S0_PH && (unsigned)iy < (unsigned)p.H;
+            const int cy = min(max(iy, 0), p.H - 1);
+            const float f = ((const float*)p.x)[(((size_t)b * 3 + ci) * p.H + cy) * p.W + cx];
+            v[it] = ok ? f : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = r0 + it * RSTEP;
+            if (tact && r < S0_PH) Xs[r * S0P_PROW + 2 + e] = (T)(pack_bf16x2(v[it], 0.0f) & 0xffffu);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: stem conv D[pixel][channel] = X . Ws^T, Swish (pre-scaled), pixel pairs -> E
+    u32x4 ws[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) ws[c] = ld16((const char*)p.wstem + ((size_t)c * 64 + lane) * 16);
+    // Toeplitz operands of the 32 stem channels: [2 channel quads][3 rows][2 k-steps] register pairs (mx_pack_taps)
+    u32x2 A[2][3][2];
+    {
+        const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + lane;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) A[q][ky][ks] = at[((q * 3 + ky) * 2 + ks) * 64];
+    }
+    constexpr int MAXB = (S0M_NIB + S0P_NW - 1) / S0P_NW;           // 3 halo pixel blocks per wave (18 rows x 5 quads = 90 quads)
+    u32x4 xg[MAXB][2];
+    // tiles whose whole 18 x 18 halo lies inside the H/2 x W/2 map need no zero-padding selects either (the lanes past the
+    // halo in the last block then carry a copy of its last pixel: their results are never activated or stored)
+    const bool halo_inside = oy0 >= 1 && oy0 + S0_TOH + 1 <= Ho && ox0 >= 1 && ox0 + S0_TOW + 1 <= Wo;
+    auto gather = [&](auto inside) {
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        const int ib = wave + S0P_NW * t;
+        const int ip = ib * 32 + pl;
+        // halo rows of 5 x-quads = 20 columns: columns 18, 19 lie past the 18-wide halo (no output reads them) and repeat column 17
+        const int ipc = ip < S0M_IPX ? ip : S0M_IPX - 1;
+        const int ty = ipc / S0M_IWP, txq = ipc - ty * S0M_IWP, tx = txq < S0_IW ? txq : S0_IW - 1;
+        const int y = oy0 - 1 + ty, x = ox0 - 1 + tx;
+        // a halo pixel outside the map is the depthwise conv's zero padding: zero operand row -> swish(0) = 0
+        const bool inmap = decltype(inside)::value || (ip < S0M_IPX && (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo);
+        // eight aligned dword reads per lane, already in operand order (see stem0px_pack): no packing ops
+        const char* xp = reinterpret_cast<const char*>(Xs) + ((2 * ty) * S0P_PROW + (2 * tx) * 3 + 2) * 2;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint32_t w4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int off = c == 0 ? h * (S0P_PROW * 2) + 4 * i
+                                       : (h == 0 ? 2 * (S0P_PROW * 2) + 4 * i : 16 + (i < 2 ? i : 2) * (S0P_PROW * 2));
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(xp + off);
+                w4[i] = inmap ? v : 0u;
+            }
+            xg[t][c].x = w4[0]; xg[t][c].y = w4[1]; xg[t][c].z = w4[2]; xg[t][c].w = w4[3];
+        }
+    }
+    };
+    if (halo_inside) gather(std::true_type{}); else gather(std::false_type{});
+    __syncthreads();                                              // every wave has its operands: Xs may be overwritten
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+        const int ib = wave + S0P_NW * t;
+        if (ib >= S0M_NIB) break;
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xg[t][c]),
+                                                        __builtin_bit_cast(mfma_bf16x8, ws[c]), a, 0, 0, 0);
+        // D rows (r & 3) + 8 (r >> 2) + 4 h: register quad tq = halo quad ib * 8 + 2 tq + h -> one 8-byte cell of lane channel pl
+        char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)S0M_CP + pl * 8;
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            f32x2 u0, u1; u0.x = a[4 * tq]; u0.y = a[4 * tq + 1]; u1.x = a[4 * tq + 2]; u1.y = a[4 * tq + 3];
+            const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+            u32x2 d;
+            d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+            d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+            *reinterpret_cast<u32x2*>(ecell + 2 * tq * S0M_CP) = d;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2 + 3: depthwise 3x3 on the matrix cores (cf_mx.h) + Swish -> project 32 -> 16.  One set of 16 output quads
+    // per wave; the lane's 8 channels of output pixel i are the B fragment of v_mfma_f32_16x16x32_bf16 (n = quad slot).
+    static constexpr SetMap<S0_TOH, S0_TOW, S0M_IWQ> kSets{};
+    const uint32_t se = kSets.v[wave * 16 + (lane & 15)];
+    const int soy = (se >> 6) & 0x1ff, soxq = se & 63, kg = lane >> 4;
+    f32x4 acc[8];
+    mx_depthwise<3, S0M_IWQ, S0M_CP>(E + (unsigned)(soy * S0M_IWQ + soxq) * (unsigned)S0M_CP + kg * 64,
+                                      reinterpret_cast<const u32x2 (*)[3][2]>(A), acc);
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+            const f32x2 yv = swish2_pre(u);
+            acc[g][i] = yv.x; acc[g][i + 1] = yv.y;
+        }
+    const u32x4 wpc = ld16((const char*)p.wproj + (size_t)lane * 16);
+    const int gy = oy0 + soy, gx0 = ox0 + 4 * soxq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32x4 d;
+        d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
+        d.z = packb(acc[4][i], acc[5][i]); d.w = packb(acc[6][i], acc[7][i]);
+        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wpc), __builtin_bit_cast(mfma_bf16x8, d), o, 0, 0, 0);
+        if (gy < Ho && gx0 + i < Wo) {                             // rows 4 kg .. 4 kg + 3 = output channels of pixel (quad, i)
+            u32x2 ov; ov.x = packb(o[0], o[1]); ov.y = packb(o[2], o[3]);
+            *reinterpret_cast<u32x2*>((T*)p.y + (((size_t)b * Ho + gy) * Wo + gx0 + i) * 16 + kg * 4) = ov;
+        }
+    }
+}
+
 hipError_t launch_stem0(hipStream_t s, int dtype, const Stem0Params& p) {
     if (p.B <= 0) return hipSuccess;
     const int Ho = p.H / 2, Wo = p.W / 2;
+    if (p.kind & 4) {                      // matrix-core depthwise (bf16 storage)
+        if (dtype != 1) return hipErrorInvalidValue;
+        dim3 grid((Wo + S0_TOW - 1) / S0_TOW, (Ho + S0_TOH - 1) / S0_TOH, p.B), blk(S0P_NT);
+        set_kernel_tag("void cf::stem0_mx_kernel<%d>(cf::Stem0Params)", p.in_format);
+        if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem0_mx_kernel<CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((stem0_mx_kernel<CF_IN_F32_NCHW>), grid, blk, 0, s, p);
+        return hipGetLastError();
+    }
     if (p.kind & 1) {
         if (dtype != 1) return hipErrorInvalidValue;
         dim3 grid((Wo + S0_TOW - 1) / S0_TOW, (Ho + S0_TOH - 1) / S0_TOH, p.B), blk(S0P_NT);

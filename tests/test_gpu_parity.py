@@ -730,29 +730,57 @@ def test_expand_dw_kernel_vs_oracle(cfg):
 #  layer by layer against the emulating oracle -- it replaced the bf16-vs-fp32-engine noise-floor tests that stood here)
 
 
-def test_variable_size_buckets_match_per_shape_detectors():
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_variable_size_buckets_match_per_shape_detectors(dtype):
     """BASELINE configs[3] (VGA-class images of different shapes in one batch): CenterFaceBuckets groups by
-    network shape and must return, per image and in input order, exactly what CenterFace(h, w)(img) returns."""
+    network shape and must return, per image and in input order, exactly what CenterFace(h, w)(img) returns --
+    in the fp32 parity mode and in the benchmarked bf16 mode (an image's result does not depend on its batch:
+    the batch index is only blockIdx.z)."""
     rng = np.random.default_rng(2024)
     shapes = [(480, 640), (640, 480), (640, 640), (448, 640), (640, 416), (478, 720), (300, 500), (470, 730), (630, 470)]
     imgs = [rng.integers(0, 256, shapes[i % len(shapes)] + (3,), dtype=np.uint8) for i in range(21)]
-    pool = cfa.CenterFaceBuckets(dtype="fp32", max_batch=4, max_buckets=4)        # fewer contexts than shapes: eviction
+    pool = cfa.CenterFaceBuckets(dtype=dtype, max_batch=4, max_buckets=4)        # fewer contexts than shapes: eviction
     got = pool.detect(imgs)
     assert len(got) == len(imgs)
     # raw sizes that round up to the same network shape share one context: (478,720)/(470,730) -> 480x736,
     # (640,480)/(630,470) -> 640x480; 9 raw shapes = 7 network shapes
-    roomy = cfa.CenterFaceBuckets(dtype="fp32", max_batch=4, max_buckets=16)
+    roomy = cfa.CenterFaceBuckets(dtype=dtype, max_batch=4, max_buckets=16)
     got2 = roomy.detect(imgs)
     assert roomy.created == 7
     for a, b2 in zip(got, got2):
         assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1])
     roomy.close()
     for (h, w) in shapes:
-        one = cfa.CenterFace(h, w, dtype="fp32")
+        one = cfa.CenterFace(h, w, dtype=dtype)
         for i, im in enumerate(imgs):
             if im.shape[:2] != (h, w):
                 continue
             d, l = one(im)
+            assert d.shape == got[i][0].shape and np.array_equal(d, got[i][0]) and np.array_equal(l, got[i][1]), (i, h, w)
+        one.close()
+    pool.close()
+
+
+def test_variable_size_buckets_product_configuration_128_images():
+    """The configs[3] PRODUCT configuration: 128 images of five VGA shapes through CenterFaceBuckets(bf16, max_batch=32)
+    -- chunks of 32, page-locked staging reused across chunks and shapes (one grow-only buffer per context), resized
+    and native-size chunks mixed -- against the one-image-per-call detector of each shape on a sample of the batch."""
+    rng = np.random.default_rng(7)
+    shapes = [(480, 640), (640, 480), (640, 640), (448, 640), (640, 416)]
+    order = rng.integers(0, len(shapes), 128)
+    imgs = [rng.integers(0, 256, shapes[k] + (3,), dtype=np.uint8) for k in order]
+    pool = cfa.CenterFaceBuckets(dtype="bf16", max_batch=32, max_buckets=4)
+    got = pool.detect(imgs)
+    got_again = pool.detect(imgs)                       # contexts, graphs and staging buffers reused
+    assert len(got) == 128
+    for a, b2 in zip(got, got_again):
+        assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1])
+    for si, (h, w) in enumerate(shapes):
+        one = cfa.CenterFace(h, w, dtype="bf16")
+        idx = [i for i in range(128) if order[i] == si][::5]
+        assert idx
+        for i in idx:
+            d, l = one(imgs[i])
             assert d.shape == got[i][0].shape and np.array_equal(d, got[i][0]) and np.array_equal(l, got[i][1]), (i, h, w)
         one.close()
     pool.close()
