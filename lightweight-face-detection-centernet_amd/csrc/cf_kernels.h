@@ -107,6 +107,11 @@ bool mx_fused_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s);
 void mx_fused_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
                            void* wexp_host, float* wdw_host, void* wproj_host);
 hipError_t mx_fused_launch(hipStream_t s, const MbParams& p);
+// MbGeom::kind 6 = the same for the stride-2 blocks (two sets per tile, waves = (set, channel half))
+bool mx_fused2_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s);
+void mx_fused2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+                            void* wexp_host, float* wdw_host, void* wproj_host);
+hipError_t mx_fused2_launch(hipStream_t s, const MbParams& p);
 
 // ------------------------------------------------------------------ stem 3x3 s2 3->32 + Swish
 struct StemParams {

@@ -60,6 +60,7 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
     if (g.kind == 1 || g.kind == 2) { mb2_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 4) { mx_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 5) { mx_fused_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
+    if (g.kind == 6) { mx_fused2_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     const int P = per16(dtype);
     const int NCx = Cin * (int)elem_size(dtype) / 16;
     __builtin_memset(wexp_host, 0, g.wexp_bytes);
@@ -429,6 +430,7 @@ MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
     const int sz = (int)elem_size(dtype);
     if ((Cin % 8) || (Cout % 8) || Cout > 96 || Cin > 96 || hid == Cin) return g;
     if (dtype == 1 && mx_fused_geometry(g, Cin, hid, Cout, k, s)) return g;      // stride 1: depthwise on the matrix cores
+    if (dtype == 1 && mx_fused2_geometry(g, Cin, hid, Cout, k, s)) return g;     // stride 2
     if (dtype == 1 && mb2_geometry(g, Cin, hid, Cout, k, s)) return g;
     g.JX = (Cin * sz / 16 + 1) / 2;
     g.NBO = (Cout + 31) / 32;
@@ -452,6 +454,7 @@ hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p) {
     if (p.kind == 2) return dtype == 1 ? expdw_launch(s, p) : hipErrorInvalidValue;
     if (p.kind == 4) return dtype == 1 ? mx_launch(s, p) : hipErrorInvalidValue;
     if (p.kind == 5) return dtype == 1 ? mx_fused_launch(s, p) : hipErrorInvalidValue;
+    if (p.kind == 6) return dtype == 1 ? mx_fused2_launch(s, p) : hipErrorInvalidValue;
     const MbEntry* e = mb_find(dtype, p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
     if (!e || e->hc != p.HC) return hipErrorInvalidValue;
     return e->fn(s, p);

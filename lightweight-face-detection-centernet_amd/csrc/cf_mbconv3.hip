@@ -475,6 +475,269 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
     }
 }
 
+// ================================================================== fully fused block, stride 2 (layer1.0, layer2.0)
+// The input halo of a stride-2 tile is four times the output tile, so the LDS budget allows 32 output quads = two sets per
+// workgroup.  Four waves = (set, channel half): every wave runs the depthwise of ITS four channels per group (4 x KS x 3
+// MFMAs per round: an output quad reads inputs x .. x+10 = three k-steps), Swish, and projects them with
+// v_mfma_f32_16x16x16_bf16 (K = 16 = its 4 channels x 4 groups) into its own partial accumulators; the two halves of a set
+// are added through LDS once at the end.  Everything else as mbconv_mx_kernel.  The operand table always lives in LDS.
+template <int KS, int JX, int NMB, int TOH, int TOW, bool TAIL16, bool ALDS = true>
+struct Fs {
+    static constexpr int NW = 4, KSTEPS = 3, NSTEP = KS * KSTEPS;
+    static constexpr int IH = (TOH - 1) * 2 + KS, IW0 = (TOW - 1) * 2 + KS, IWQ = (IW0 + 3) / 4, IWP = IWQ * 4;
+    static constexpr int NQD = IH * IWQ, NIB = (NQD + 7) / 8, IPX = NQD * 4, MAXI = (NIB + NW - 1) / NW;
+    static constexpr int CP8 = 32 * 8 + 16, CP4 = 16 * 8 + 16;
+    static constexpr int EBYTES = NIB * 8 * CP8;
+    static constexpr int NOQ = TOH * (TOW / 4);
+    static constexpr int WXB = JX * 1024, ATB = 2 * NSTEP * 512;
+    static constexpr int RED = 2 * 64 * 4 * NMB * 16;                  // partial accumulators of the two half-1 waves
+    static constexpr int LDS = (EBYTES + 2 * WXB + (ALDS ? ATB : 0)) > RED ? (EBYTES + 2 * WXB + (ALDS ? ATB : 0)) : RED;
+    static_assert(NOQ == 32 && TOW % 4 == 0 && KS <= 5, "two sets of 16 output quads per tile");
+    static_assert(!TAIL16 || JX <= 2, "16-channel round: one 16x16x32 expand MFMA, Cin <= 32");
+};
+
+template <int KS, int JX, int NMB, int TOH, int TOW, bool TAIL16, bool XRELOAD, bool ALDS>
+__global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
+    typedef Fs<KS, JX, NMB, TOH, TOW, TAIL16, ALDS> G;
+    constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, MAXI = G::MAXI, CP8 = G::CP8, CP4 = G::CP4;
+    constexpr int WXB = G::WXB, NW = 4, KSTEPS = 3, NSTEP = G::NSTEP;
+    typedef __attribute__((ext_vector_type(4))) __bf16 mfma_bf16x4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* E = smem;
+    char* Wst = smem + G::EBYTES;
+    char* Ats = Wst + 2 * WXB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int set = wave & 1, half = wave >> 1;
+    const int pl = lane & 31, h = lane >> 5, kg = lane >> 4;
+    const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH, b = blockIdx.z;
+    const int nq = p.nq;
+
+    const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+    const unsigned rowbytes = (unsigned)p.Cin * 2;
+
+    auto stage_weights = [&](int q) {
+        char* dst = Wst + (q & 1) * WXB;
+        const char* srcx = (const char*)p.wexp + (size_t)q * WXB;
+        for (int c = wave; c < WXB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+    };
+    u32x4 xf[MAXI][JX];
+    auto load_x = [&]() {
+#pragma unroll
+    for (int t = 0; t < MAXI; ++t) {
+        const int ib = wave + NW * t;
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < IPX ? ip : IPX - 1;
+        const int iy = ipc / IWP, ix = ipc - iy * IWP;
+        const int gy = oy0 * 2 - p.pad_lo + iy, gx = ox0 * 2 - p.pad_lo + ix;
+        const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+        const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const u32x4 v = ld16(xbase + off + j * 16);
+            xf[t][j].x = valid ? v.x : 0u; xf[t][j].y = valid ? v.y : 0u;
+            xf[t][j].z = valid ? v.z : 0u; xf[t][j].w = valid ? v.w : 0u;
+        }
+    }
+    };
+    if constexpr (!XRELOAD) load_x();
+
+    static constexpr SetMap<TOH, TOW, IWQ, 2> kSets{};
+    const uint32_t se = kSets.v[set * 16 + (lane & 15)];
+    const int soy = (se >> 6) & 0x1ff, soxq = se & 63;
+    const unsigned qcell = (unsigned)(2 * soy * IWQ + 2 * soxq);        // first input quad of this lane's output quad
+
+    f32x4 pacc[4][NMB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) pacc[i][mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    stage_weights(0);
+    for (int q = 0; q < nq; ++q) {
+        const char* wx = Wst + (q & 1) * WXB;
+        cf_sync_lds_dma();    // previous round's depthwise done with E and the operand table; this round's expand weights landed
+        u32x2 Ah[ALDS ? 1 : KS][KSTEPS];
+        if constexpr (ALDS) {
+            const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
+            for (int c = wave; c < G::ATB / 1024; c += NW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
+        } else {
+            const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + ((size_t)q * 2 + half) * NSTEP * 64 + lane;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) Ah[ky][ks] = at[(ky * KSTEPS + ks) * 64];
+        }
+        u32x2 wp4[NMB];      // project fragments of this wave's 16 channels (4 per group): A operand of 16x16x16, 8 bytes per lane
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+            wp4[mb] = *reinterpret_cast<const u32x2*>((const char*)p.wproj + ((((size_t)q * 2 + half) * NMB + mb) * 64 + lane) * 8);
+        if constexpr (XRELOAD) load_x();
+
+        // ---- phase 1: expand + Swish -> quad cells
+#pragma unroll
+        for (int t = 0; t < MAXI; ++t) {
+            const int ib = wave + NW * t;
+            if (ib >= NIB) break;
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < JX; ++j) {
+                const u32x4 wv = ld16(wx + (j * 64 + lane) * 16);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xf[t][j]),
+                                                            __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
+            }
+            char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)CP8 + pl * 8;
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                f32x2 u0, u1; u0.x = a[4 * tq]; u0.y = a[4 * tq + 1]; u1.x = a[4 * tq + 2]; u1.y = a[4 * tq + 3];
+                const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+                u32x2 d;
+                d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+                d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+                *reinterpret_cast<u32x2*>(ecell + 2 * tq * CP8) = d;
+            }
+        }
+        cf_sync_lds_dma();          // E complete; the operand table landed
+        if (q + 1 < nq) stage_weights(q + 1);
+
+        // ---- phase 2: this wave's (set, channel half): depthwise + Swish + project
+        {
+            f32x4 acc[4];
+            if constexpr (ALDS) mx_depthwise_half<KS, KSTEPS, IWQ, CP8>(E + qcell * (unsigned)CP8 + kg * 64 + half * 32, Ats + half * (NSTEP * 512) + lane * 8, acc);
+            else mx_depthwise_half_reg<KS, KSTEPS, IWQ, CP8>(E + qcell * (unsigned)CP8 + kg * 64 + half * 32, reinterpret_cast<const u32x2 (*)[KSTEPS]>(Ah), acc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+                    const f32x2 y = swish2_pre(u);
+                    acc[g][i] = y.x; acc[g][i + 1] = y.y;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x2 d; d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb)
+                    pacc[i][mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mfma_bf16x4, wp4[mb]),
+                                                                            __builtin_bit_cast(mfma_bf16x4, d), pacc[i][mb], 0, 0, 0);
+            }
+        }
+    }
+
+    if constexpr (TAIL16) {
+        // ---- last round: 16 hidden channels (4 groups x 4), done by the half-0 wave of each set (1 / 9 of the work at hid = 144)
+        const u32x4 wv = ld16((const char*)p.wexp + (size_t)nq * WXB + lane * 16);
+        u32x2 A4[KS][KSTEPS];
+        {
+            const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)nq * (2 * NSTEP) * 64 + lane;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) A4[ky][ks] = at[(ky * KSTEPS + ks) * 64];
+        }
+        u32x2 wp4[NMB];
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+            wp4[mb] = *reinterpret_cast<const u32x2*>((const char*)p.wproj + (size_t)nq * 2 * NMB * 512 + ((size_t)mb * 64 + lane) * 8);
+        __syncthreads();
+        for (int sb = wave; sb < NIB * 2; sb += NW) {               // 16-pixel sub-blocks = 4 quads each
+            const int ip = sb * 16 + (lane & 15), kc = lane >> 4;
+            const int ipc = ip < IPX ? ip : IPX - 1;
+            const int iy = ipc / IWP, ix = ipc - iy * IWP;
+            const int gy = oy0 * 2 - p.pad_lo + iy, gx = ox0 * 2 - p.pad_lo + ix;
+            const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win && kc * 8 < p.Cin;
+            const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+            u32x4 xv = ld16(xbase + ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(min(kc * 8, p.Cin - 8) * 2));
+            xv.x = valid ? xv.x : 0u; xv.y = valid ? xv.y : 0u; xv.z = valid ? xv.z : 0u; xv.w = valid ? xv.w : 0u;
+            f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, xv), __builtin_bit_cast(mfma_bf16x8, wv), a4, 0, 0, 0);
+            f32x2 u0, u1; u0.x = a4[0]; u0.y = a4[1]; u1.x = a4[2]; u1.y = a4[3];
+            const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+            u32x2 d;
+            d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+            d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+            *reinterpret_cast<u32x2*>(E + (unsigned)(sb * 4 + kc) * (unsigned)CP4 + (lane & 15) * 8) = d;
+        }
+        __syncthreads();
+        if (half == 0) {
+            const char* bb = E + qcell * (unsigned)CP4 + kg * 32;
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                const char* bs = bb + ((st / KSTEPS) * IWQ + (st % KSTEPS)) * CP4;
+                const u32x4 b0 = ld16(bs), b1 = ld16(bs + 16);
+                const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, A4[st / KSTEPS][st % KSTEPS]);
+                u32x2 t0, t1, t2, t3; t0.x = b0.x; t0.y = b0.y; t1.x = b0.z; t1.y = b0.w; t2.x = b1.x; t2.y = b1.y; t3.x = b1.z; t3.y = b1.w;
+                CF_MX_MFMA(acc[0], av, __builtin_bit_cast(mfma_f16x4, t0), 0);
+                CF_MX_MFMA(acc[1], av, __builtin_bit_cast(mfma_f16x4, t1), 1);
+                CF_MX_MFMA(acc[2], av, __builtin_bit_cast(mfma_f16x4, t2), 2);
+                CF_MX_MFMA(acc[3], av, __builtin_bit_cast(mfma_f16x4, t3), 3);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+                    const f32x2 y = swish2_pre(u);
+                    acc[g][i] = y.x; acc[g][i + 1] = y.y;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x2 d; d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb)
+                    pacc[i][mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mfma_bf16x4, wp4[mb]),
+                                                                            __builtin_bit_cast(mfma_bf16x4, d), pacc[i][mb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- add the two channel halves of every set through LDS, then the epilogue by the half-0 waves
+    __syncthreads();
+    {
+        f32x4* red = reinterpret_cast<f32x4*>(smem) + ((size_t)set * 64 + lane) * (4 * NMB);
+        if (half == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb) red[i * NMB + mb] = pacc[i][mb];
+        }
+        __syncthreads();
+        if (half == 1) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb) pacc[i][mb] += red[i * NMB + mb];
+    }
+    const int gy = oy0 + soy, gx0 = ox0 + 4 * soxq;
+    if ((se & 0x8000u) || gy >= p.Hout) return;
+    const size_t opix0 = ((size_t)b * p.Hout + gy) * p.Wout + gx0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (gx0 + i >= p.Wout) break;
+        const size_t opix = opix0 + i;
+#pragma unroll
+        for (int mp = 0; mp < NMB / 2; ++mp) {
+            const int ch = mp * 32 + kg * 8;
+            if (ch >= p.Cout) break;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = pacc[i][2 * mp][r]; v[4 + r] = pacc[i][2 * mp + 1][r]; }
+            st16((char*)p.y + (p.yblock ? blk_off(opix, p.Cout / 8, ch / 8) : (opix * p.Cout + ch) * 2), pack16b(v));
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side
 struct MxEntry {
     int k, jx, toh, tow, nw, var, lds_bytes;
@@ -554,20 +817,20 @@ MbGeom expdw_mx_geometry(int dtype, int Cin, int hid, int k, int s) {
 
 // Toeplitz A operands: [round][channel quad q][ky][k-step][lane (kg, pg, i)] = 4 fp16: tap w[ky][4 ks + k - i] of channel
 // round*32 + kg*8 + q*4 + pg (MFMA abid = pg selects it for the whole group kg)
-void mx_pack_taps(int nq, int k, const float* wd /*[hid][k*k]*/, uint32_t* out) {
+void mx_pack_taps(int nq, int k, const float* wd /*[hid][k*k]*/, uint32_t* out, int stride, int ksteps) {
     for (int r = 0; r < nq; ++r)
         for (int q = 0; q < 2; ++q)
             for (int ky = 0; ky < k; ++ky)
-                for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < ksteps; ++ks)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int kg = lane >> 4, pg = (lane >> 2) & 3, i = lane & 3;
                         const float* wrow = wd + (size_t)(r * 32 + kg * 8 + q * 4 + pg) * k * k + (size_t)ky * k;
                         uint16_t v[4];
                         for (int kk = 0; kk < 4; ++kk) {
-                            const int kx = 4 * ks + kk - i;
+                            const int kx = 4 * ks + kk - stride * i;
                             v[kk] = (kx >= 0 && kx < k) ? host_f32_to_f16_3(wrow[kx]) : 0;
                         }
-                        uint32_t* dst = out + ((((size_t)(r * 2 + q) * k + ky) * 2 + ks) * 64 + lane) * 2;
+                        uint32_t* dst = out + ((((size_t)(r * 2 + q) * k + ky) * ksteps + ks) * 64 + lane) * 2;
                         dst[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
                         dst[1] = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
                     }
@@ -728,6 +991,136 @@ void mx_fused_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, c
 hipError_t mx_fused_launch(hipStream_t s, const MbParams& p) {
     const FxEntry* e = fx_find(p.k, p.JX, 2 * ((p.Cout + 31) / 32), p.residual ? 1 : 0, (p.hid % 32) ? 1 : 0);
     if (!e || p.s != 1) return hipErrorInvalidValue;
+    return e->fn(s, p);
+}
+
+
+// ---------------------------------------------------------------- fused block, stride 2, host side (MbGeom::kind = 6)
+struct FsEntry {
+    int k, jx, nmb, tail, toh, tow, xr, var, lds_bytes;
+    hipError_t (*fn)(hipStream_t, const MbParams&);
+};
+template <int KS, int JX, int NMB, int TOH, int TOW, bool TAIL16, bool XRELOAD, bool ALDS>
+static hipError_t fs_launch_t(hipStream_t s, const MbParams& p) {
+    typedef Fs<KS, JX, NMB, TOH, TOW, TAIL16, ALDS> G;
+    auto kfn = mbconv_mx2_kernel<KS, JX, NMB, TOH, TOW, TAIL16, XRELOAD, ALDS>;
+    static thread_local bool configured_dev[32] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool& configured = configured_dev[dev & 31];
+    if (G::LDS > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(256);
+    set_kernel_tag("void cf::mbconv_mx2_kernel<%d, %d, %d, %d, %d, %s, %s, %s>(cf::MbParams)", KS, JX, NMB, TOH, TOW,
+                   TAIL16 ? "true" : "false", XRELOAD ? "true" : "false", ALDS ? "true" : "false");
+    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
+    return hipGetLastError();
+}
+#define FSE(V, KS, JX, NMB, TAIL, TOH, TOW, XR, AL) \
+    {KS, JX, NMB, TAIL, TOH, TOW, XR, V, Fs<KS, JX, NMB, TOH, TOW, (TAIL != 0), (AL != 0)>::LDS, &fs_launch_t<KS, JX, NMB, TOH, TOW, (TAIL != 0), (XR != 0), (AL != 0)>}
+static const FsEntry kFsTable[] = {
+    //  var KS JX NMB tail  tile  X reload  A in LDS       (B = 64, 640x640, HIP events; cf_mbconv2.hip kernel of the layer in brackets)
+    FSE(0, 5, 2, 2, 1, 8, 16, 0, 0),      // 2.0  24 -> 144 -> 32, 160x160 -> 80x80, four rounds of 32 + one of 16: 0.150 ms [0.177]
+    // layer1.0 (16 -> 96 -> 24, 3x3, 320x320 -> 160x160) stays on cf_mbconv2.hip: its depthwise is 4 % of the block's work and
+    // 25 600 small workgroups pay the operand-table fetch three times each: 0.264 ms here (0.327 with the table in LDS) vs 0.246
+    FSE(1, 3, 1, 2, 0, 8, 16, 0, 0),
+    FSE(1, 5, 2, 2, 1, 8, 16, 0, 1),
+    FSE(2, 3, 1, 2, 0, 8, 16, 0, 1),
+    FSE(2, 5, 2, 2, 1, 8, 16, 1, 0),
+};
+#undef FSE
+static const FsEntry* fs_find(int k, int jx, int nmb, int tail) {
+    static const int want = getenv("CF_FS_VARIANT") ? atoi(getenv("CF_FS_VARIANT")) : 0;
+    const FsEntry* base = nullptr;
+    for (const FsEntry& e : kFsTable)
+        if (e.k == k && e.jx == jx && e.nmb == nmb && e.tail == tail) {
+            if (e.var == want) return &e;
+            if (e.var == 0) base = &e;
+        }
+    return base;
+}
+
+bool mx_fused2_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
+    static const bool off = getenv("CF_FS") && atoi(getenv("CF_FS")) == 0;
+    if (off || s != 2 || (Cin % 8) || (Cout % 8) || Cout > 64 || (hid % 16) || hid == Cin) return false;
+    const int jx = (Cin * 2 / 16 + 1) / 2, nmb = 2 * ((Cout + 31) / 32), tail = (hid % 32) ? 1 : 0;
+    const FsEntry* e = fs_find(k, jx, nmb, tail);
+    if (!e) return false;
+    g = MbGeom{};
+    g.ok = true; g.kind = 6; g.S = 2;
+    g.JX = jx; g.NBO = nmb; g.HC = 32; g.nq = hid / 32; g.NBE = 1; g.HALF = tail;
+    g.rowb = 32 * 8 + 16;
+    g.lds_bytes = (size_t)e->lds_bytes;
+    g.wexp_bytes = (size_t)g.nq * g.JX * 1024 + (tail ? 1024 : 0);
+    g.wdw_floats = ((size_t)g.nq * 2 + (tail ? 1 : 0)) * k * 3 * 64 * 2;
+    g.wproj_bytes = (size_t)g.nq * 2 * nmb * 512 + (tail ? (size_t)nmb * 512 : 0);
+    return true;
+}
+
+void mx_fused2_pack_weights(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+                            void* wexp_host, float* wdw_host, void* wproj_host) {
+    const int NCx = Cin * 2 / 16, nq = g.nq, tail = g.HALF, nmb = g.NBO;
+    __builtin_memset(wexp_host, 0, g.wexp_bytes);
+    __builtin_memset(wproj_host, 0, g.wproj_bytes);
+    for (int q = 0; q < nq; ++q)
+        for (int j = 0; j < g.JX; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 31, hh = lane >> 5, c = hh * g.JX + j;
+                if (c >= NCx) continue;
+                uint16_t* dst = (uint16_t*)((char*)wexp_host + (((size_t)q * g.JX + j) * 64 + lane) * 16);
+                for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLog2e3 * we[(size_t)(q * 32 + n) * Cin + (size_t)c * 8 + e]);
+            }
+    uint32_t* wt = reinterpret_cast<uint32_t*>(wdw_host);
+    mx_pack_taps(nq, k, wd, wt, 2, 3);
+    // project, per (round, channel half): A fragment of 16x16x16: lane (m = output channel slot, kc = group) holds the 4
+    // hidden channels q*32 + kc*8 + half*4 + e
+    for (int q = 0; q < nq; ++q)
+        for (int hf = 0; hf < 2; ++hf)
+            for (int mb = 0; mb < nmb; ++mb)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = fx_out_channel(mb, lane & 15), kc = lane >> 4;
+                    if (co >= Cout) continue;
+                    uint16_t* dst = (uint16_t*)((char*)wproj_host + ((((size_t)q * 2 + hf) * nmb + mb) * 64 + lane) * 8);
+                    for (int e = 0; e < 4; ++e) dst[e] = host_f32_to_bf16(kNegLn23 * wp[(size_t)co * hid + q * 32 + kc * 8 + hf * 4 + e]);
+                }
+    if (tail) {
+        const int c0 = nq * 32;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int n = lane & 15, kc = lane >> 4;
+            if (kc >= NCx) continue;
+            uint16_t* dst = (uint16_t*)((char*)wexp_host + (size_t)nq * g.JX * 1024 + (size_t)lane * 16);
+            for (int e = 0; e < 8; ++e) dst[e] = host_f32_to_bf16(kNegLog2e3 * we[(size_t)(c0 + n) * Cin + (size_t)kc * 8 + e]);
+        }
+        uint32_t* tt = wt + (size_t)nq * 2 * k * 3 * 64 * 2;
+        for (int ky = 0; ky < k; ++ky)
+            for (int ks = 0; ks < 3; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int kgq = lane >> 4, pg = (lane >> 2) & 3, i = lane & 3;
+                    const float* wrow = wd + (size_t)(c0 + kgq * 4 + pg) * k * k + (size_t)ky * k;
+                    uint16_t v[4];
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int kx = 4 * ks + kk - 2 * i;
+                        v[kk] = (kx >= 0 && kx < k) ? host_f32_to_f16_3(wrow[kx]) : 0;
+                    }
+                    uint32_t* dst = tt + (((size_t)ky * 3 + ks) * 64 + lane) * 2;
+                    dst[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+                    dst[1] = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+                }
+        for (int mb = 0; mb < nmb; ++mb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = fx_out_channel(mb, lane & 15), kc = lane >> 4;
+                if (co >= Cout) continue;
+                uint16_t* dst = (uint16_t*)((char*)wproj_host + (size_t)nq * 2 * nmb * 512 + ((size_t)mb * 64 + lane) * 8);
+                for (int e = 0; e < 4; ++e) dst[e] = host_f32_to_bf16(kNegLn23 * wp[(size_t)co * hid + c0 + kc * 4 + e]);
+            }
+    }
+}
+
+hipError_t mx_fused2_launch(hipStream_t s, const MbParams& p) {
+    const FsEntry* e = fs_find(p.k, p.JX, 2 * ((p.Cout + 31) / 32), (p.hid % 32) ? 1 : 0);
+    if (!e || p.s != 2) return hipErrorInvalidValue;
     return e->fn(s, p);
 }
 

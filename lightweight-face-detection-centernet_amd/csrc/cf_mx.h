@@ -53,14 +53,14 @@ static inline uint16_t host_f32_to_f16_3(float f) {       // round-to-nearest-ev
 }
 
 // lane & 15 -> output quad of a set (entry: bit 15 = no quad, bits 6.. = oy, bits 0-5 = x-quad)
-template <int TOH, int TOW, int IWQ>
+template <int TOH, int TOW, int IWQ, int S = 1>
 struct SetMap {
     static constexpr int OWQ = TOW / 4, NOQ = TOH * OWQ, NSET = (NOQ + 15) / 16, NSLOT = NSET * 16;
     static_assert(OWQ <= 64 && TOH <= 256, "entry packing");
     uint16_t v[NSLOT];
     constexpr SetMap() : v() {
         int bucket[16][NOQ] = {}; int cnt[16] = {}, used[16] = {};
-        for (int r = 0; r < NOQ; ++r) { const int b = ((r / OWQ) * IWQ + (r % OWQ)) & 15; bucket[b][cnt[b]++] = r; }
+        for (int r = 0; r < NOQ; ++r) { const int b = (S * (r / OWQ) * IWQ + S * (r % OWQ)) & 15; bucket[b][cnt[b]++] = r; }     // class of the quad's first INPUT quad
         int slot[NSLOT] = {};
         for (int s = 0; s < NSET; ++s)
             for (int q = 0; q < 16; ++q) {
@@ -157,7 +157,69 @@ __device__ __forceinline__ void mx_depthwise_lds(const char* bb, const char* at 
     }
 }
 
+// Half a set's channels (g = 4 half .. 4 half + 3: 32 contiguous bytes of a cell row) for the stride-2 blocks, where a wave is
+// (set, channel half); KSTEPS k-steps per kernel row (stride 2: inputs x .. x + 10 of an output quad = three quads); the Toeplitz
+// operand table in LDS is [2 channel quads][KS][KSTEPS][64 lanes] x 8 B, `at` points at this half's quad + lane * 8
+template <int KS, int KSTEPS, int IWQ, int CP>
+__device__ __forceinline__ void mx_depthwise_half(const char* bb, const char* at, f32x4* acc) {
+    constexpr int NSTEP = KS * KSTEPS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    u32x4 bq[2][2];
+    u32x2 aq[2];
+    bq[0][0] = ld16(bb); bq[0][1] = ld16(bb + 16);
+    aq[0] = *reinterpret_cast<const u32x2*>(at);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) {
+            const int ky = (st + 1) / KSTEPS, ks = (st + 1) % KSTEPS;
+            bq[(st + 1) & 1][0] = ld16(bb + (ky * IWQ + ks) * CP);
+            bq[(st + 1) & 1][1] = ld16(bb + (ky * IWQ + ks) * CP + 16);
+            aq[(st + 1) & 1] = *reinterpret_cast<const u32x2*>(at + (st + 1) * 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, aq[st & 1]);
+        u32x2 t0, t1, t2, t3;
+        t0.x = bq[st & 1][0].x; t0.y = bq[st & 1][0].y; t1.x = bq[st & 1][0].z; t1.y = bq[st & 1][0].w;
+        t2.x = bq[st & 1][1].x; t2.y = bq[st & 1][1].y; t3.x = bq[st & 1][1].z; t3.y = bq[st & 1][1].w;
+        CF_MX_MFMA(acc[0], av, __builtin_bit_cast(mfma_f16x4, t0), 0);
+        CF_MX_MFMA(acc[1], av, __builtin_bit_cast(mfma_f16x4, t1), 1);
+        CF_MX_MFMA(acc[2], av, __builtin_bit_cast(mfma_f16x4, t2), 2);
+        CF_MX_MFMA(acc[3], av, __builtin_bit_cast(mfma_f16x4, t3), 3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the same with this half's Toeplitz operands resident in registers (KS x KSTEPS pairs)
+template <int KS, int KSTEPS, int IWQ, int CP>
+__device__ __forceinline__ void mx_depthwise_half_reg(const char* bb, const u32x2 (*A)[KSTEPS], f32x4* acc) {
+    constexpr int NSTEP = KS * KSTEPS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    u32x4 bq[2][2];
+    bq[0][0] = ld16(bb); bq[0][1] = ld16(bb + 16);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) {
+            const int ky = (st + 1) / KSTEPS, ks = (st + 1) % KSTEPS;
+            bq[(st + 1) & 1][0] = ld16(bb + (ky * IWQ + ks) * CP);
+            bq[(st + 1) & 1][1] = ld16(bb + (ky * IWQ + ks) * CP + 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, A[st / KSTEPS][st % KSTEPS]);
+        u32x2 t0, t1, t2, t3;
+        t0.x = bq[st & 1][0].x; t0.y = bq[st & 1][0].y; t1.x = bq[st & 1][0].z; t1.y = bq[st & 1][0].w;
+        t2.x = bq[st & 1][1].x; t2.y = bq[st & 1][1].y; t3.x = bq[st & 1][1].z; t3.y = bq[st & 1][1].w;
+        CF_MX_MFMA(acc[0], av, __builtin_bit_cast(mfma_f16x4, t0), 0);
+        CF_MX_MFMA(acc[1], av, __builtin_bit_cast(mfma_f16x4, t1), 1);
+        CF_MX_MFMA(acc[2], av, __builtin_bit_cast(mfma_f16x4, t2), 2);
+        CF_MX_MFMA(acc[3], av, __builtin_bit_cast(mfma_f16x4, t3), 3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Toeplitz A operands of nq rounds of 32 channels: [round][channel quad q][ky][k-step][lane (kg, pg, i)] = 4 fp16 (cf_mbconv3.hip)
-void mx_pack_taps(int nq, int k, const float* wd /*[channels][k*k]*/, uint32_t* out);
+// tap of output offset i against input k of k-step ks: w[ky][4 ks + k - stride * i]
+void mx_pack_taps(int nq, int k, const float* wd /*[channels][k*k]*/, uint32_t* out, int stride = 1, int ksteps = 2);
 
 }  // namespace cf

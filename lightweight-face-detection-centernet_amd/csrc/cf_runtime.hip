@@ -140,7 +140,7 @@ void layout_pass(cf_ctx* c) {
         if (j < 0) continue;
         Op& pr = ops[j];
         const bool can_write = !pr.fused_away && pr.low < 0 &&
-                               ((pr.kind == OP_PW && pr.bnkey.empty()) || (pr.kind == OP_MB && (pr.geo.kind == 1 || pr.geo.kind == 5)));
+                               ((pr.kind == OP_PW && pr.bnkey.empty()) || (pr.kind == OP_MB && (pr.geo.kind == 1 || pr.geo.kind == 5 || pr.geo.kind == 6)));
         if (!can_write) continue;
         bool ok = true;
         size_t end = j + 1;
