@@ -132,6 +132,14 @@ __device__ __forceinline__ void cf_sync_lds_dma() {
     __syncthreads();
 }
 
+// ... keeping the N most recently issued vector-memory operations in flight across the barrier (register prefetches issued
+// AFTER the DMAs: vmcnt retires in order, so vmcnt(N) still covers every DMA).  Every wave must really have issued those N.
+template <int N> __device__ __forceinline__ void cf_sync_lds_dma_keep() {
+    static_assert(N >= 0 && N <= 63, "vmcnt field");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+    __syncthreads();
+}
+
 // Lane -> output pixel map of the depthwise phase (pixel-pair tile kernels: cf_mbconv2.hip, cf_stem0.hip).
 //
 // A lane reads its pixel's pixel-pair rows from the LDS tile with ds_read_b128 at  e * PITCH + const, PITCH / 16 odd,

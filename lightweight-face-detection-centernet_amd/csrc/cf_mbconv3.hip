@@ -74,6 +74,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void*)(Wst + c * 1024), 16, 0, 0);
     }
+    asm volatile("" ::: "memory");        // the loads below stay behind the DMAs in program order (cf_sync_lds_dma_keep counts on it)
     // Toeplitz A operands of this round ([2 channel quads][KS][2 k-steps][lane] x 8 B): an LDS copy next to the expand
     // weights (ALDS: 81-110 VGPRs, + 6 / 10 KB of LDS) or resident register pairs (132-148 VGPRs)
     char* Ats = Wst + WXB;
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) A[q][ky][ks] = at[((q * KS + ky) * 2 + ks) * 64];
     }
+    asm volatile("" ::: "memory");
     const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
     const unsigned rowbytes = (unsigned)p.Cin * 2;
     auto load_x = [&](int ib, u32x4* xf) -> bool {
@@ -121,7 +123,8 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
     u32x4 xa[JX];
     bool va = false;
     if (wave < NIB) va = load_x(wave, xa);
-    cf_sync_lds_dma();               // expand weights and the operand table have landed for every wave
+    static_assert(NIB >= NW, "every wave issues the X loads the wait below keeps in flight");
+    cf_sync_lds_dma_keep<(ALDS ? 0 : 2 * KS * 2) + JX>();      // expand weights / operand table (DMA, issued first) landed for every wave
     mask_x(xa, va);
 
     // ---- phase 1: expand + Swish -> quad cells.  D rows (r & 3) + 8 (r >> 2) + 4 h: register quad t = halo quad ib*8 + 2t + h
@@ -292,17 +295,13 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
             for (int mb = 0; mb < NMB; ++mb) pacc[sw][i][mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     stage_weights(0);
+    asm volatile("" ::: "memory");
     for (int q = 0; q < nq; ++q) {
         const char* wx = Wst + (q & 1) * WXB;
-        cf_sync_lds_dma();    // previous round's depthwise done with E (and the operand table); this round's expand weights (DMA) landed
-        // Toeplitz operands + project fragments of this round: requested before the expand phase, used after it
+        // Toeplitz operands + project fragments of this round (and the X fragments when reloaded): requested before the barrier,
+        // used after it -- they stay in flight across it, only the older expand-weight DMA is drained
         u32x2 A[ALDS ? 1 : 2][ALDS ? 1 : KS][2];
-        if constexpr (ALDS) {      // this round's Toeplitz table -> LDS under the expand phase (drained before the next barrier)
-            const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
-            for (int c = wave; c < G::ATB / 1024; c += NW)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
-        } else {
+        if constexpr (!ALDS) {
             const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)q * (2 * KS * 2) * 64 + lane;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -315,6 +314,13 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb) wpc[mb] = ld16((const char*)p.wproj + (((size_t)q * NMB + mb) * 64 + lane) * 16);
         if constexpr (XRELOAD) load_x();
+        cf_sync_lds_dma_keep<(ALDS ? 0 : 2 * KS * 2) + NMB + (XRELOAD ? MAXI * JX : 0)>();   // previous round's depthwise done with E / the table; expand weights landed
+        if constexpr (ALDS) {      // this round's Toeplitz table -> LDS under the expand phase (drained before the next barrier)
+            const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
+            for (int c = wave; c < G::ATB / 1024; c += NW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
+        }
 
         // ---- phase 1: expand + Swish -> quad cells
 #pragma unroll
@@ -343,6 +349,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
         }
         cf_sync_lds_dma();          // E complete; the operand table (DMA) landed
         if (q + 1 < nq) stage_weights(q + 1);
+        asm volatile("" ::: "memory");        // later loads stay behind the DMA in program order (cf_sync_lds_dma_keep counts on it)
 
         // ---- phase 2: depthwise (matrix cores) + Swish + project
 #pragma unroll
@@ -558,16 +565,12 @@ __global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
         for (int mb = 0; mb < NMB; ++mb) pacc[i][mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     stage_weights(0);
+    asm volatile("" ::: "memory");
     for (int q = 0; q < nq; ++q) {
         const char* wx = Wst + (q & 1) * WXB;
-        cf_sync_lds_dma();    // previous round's depthwise done with E and the operand table; this round's expand weights landed
+        // this half's Toeplitz operands + project fragments (+ X fragments when reloaded): requested before the barrier, in flight across it
         u32x2 Ah[ALDS ? 1 : KS][KSTEPS];
-        if constexpr (ALDS) {
-            const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
-            for (int c = wave; c < G::ATB / 1024; c += NW)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
-        } else {
+        if constexpr (!ALDS) {
             const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + ((size_t)q * 2 + half) * NSTEP * 64 + lane;
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky)
@@ -579,6 +582,13 @@ __global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
         for (int mb = 0; mb < NMB; ++mb)
             wp4[mb] = *reinterpret_cast<const u32x2*>((const char*)p.wproj + ((((size_t)q * 2 + half) * NMB + mb) * 64 + lane) * 8);
         if constexpr (XRELOAD) load_x();
+        cf_sync_lds_dma_keep<(ALDS ? 0 : NSTEP) + NMB + (XRELOAD ? MAXI * JX : 0)>();   // previous round's depthwise done with E / the table; expand weights landed
+        if constexpr (ALDS) {
+            const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
+            for (int c = wave; c < G::ATB / 1024; c += NW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
+        }
 
         // ---- phase 1: expand + Swish -> quad cells
 #pragma unroll
@@ -607,6 +617,7 @@ __global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
         }
         cf_sync_lds_dma();          // E complete; the operand table landed
         if (q + 1 < nq) stage_weights(q + 1);
+        asm volatile("" ::: "memory");        // later loads stay behind the DMA in program order (cf_sync_lds_dma_keep counts on it)
 
         // ---- phase 2: this wave's (set, channel half): depthwise + Swish + project
         {

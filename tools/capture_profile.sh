@@ -37,7 +37,7 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAVES \
     --kernel-trace --output-format csv -d "$OUT/prof_inst" -o i -- \
     python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_inst.log" 2>&1
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM \
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM \
     --kernel-trace --output-format csv -d "$OUT/prof_sq" -o s -- \
     python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_sq.log" 2>&1
 timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS \
