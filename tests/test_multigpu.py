@@ -91,6 +91,32 @@ def test_bench_step_configs4_shard_two_contexts_one_communicator():
         e.close()
 
 
+def test_two_contexts_in_flight_are_deterministic():
+    """Two contexts running concurrently on one GPU (the benchmarked schedule) return, step after step, exactly what one context
+    returns alone.  Regression test for the LDS-DMA publication race (a wave passing the barrier before another wave's
+    `global_load_lds` had landed: rare stale expand weights, only when a second context competed for the chip)."""
+    import torch
+    B, S, K = 8, 640, 100
+    dev = torch.device("cuda", 0)
+    imgs = np.random.default_rng(21).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    d_in = torch.from_numpy(imgs).to(dev)
+    fmt = cfa._lib.CF_IN_U8_HWC_BGR
+    engs = [cfa.Engine(S, S, max_batch=B, dtype="bf16") for _ in range(2)]
+    engs[0].forward_enqueue(imgs)
+    want = engs[0].decode_topk(K)
+    outs = [[torch.empty((B, K, 6), dtype=torch.float32, device=dev), torch.empty((B, K, 10), dtype=torch.float32, device=dev),
+             torch.empty((B, K), dtype=torch.int64, device=dev)] for _ in engs]
+    for it in range(24):
+        e, o = engs[it % 2], outs[it % 2]
+        if it >= 2:                                          # the result this slot produced two steps ago
+            e.synchronize()
+            assert np.array_equal(o[0].cpu().numpy(), want[0]) and np.array_equal(o[2].cpu().numpy(), want[2]), it
+        e.forward_enqueue(d_in.data_ptr(), on_device=True, B=B, in_format=fmt)
+        e.decode_topk_device(K, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+    for e in engs:
+        e.close()
+
+
 def test_comm_create_all_grouped_and_abort():
     """cf_comm_create_all (the single-process host: n ncclCommInitRank calls inside one ncclGroupStart/End) at n = 1, its
     gather, and cf_comm_abort on a live communicator; two contexts on one device are refused (one rank per GPU)."""
