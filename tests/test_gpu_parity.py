@@ -847,6 +847,30 @@ def test_target_encoder_kernel_vs_reference_goldens(golden):
         np.testing.assert_allclose(t["hm"][b], r["hm"], rtol=2e-7, atol=1e-9)
 
 
+def test_target_encoder_kernel_vs_reference_getitem(golden):
+    """losses.to_output_map + cf_op_encode_targets against what the reference's own ``CenterFaceData.__getitem__`` returned
+    (tests/golden/train_getitem.npz, tools/gen_goldens_getitem.py): integer outputs and fp32 targets bit-exact, the Gaussian
+    heat map to 1 float32 ulp with identical peaks."""
+    from centerface_amd import losses
+    from test_oracle_vs_golden import _getitem_inputs
+    g = golden("train_getitem")
+    n = int(g["n_samples"])
+    bx = np.zeros((n, 128, 4), np.float32); lm = -np.ones((n, 128, 10), np.float32); cnt = np.zeros(n, np.int32)
+    for i in range(n):
+        w = int(g["s%d_size" % i][1])
+        boxes, lms = _getitem_inputs(g, i)
+        ob, ol = losses.to_output_map(boxes[:128], lms[:128], g["s%d_c" % i], float(g["s%d_s" % i]), 160, 160,
+                                      flipped=bool(g["s%d_flipped" % i]), width=w)
+        cnt[i] = len(ob); bx[i, :len(ob)] = ob; lm[i, :len(ob)] = ol
+    t = losses.encode_targets(bx, lm, cnt, 160, 160)
+    for i in range(n):
+        for k, gk in (("wh", "wh"), ("reg", "reg"), ("ind", "ind"), ("reg_mask", "reg_mask"), ("landmarks", "lm"),
+                      ("lm_ind", "lm_ind"), ("lm_mask", "lm_mask")):
+            assert np.array_equal(t[k][i], g["s%d_%s" % (i, gk)]), (i, k)
+        np.testing.assert_allclose(t["hm"][i], g["s%d_hm" % i], rtol=2e-7, atol=1e-9)
+        assert np.array_equal(t["hm"][i] == 1.0, g["s%d_hm" % i] == 1.0)
+
+
 def test_dataset_affine_and_rotated_transform_vs_oracle():
     """dataset/dataset.py:146,160-179 (boxes / landmarks -> output-map coordinates, incl. the flip) in front of the
     target encoder, and get_affine_transform with rotation and shift (utils/image.py:27-60), against the oracle's

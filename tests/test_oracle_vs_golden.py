@@ -190,6 +190,37 @@ def test_target_encoding_and_losses_match_reference(golden):
         np.testing.assert_allclose(O.ctdet_loss(out, batch), g["loss_" + name], rtol=1e-6, atol=1e-7)
 
 
+def _getitem_inputs(g, i):
+    """Raw WIDER-style annotation rows of sample i -> (boxes x1y1x2y2, landmarks or -1) as dataset.py:96-110 builds them."""
+    anns = g["s%d_anns" % i]
+    boxes = np.array([[a[0], a[1], a[0] + a[2], a[1] + a[3]] for a in anns], np.float32)
+    lms = -np.ones((len(anns), 10), np.float32)
+    for k, a in enumerate(anns):
+        if a[4] >= 0:
+            for j in range(5):
+                lms[k, 2 * j], lms[k, 2 * j + 1] = a[4 + 3 * j], a[5 + 3 * j]
+    return boxes, lms
+
+
+def test_target_encoding_matches_reference_getitem(golden):
+    """The oracle's dataset_to_output_map + encode_targets against the dict the reference's OWN
+    ``CenterFaceData.__getitem__`` returned (tools/gen_goldens_getitem.py drives the class itself, split = "train", seeded
+    random scale / centre / flip; tests/golden/train_getitem.npz) -- every target tensor bit-exact."""
+    g = golden("train_getitem")
+    total = 0
+    for i in range(int(g["n_samples"])):
+        h, w = (int(v) for v in g["s%d_size" % i])
+        boxes, lms = _getitem_inputs(g, i)
+        ob, ol = O.dataset_to_output_map(boxes[:128], lms[:128], g["s%d_c" % i], float(g["s%d_s" % i]), 160, 160,
+                                         flipped=bool(g["s%d_flipped" % i]), width=w)
+        t = O.encode_targets(ob, ol, 160, 160, 128)
+        for k, gk in (("hm", "hm"), ("wh", "wh"), ("reg", "reg"), ("ind", "ind"), ("reg_mask", "reg_mask"),
+                      ("landmarks", "lm"), ("lm_ind", "lm_ind"), ("lm_mask", "lm_mask")):
+            assert np.array_equal(t[k], g["s%d_%s" % (i, gk)]), (i, k)
+        total += int(t["reg_mask"].sum())
+    assert total > 50
+
+
 def test_reference_format_checkpoint_round_trip(tmp_path):
     """A checkpoint written the way the reference writes it (train.py:165: torch.save(model.state_dict()), an
     OrderedDict of tensors incl. the int64 num_batches_tracked buffers) loads through weights.load_checkpoint
