@@ -75,7 +75,23 @@ int main(int argc, char** argv) {
         for (int b = 0; b < world * B; ++b)
             if (rec[(size_t)b * K * 16 + 4] != dets[(size_t)b * K * 6 + 4]) { fprintf(stderr, "gathered record differs\n"); return 1; }
         printf("gathered %d x %d records over RCCL (world %d)\n", world * B, K, world);
+        /* a host with a deadline polls instead of blocking: 0 = every enqueued gather has completed */
+        if (cf_comm_query(comm) != 0) { fprintf(stderr, "gather still running after a blocking gather\n"); return 1; }
         CHECK(ctx, cf_comm_destroy(comm));
+        /* A single process / thread that owns one context per GPU creates all communicators in ONE grouped call
+         * (un-grouped, the first ncclCommInitRank would wait forever for the others); ONE communicator per rank, shared
+         * by all contexts of that rank.  Shown with n = 1; cf_comm_abort is the way out of a collective that hangs. */
+        {
+            cf_ctx* ctxs[1]; cf_comm* comms[1];
+            ctxs[0] = ctx;
+            CHECK(ctx, cf_comm_create_all(ctxs, 1, comms));
+            CHECK(ctx, cf_forward(ctx, img, CF_IN_U8_HWC_BGR, 0, B));
+            CHECK(ctx, cf_gather_topk(ctx, comms[0], K, 1, rec, 0));
+            for (int b = 0; b < B; ++b)
+                if (rec[(size_t)b * K * 16 + 4] != dets[(size_t)b * K * 6 + 4]) { fprintf(stderr, "gathered record differs (grouped)\n"); return 1; }
+            printf("grouped communicator: gathered %d x %d records\n", B, K);
+            CHECK(ctx, cf_comm_abort(comms[0]));
+        }
         free(rec);
     }
     CHECK(ctx, cf_destroy(ctx));

@@ -38,7 +38,8 @@ def test_c_example_matches_python_host(tmp_path):
     export_weights.export(wfile, cfa.weights.synthetic_state_dict(0))
     H, W, B = 64, 96, 2
     out = subprocess.run([exe, wfile, str(H), str(W), str(B), "gather"], check=True, capture_output=True, text=True).stdout.strip().splitlines()
-    assert out[-1].startswith("gathered %d x 10 records over RCCL" % B), out[-1]     # cf_comm_* / cf_gather_topk from plain C
+    assert out[-2].startswith("gathered %d x 10 records over RCCL" % B), out[-2]     # cf_comm_* / cf_gather_topk from plain C
+    assert out[-1].startswith("grouped communicator: gathered %d x 10 records" % B), out[-1]      # cf_comm_create_all / cf_comm_abort
     out = [l for l in out if l.startswith("image ")]                                    # (librccl prints its version banner on stdout)
     assert len(out) == B
     # the same bytes as detect.c's LCG
