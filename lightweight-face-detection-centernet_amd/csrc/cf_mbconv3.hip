@@ -204,6 +204,157 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
     }
 }
 
+// The same with the workgroup walking R rounds of its tile (grid.y = rounds / R): launch + first-DMA latency once per R rounds, the
+// next round's weights and operand table streaming into a second LDS stage under the current round's depthwise
+template <int KS, int JX, int TOH, int TOW, int NW, int R>
+__global__ __launch_bounds__(NW * 64) void expdw_mxr_kernel(MbParams p) {
+    constexpr bool ALDS = true;
+    typedef Mx<KS, JX, TOH, TOW, NW, true> G;
+    constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, CP = G::CP, NSET = G::NSET, WXB = G::WXB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* E = smem;
+    char* Wst = smem + G::EBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.Wout + TOW - 1) / TOW;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int ox0 = txi * TOW, oy0 = tyi * TOH, b = blockIdx.z;
+    const int grp = blockIdx.y;
+
+    // round r of this workgroup = hidden-channel round grp * R + r; expand weights and the operand table of round r + 1 are DMA'd
+    // into the other LDS stage while round r's depthwise runs
+    constexpr int STG = WXB + G::ATB;
+    auto stage = [&](int r) {
+        char* dst = Wst + (r & 1) * STG;
+        const char* srcx = (const char*)p.wexp + (size_t)(grp * R + r) * WXB;
+        for (int c = wave; c < WXB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+        const char* srca = (const char*)p.wdw + (size_t)(grp * R + r) * G::ATB;
+        for (int c = wave; c < G::ATB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + WXB + c * 1024), 16, 0, 0);
+        asm volatile("" ::: "memory");
+    };
+    stage(0);
+    asm volatile("" ::: "memory");
+    const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+    const unsigned rowbytes = (unsigned)p.Cin * 2;
+    auto load_x = [&](int ib, u32x4* xf) -> bool {
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < IPX ? ip : IPX - 1;
+        const int iy = ipc / IWP, ix = ipc - iy * IWP;
+        const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
+        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+        if (p.xblock) {
+            const char* xb = (const char*)p.x + blk_off(((size_t)b * p.Hin + cy) * p.Win + cx, p.Cin / 8, h * JX);
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xf[j] = ld16(xb + j * 512);
+        } else {
+            const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
+        }
+        return ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+    };
+    auto mask_x = [&](u32x4* xf, bool valid) {
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            xf[j].x = valid ? xf[j].x : 0u; xf[j].y = valid ? xf[j].y : 0u; xf[j].z = valid ? xf[j].z : 0u; xf[j].w = valid ? xf[j].w : 0u;
+        }
+    };
+    const int abl = 0;
+    static constexpr SetMap<TOH, TOW, IWQ> kSets{};
+    const int kg = lane >> 4;
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+    const char* Wr = Wst + (r & 1) * STG;
+    const char* Ats = Wr + WXB;
+    u32x4 xa[JX];
+    bool va = false;
+    if (wave < NIB) va = load_x(wave, xa);
+    static_assert(NIB >= NW, "every wave issues the X loads the wait below keeps in flight");
+    cf_sync_lds_dma_keep<JX>();      // previous round's depthwise done with E; this round's weights / table (DMA, issued earlier) landed
+    mask_x(xa, va);
+
+    // ---- phase 1: expand + Swish -> quad cells.  D rows (r & 3) + 8 (r >> 2) + 4 h: register quad t = halo quad ib*8 + 2t + h
+    for (int ib = wave; ib < NIB; ib += NW) {
+        u32x4 xn[JX];
+        const bool more = ib + NW < NIB;
+        bool vn = false;
+        if (more) { if (abl & 8) { for (int j = 0; j < JX; ++j) xn[j] = xa[j]; vn = va; } else vn = load_x(ib + NW, xn); }
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+        const char* wb = Wr + lane * 16;
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const u32x4 wv = ld16(wb + j * 1024);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xa[j]),
+                                                        __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
+        }
+        char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)CP + pl * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x2 u0, u1; u0.x = a[4 * t]; u0.y = a[4 * t + 1]; u1.x = a[4 * t + 2]; u1.y = a[4 * t + 3];
+            f32x2 y0 = u0, y1 = u1;
+            if (!(abl & 4)) { y0 = swish2_pre(u0); y1 = swish2_pre(u1); }
+            u32x2 d;
+            d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+            d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+            *reinterpret_cast<u32x2*>(ecell + 2 * t * CP) = d;
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xa[j] = xn[j];
+            mask_x(xa, vn);
+        }
+    }
+    __syncthreads();
+    if (r + 1 < R) stage(r + 1);
+
+    // ---- phase 2: depthwise on the matrix cores + Swish, 16 output quads x 32 channels per wave step
+    for (int set = wave; set < NSET; set += NW) {
+        const uint32_t e = kSets.v[set * 16 + (lane & 15)];
+        const int oy = (e >> 6) & 0x1ff, oxq = e & 63;
+        const bool live = (e & 0x8000u) == 0;
+        f32x4 acc[8];
+        const char* bb = E + (unsigned)(oy * IWQ + oxq) * (unsigned)CP + kg * 64;
+        if (abl & 1) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) acc[g] = f32x4{(float)oy, (float)oxq, (float)g, 1.0f};
+        } else {
+        mx_depthwise_lds<KS, IWQ, CP>(bb, Ats + lane * 8, acc);
+        }
+        // a = -log2(e) * depthwise output -> Swish, leftover factor out again (the project GEMM has plain weights)
+        if (!(abl & 2))
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+                const f32x2 y = swish2_pre(u) * kNegLn23;
+                acc[g][i] = y.x; acc[g][i + 1] = y.y;
+            }
+        const int gy = oy0 + oy, gx0 = ox0 + 4 * oxq;
+        if (!live || gy >= p.Hout || ((abl & 16) && acc[0][0] != 123.0f)) continue;
+        const size_t opix0 = ((size_t)b * p.Hout + gy) * p.Wout + gx0;
+        const int chunk = (grp * R + r) * 4 + kg;                     // 8-channel chunk of the depthwise tensor
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (gx0 + i >= p.Wout) break;
+            u32x4 o;
+            o.x = packb(acc[0][i], acc[1][i]); o.y = packb(acc[2][i], acc[3][i]);
+            o.z = packb(acc[4][i], acc[5][i]); o.w = packb(acc[6][i], acc[7][i]);
+            const size_t opix = opix0 + i;
+            st16((char*)p.y + (p.yblock ? blk_off(opix, p.hid / 8, chunk) : (opix * p.hid + (size_t)chunk * 8) * 2), o);
+        }
+    }
+    }
+}
+
 // ================================================================== fully fused block: expand -> depthwise -> project (+residual)
 // One workgroup per output tile; the hidden channels go through the tile in rounds of 32 (+ an optional last round of 16:
 // hid = 144): expand the halo for the round -> quad cells in LDS -> matrix-core depthwise -> Swish -> the lane's eight (four)
@@ -773,6 +924,26 @@ static hipError_t xmx_launch_t(hipStream_t s, const MbParams& p) {
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, q);
     return hipGetLastError();
 }
+template <int KS, int JX, int TOH, int TOW, int NW, int R>
+static hipError_t xmxr_launch_t(hipStream_t s, const MbParams& p) {
+    typedef Mx<KS, JX, TOH, TOW, NW, true> G;
+    constexpr int LDS = G::EBYTES + 2 * (G::WXB + G::ATB);
+    auto kfn = expdw_mxr_kernel<KS, JX, TOH, TOW, NW, R>;
+    static thread_local bool configured_dev[32] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool& configured = configured_dev[dev & 31];
+    if (LDS > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    if ((p.hid / 32) % R) return hipErrorInvalidValue;
+    dim3 grid(((p.Wout + TOW - 1) / TOW) * ((p.Hout + TOH - 1) / TOH), p.hid / 32 / R, p.B), blk(NW * 64);
+    set_kernel_tag("void cf::expdw_mxr_kernel<%d, %d, %d, %d, %d, %d>(cf::MbParams)", KS, JX, TOH, TOW, NW, R);
+    hipLaunchKernelGGL(kfn, grid, blk, LDS, s, p);
+    return hipGetLastError();
+}
+#define XMR(V, KS, JX, TOH, TOW, NW, R) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, true>::EBYTES + 2 * (Mx<KS, JX, TOH, TOW, NW, true>::WXB + Mx<KS, JX, TOH, TOW, NW, true>::ATB), &xmxr_launch_t<KS, JX, TOH, TOW, NW, R>}
 #define XMX(V, KS, JX, TOH, TOW, NW, AL) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, (AL != 0)>::LDS, &xmx_launch_t<KS, JX, TOH, TOW, NW, (AL != 0)>}
 static const MxEntry kXmxTable[] = {
     //  var KS JX  tile   waves  A in LDS          (B = 64, 640x640, HIP events; expdw_px_kernel of the layer in brackets)
@@ -795,8 +966,22 @@ static const MxEntry kXmxTable[] = {
     XMX(3, 3, 10, 20, 20, 4, 0),
     XMX(4, 5, 4, 20, 40, 7, 0),
     XMX(4, 5, 6, 20, 40, 7, 0),
+    // rounds-persistent workgroups (expdw_mxr_kernel)
+    XMR(5, 5, 4, 10, 40, 8, 6),      // 4.0: 12 rounds -> 2 per tile
+    XMR(5, 5, 6, 10, 40, 8, 9),      // 4.1: 18 rounds -> 2 per tile
+    XMR(5, 5, 10, 10, 20, 4, 5),     // 5.1: 30 rounds
+    XMR(5, 3, 10, 10, 20, 4, 5),     // 6.0
+    XMR(6, 5, 4, 10, 40, 8, 3),
+    XMR(6, 5, 6, 10, 40, 8, 3),
+    XMR(6, 5, 10, 20, 20, 4, 3),
+    XMR(6, 3, 10, 20, 20, 4, 3),
+    XMR(7, 5, 4, 10, 40, 4, 4),
+    XMR(7, 5, 6, 10, 40, 4, 6),
+    XMR(7, 5, 10, 20, 20, 4, 6),
+    XMR(7, 3, 10, 20, 20, 4, 6),
 };
 #undef XMX
+#undef XMR
 static const MxEntry* xmx_find(int k, int jx) {
     static const int want = getenv("CF_MX_VARIANT") ? atoi(getenv("CF_MX_VARIANT")) : 0;
     const MxEntry* base = nullptr;
