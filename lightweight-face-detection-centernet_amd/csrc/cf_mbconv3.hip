@@ -1220,7 +1220,7 @@ static const FsEntry kFsTable[] = {
     //  var KS JX NMB tail  tile  X reload  A in LDS       (B = 64, 640x640, HIP events; cf_mbconv2.hip kernel of the layer in brackets)
     FSE(0, 5, 2, 2, 1, 8, 16, 0, 0),      // 2.0  24 -> 144 -> 32, 160x160 -> 80x80, four rounds of 32 + one of 16: 0.150 ms [0.177]
     // layer1.0 (16 -> 96 -> 24, 3x3, 320x320 -> 160x160) stays on cf_mbconv2.hip: its depthwise is 4 % of the block's work and
-    // 25 600 small workgroups pay the operand-table fetch three times each: 0.264 ms here (0.327 with the table in LDS) vs 0.246
+    // 12 800 small workgroups pay the operand-table fetch three times each: 0.264 ms here (0.327 with the table in LDS) vs 0.246
     FSE(1, 3, 1, 2, 0, 8, 16, 0, 0),
     FSE(1, 5, 2, 2, 1, 8, 16, 0, 1),
     FSE(2, 3, 1, 2, 0, 8, 16, 0, 1),
