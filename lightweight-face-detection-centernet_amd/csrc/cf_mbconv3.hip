@@ -377,7 +377,7 @@ struct Fx {
     static_assert(!TAIL16 || JX <= 2, "16-channel round: one 16x16x32 expand MFMA, Cin <= 32");
 };
 
-template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16, bool XRELOAD, bool ALDS>
+template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16, bool XRELOAD, bool ALDS, bool SB = false>
 __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
     typedef Fx<KS, JX, NMB, TOH, TOW, NW, TAIL16, ALDS> G;
     constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, MAXI = G::MAXI, CP8 = G::CP8, CP4 = G::CP4;
@@ -506,7 +506,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
 #pragma unroll
         for (int sw = 0; sw < SPW; ++sw) {
             f32x4 acc[8];
-            if constexpr (ALDS) mx_depthwise_lds<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, Ats + lane * 8, acc);
+            if constexpr (ALDS && SB) mx_depthwise_lds1<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, Ats + lane * 8, acc);
+            else if constexpr (ALDS) mx_depthwise_lds<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, Ats + lane * 8, acc);
             else mx_depthwise<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, reinterpret_cast<const u32x2 (*)[KS][2]>(A), acc);
 #pragma unroll
             for (int g = 0; g < 8; ++g)
@@ -1061,10 +1062,10 @@ struct FxEntry {
     int k, jx, nmb, res, tail, toh, tow, nw, var, lds_bytes;
     hipError_t (*fn)(hipStream_t, const MbParams&);
 };
-template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16, bool XRELOAD, bool ALDS>
+template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16, bool XRELOAD, bool ALDS, bool SB = false>
 static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
     typedef Fx<KS, JX, NMB, TOH, TOW, NW, TAIL16, ALDS> G;
-    auto kfn = mbconv_mx_kernel<KS, JX, NMB, RESID, TOH, TOW, NW, TAIL16, XRELOAD, ALDS>;
+    auto kfn = mbconv_mx_kernel<KS, JX, NMB, RESID, TOH, TOW, NW, TAIL16, XRELOAD, ALDS, SB>;
     static thread_local bool configured_dev[32] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     bool& configured = configured_dev[dev & 31];
@@ -1074,7 +1075,8 @@ static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
         configured = true;
     }
     dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
-    set_kernel_tag("void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false",
+    set_kernel_tag(SB ? "void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s, true>(cf::MbParams)"
+                      : "void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false",
                    TOH, TOW, NW, TAIL16 ? "true" : "false", XRELOAD ? "true" : "false", ALDS ? "true" : "false");
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
     return hipGetLastError();
@@ -1096,6 +1098,11 @@ static const FxEntry kFxTable[] = {
     FXE(3, 3, 2, 2, 1, 1, 32, 16, 4, 1, 1),
     FXE(1, 3, 4, 4, 1, 0, 16, 16, 4, 1, 1),
     FXE(2, 3, 4, 4, 1, 0, 8, 40, 5, 1, 1),
+    // wide tiles, eight waves, single-buffered operand reads (<= 128 VGPRs: four waves per SIMD)
+    {3, 2, 2, 1, 1, 16, 32, 8, 4, Fx<3, 2, 2, 16, 32, 8, true, true>::LDS, &fx_launch_t<3, 2, 2, true, 16, 32, 8, true, true, true, true>},
+    {5, 2, 2, 1, 0, 16, 32, 8, 4, Fx<5, 2, 2, 16, 32, 8, false, true>::LDS, &fx_launch_t<5, 2, 2, true, 16, 32, 8, false, true, true, true>},
+    {3, 2, 2, 1, 1, 16, 16, 4, 5, Fx<3, 2, 2, 16, 16, 4, true, true>::LDS, &fx_launch_t<3, 2, 2, true, 16, 16, 4, true, true, true, true>},
+    {5, 2, 2, 1, 0, 16, 16, 4, 5, Fx<5, 2, 2, 16, 16, 4, false, true>::LDS, &fx_launch_t<5, 2, 2, true, 16, 16, 4, false, true, true, true>},
 };
 #undef FXE
 static const FxEntry* fx_find(int k, int jx, int nmb, int res, int tail) {

@@ -157,6 +157,40 @@ __device__ __forceinline__ void mx_depthwise_lds(const char* bb, const char* at 
     }
 }
 
+// single-buffered form (16 VGPRs less): the reads of a step are issued and consumed in place; for kernels that run four waves per
+// SIMD, where the other waves cover the LDS latency
+template <int KS, int IWQ, int CP>
+__device__ __forceinline__ void mx_depthwise_lds1(const char* bb, const char* at, f32x4* acc) {
+    constexpr int NSTEP = KS * 2;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        const int ky = st >> 1, ks = st & 1;
+        u32x4 bq[4];
+#pragma unroll
+        for (int g2 = 0; g2 < 4; ++g2) bq[g2] = ld16(bb + (ky * IWQ + ks) * CP + g2 * 16);
+        u32x2 aq[2];
+        aq[0] = *reinterpret_cast<const u32x2*>(at + st * 512);
+        aq[1] = *reinterpret_cast<const u32x2*>(at + (NSTEP + st) * 512);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, aq[g >> 2]);
+            u32x2 b2;
+            b2.x = (g & 1) ? bq[g >> 1].z : bq[g >> 1].x;
+            b2.y = (g & 1) ? bq[g >> 1].w : bq[g >> 1].y;
+            const mfma_f16x4 bv = __builtin_bit_cast(mfma_f16x4, b2);
+            switch (g & 3) {
+                case 0: CF_MX_MFMA(acc[g], av, bv, 0); break;
+                case 1: CF_MX_MFMA(acc[g], av, bv, 1); break;
+                case 2: CF_MX_MFMA(acc[g], av, bv, 2); break;
+                default: CF_MX_MFMA(acc[g], av, bv, 3); break;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Half a set's channels (g = 4 half .. 4 half + 3: 32 contiguous bytes of a cell row) for the stride-2 blocks, where a wave is
 // (set, channel half); KSTEPS k-steps per kernel row (stride 2: inputs x .. x + 10 of an output quad = three quads); the Toeplitz
 // operand table in LDS is [2 channel quads][KS][KSTEPS][64 lanes] x 8 B, `at` points at this half's quad + lane * 8
