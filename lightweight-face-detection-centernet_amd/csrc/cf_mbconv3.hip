@@ -119,7 +119,11 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
             xf[j].x = valid ? xf[j].x : 0u; xf[j].y = valid ? xf[j].y : 0u; xf[j].z = valid ? xf[j].z : 0u; xf[j].w = valid ? xf[j].w : 0u;
         }
     };
-    const int abl = p.nw;            // timing experiments only (CF_MX_ABL): 1 no depthwise MFMAs, 2 no output Swish, 4 no expand Swish, 8 one X load, 16 no stores
+#ifdef CF_ABLATION
+    const int abl = p.nw;            // timing experiments only (-DCF_ABLATION, CF_MX_ABL): 1 no depthwise MFMAs, 2 no output Swish, 4 no expand Swish, 8 one X load, 16 no stores
+#else
+    constexpr int abl = 0;           // (the run-time tests cost the production kernel 4-7 %: compiled out)
+#endif
     u32x4 xa[JX];
     bool va = false;
     if (wave < NIB) va = load_x(wave, xa);
@@ -392,6 +396,11 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
     const int pl = lane & 31, h = lane >> 5, kg = lane >> 4;
     const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH, b = blockIdx.z;
     const int nq = p.nq;                                            // full rounds of 32 hidden channels
+#ifdef CF_ABLATION
+    const int abl = p.nw;      // timing experiments only (-DCF_ABLATION, CF_FX_ABL): 1 no depthwise MFMAs, 2 no output Swish, 4 no expand Swish, 8 no project MFMAs, 16 no stores
+#else
+    constexpr int abl = 0;     // (the run-time tests cost the production kernel 3-4 %: compiled out)
+#endif
 
     const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
     const unsigned rowbytes = (unsigned)p.Cin * 2;
@@ -466,12 +475,15 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
         for (int mb = 0; mb < NMB; ++mb) wpc[mb] = ld16((const char*)p.wproj + (((size_t)q * NMB + mb) * 64 + lane) * 16);
         if constexpr (XRELOAD) load_x();
         cf_sync_lds_dma_keep<(ALDS ? 0 : 2 * KS * 2) + NMB + (XRELOAD ? MAXI * JX : 0)>();   // previous round's depthwise done with E / the table; expand weights landed
-        if constexpr (ALDS) {      // this round's Toeplitz table -> LDS under the expand phase (drained before the next barrier)
+        // this round's Toeplitz table -> LDS under the expand phase (drained before the next barrier).  Staging it one round
+        // ahead in a second buffer was measured: no gain (0.192 vs 0.189 ms on layer1.1), 6-10 KB more LDS
+        if constexpr (ALDS) {
             const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
             for (int c = wave; c < G::ATB / 1024; c += NW)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
                                                  (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
         }
+        const char* Atq = Ats;
 
         // ---- phase 1: expand + Swish -> quad cells
 #pragma unroll
@@ -491,7 +503,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
 #pragma unroll
             for (int tq = 0; tq < 4; ++tq) {
                 f32x2 u0, u1; u0.x = a[4 * tq]; u0.y = a[4 * tq + 1]; u1.x = a[4 * tq + 2]; u1.y = a[4 * tq + 3];
-                const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+                f32x2 y0 = u0, y1 = u1;
+                if (!(abl & 4)) { y0 = swish2_pre(u0); y1 = swish2_pre(u1); }
                 u32x2 d;
                 d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
                 d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
@@ -506,9 +519,15 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
 #pragma unroll
         for (int sw = 0; sw < SPW; ++sw) {
             f32x4 acc[8];
-            if constexpr (ALDS && SB) mx_depthwise_lds1<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, Ats + lane * 8, acc);
-            else if constexpr (ALDS) mx_depthwise_lds<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, Ats + lane * 8, acc);
+            if (abl & 1) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) acc[g] = f32x4{(float)q, (float)g, 1.0f, 2.0f};
+            } else {
+            if constexpr (ALDS && SB) mx_depthwise_lds1<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, Atq + lane * 8, acc);
+            else if constexpr (ALDS) mx_depthwise_lds<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, Atq + lane * 8, acc);
             else mx_depthwise<KS, IWQ, CP8>(E + qcell[sw] * (unsigned)CP8 + kg * 64, reinterpret_cast<const u32x2 (*)[KS][2]>(A), acc);
+            }
+            if (!(abl & 2))
 #pragma unroll
             for (int g = 0; g < 8; ++g)
 #pragma unroll
@@ -522,6 +541,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
                 u32x4 d;
                 d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
                 d.z = packb(acc[4][i], acc[5][i]); d.w = packb(acc[6][i], acc[7][i]);
+                if (abl & 8) { pacc[sw][i][0][0] += __uint_as_float(d.x ^ d.y ^ d.z ^ d.w); continue; }
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb)
                     pacc[sw][i][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wpc[mb]),
@@ -609,7 +629,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
         const uint32_t e = kSets.v[(wave * SPW + sw) * 16 + (lane & 15)];
         const int oy = (e >> 6) & 0x1ff, oxq = e & 63;
         const int gy = oy0 + oy, gx0 = ox0 + 4 * oxq;
-        if ((e & 0x8000u) || gy >= p.Hout) continue;
+        if ((e & 0x8000u) || gy >= p.Hout || ((abl & 16) && pacc[sw][0][0][0] != 123.0f)) continue;
         const size_t opix0 = ((size_t)b * p.Hout + gy) * p.Wout + gx0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1075,10 +1095,12 @@ static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
         configured = true;
     }
     dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
+    static const int abl = getenv("CF_FX_ABL") ? atoi(getenv("CF_FX_ABL")) : 0;      // timing experiments only: results invalid
+    MbParams q = p; q.nw = abl;
     set_kernel_tag(SB ? "void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s, true>(cf::MbParams)"
                       : "void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false",
                    TOH, TOW, NW, TAIL16 ? "true" : "false", XRELOAD ? "true" : "false", ALDS ? "true" : "false");
-    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
+    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, q);
     return hipGetLastError();
 }
 #define FXE(V, KS, JX, NMB, RES, TAIL, TOH, TOW, NW, XR, AL) \
