@@ -654,6 +654,281 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
     }
 }
 
+// ================================================================== fused block with ROLE-SPECIALISED waves (stride 1)
+// mbconv_mx_kernel alternates a transcendental-bound phase (expand + Swish) and a matrix-pipe-bound one (depthwise) behind
+// barriers: a 4x4x4 MFMA costs ~13 cycles of SIMD time there instead of the ~4.5 it costs beside dense VALU work (ablation in
+// profiles/r03_mfma_depthwise.md).  Here a workgroup has eight waves in two roles on a DOUBLE-BUFFERED tile: waves 0-3 expand
+// round q + 1 into E[(q + 1) & 1] while waves 4-7 run depthwise + Swish + project of round q from E[q & 1]; every SIMD then
+// always holds one wave issuing transcendentals and one feeding the matrix pipe.  One barrier per round.  The roles share one
+// register array (X fragments / project accumulators) so that two workgroups fit a CU.
+// MEASURED SLOWER than mbconv_mx_kernel (layer1.1 0.204 vs 0.181 ms, layer2.1 0.084 vs 0.082; 0.286 / 0.112 with one workgroup per
+// CU): three independent workgroups per SIMD already interleave the two phases, and the pipeline's fill and drain steps idle one
+// role.  Kept as CF_FX_VARIANT=6 (parity green), not in the default table.
+template <int KS, int JX, int NMB, int TOH, int TOW, bool TAIL16>
+struct Fz {
+    static constexpr int NR = 4;                                    // waves per role
+    static constexpr int IH = TOH + KS - 1, IWQ = TOW / 4 + 1, IWP = IWQ * 4;
+    static constexpr int NQD = IH * IWQ, NIB = (NQD + 7) / 8, IPX = NQD * 4, MAXI = (NIB + NR - 1) / NR;
+    static constexpr int CP8 = 32 * 8 + 16, CP4 = 16 * 8 + 16;
+    static constexpr int EBYTES = NIB * 8 * CP8;
+    static constexpr int NOQ = TOH * (TOW / 4), NSET = (NOQ + 15) / 16;
+    static constexpr int WXB = JX * 1024, ATB = 2 * KS * 2 * 512;
+    static constexpr int LDS = 2 * EBYTES + 2 * WXB + 2 * ATB;
+    static_assert(NSET == NR && TOW % 4 == 0 && KS <= 5 && (NMB == 2 || NMB == 4), "one set per depthwise wave");
+    static_assert(!TAIL16 || JX <= 2, "16-channel round: one 16x16x32 expand MFMA, Cin <= 32");
+};
+
+template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, bool TAIL16>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void mbconv_mxs_kernel(MbParams p) {
+    typedef Fz<KS, JX, NMB, TOH, TOW, TAIL16> G;
+    constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, MAXI = G::MAXI, CP8 = G::CP8, CP4 = G::CP4;
+    constexpr int WXB = G::WXB, NR = G::NR;
+    typedef __attribute__((ext_vector_type(4))) __bf16 mfma_bf16x4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Wst = smem + 2 * G::EBYTES;
+    char* Ats = Wst + 2 * WXB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave8 >> 2, wave = wave8 & 3;                  // role 0: expand, role 1: depthwise + project
+    const int pl = lane & 31, h = lane >> 5, kg = lane >> 4;
+    const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH, b = blockIdx.z;
+    const int nq = p.nq;
+    const int nrounds = nq + (TAIL16 ? 1 : 0);
+
+    const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+    const unsigned rowbytes = (unsigned)p.Cin * 2;
+
+    // ---- expand role state: X fragments of this wave's halo pixel blocks
+    static_assert(MAXI * JX <= 4 * NMB, "the two roles share one register array");
+    u32x4 st[4 * NMB];                                               // role 0: X fragments; role 1: project accumulators
+#define xf(t, j) st[(t) * JX + (j)]
+#define pacc(i, mb) (*reinterpret_cast<f32x4*>(&st[(i) * NMB + (mb)]))
+    if (role == 0) {
+#pragma unroll
+        for (int t = 0; t < MAXI; ++t) {
+            const int ib = wave + NR * t;
+            const int ip = ib * 32 + pl;
+            const int ipc = ip < IPX ? ip : IPX - 1;
+            const int iy = ipc / IWP, ix = ipc - iy * IWP;
+            const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
+            const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+            const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+            const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
+#pragma unroll
+            for (int j = 0; j < JX; ++j) {
+                const u32x4 v = ld16(xbase + off + j * 16);
+                xf(t, j).x = valid ? v.x : 0u; xf(t, j).y = valid ? v.y : 0u;
+                xf(t, j).z = valid ? v.z : 0u; xf(t, j).w = valid ? v.w : 0u;
+            }
+        }
+    }
+    auto stage_w = [&](int q) {                 // expand role: expand weights of round q -> stage q & 1
+        char* dst = Wst + (q & 1) * WXB;
+        const char* srcx = (const char*)p.wexp + (size_t)q * WXB;
+        for (int c = wave; c < WXB / 1024; c += NR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+    };
+    auto stage_a = [&](int q) {                 // depthwise role: Toeplitz table of round q -> stage q & 1
+        char* dst = Ats + (q & 1) * G::ATB;
+        const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
+        for (int c = wave; c < G::ATB / 1024; c += NR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+    };
+    auto expand_round = [&](int q) {            // full round q (32 channels) -> E[q & 1]
+        char* E = smem + (q & 1) * G::EBYTES;
+        const char* wx = Wst + (q & 1) * WXB;
+#pragma unroll
+        for (int t = 0; t < MAXI; ++t) {
+            const int ib = wave + NR * t;
+            if (ib >= NIB) break;
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < JX; ++j) {
+                const u32x4 wv = ld16(wx + (j * 64 + lane) * 16);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xf(t, j)),
+                                                            __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
+            }
+            char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)CP8 + pl * 8;
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                f32x2 u0, u1; u0.x = a[4 * tq]; u0.y = a[4 * tq + 1]; u1.x = a[4 * tq + 2]; u1.y = a[4 * tq + 3];
+                const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+                u32x2 d;
+                d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+                d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+                *reinterpret_cast<u32x2*>(ecell + 2 * tq * CP8) = d;
+            }
+        }
+    };
+    auto expand_tail = [&]() {                  // last round: 16 channels on 16x16x32 MFMAs -> E[nq & 1], cell row 144 B
+        char* E = smem + (nq & 1) * G::EBYTES;
+        const u32x4 wv = ld16((const char*)p.wexp + (size_t)nq * WXB + lane * 16);
+        for (int sb = wave; sb < NIB * 2; sb += NR) {
+            const int ip = sb * 16 + (lane & 15), kc = lane >> 4;
+            const int ipc = ip < IPX ? ip : IPX - 1;
+            const int iy = ipc / IWP, ix = ipc - iy * IWP;
+            const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
+            const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win && kc * 8 < p.Cin;
+            const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+            u32x4 xv = ld16(xbase + ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(min(kc * 8, p.Cin - 8) * 2));
+            xv.x = valid ? xv.x : 0u; xv.y = valid ? xv.y : 0u; xv.z = valid ? xv.z : 0u; xv.w = valid ? xv.w : 0u;
+            f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, xv), __builtin_bit_cast(mfma_bf16x8, wv), a4, 0, 0, 0);
+            f32x2 u0, u1; u0.x = a4[0]; u0.y = a4[1]; u1.x = a4[2]; u1.y = a4[3];
+            const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+            u32x2 d;
+            d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+            d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+            *reinterpret_cast<u32x2*>(E + (unsigned)(sb * 4 + kc) * (unsigned)CP4 + (lane & 15) * 8) = d;
+        }
+    };
+
+    // ---- depthwise role state: this wave's output quads (one set) and its project accumulators
+    static constexpr SetMap<TOH, TOW, IWQ> kSets{};
+    const uint32_t se = kSets.v[wave * 16 + (lane & 15)];
+    const unsigned qcell = ((se >> 6) & 0x1ff) * IWQ + (se & 63);
+    if (role == 1) {
+#pragma unroll
+        for (int i = 0; i < 4 * NMB; ++i) st[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    u32x4 wpc[NMB];
+    auto load_wp = [&](int q) {
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) wpc[mb] = ld16((const char*)p.wproj + (((size_t)q * NMB + mb) * 64 + lane) * 16);
+    };
+    auto dw_round = [&](int q) {                // depthwise + Swish + project of full round q from E[q & 1]
+        const char* E = smem + (q & 1) * G::EBYTES;
+        f32x4 acc[8];
+        mx_depthwise_lds1<KS, IWQ, CP8>(E + qcell * (unsigned)CP8 + kg * 64, Ats + (q & 1) * G::ATB + lane * 8, acc);
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+                const f32x2 y = swish2_pre(u);
+                acc[g][i] = y.x; acc[g][i + 1] = y.y;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 d;
+            d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
+            d.z = packb(acc[4][i], acc[5][i]); d.w = packb(acc[6][i], acc[7][i]);
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb)
+                st[i * NMB + mb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wpc[mb]), __builtin_bit_cast(mfma_bf16x8, d),
+                                                                                         __builtin_bit_cast(f32x4, st[i * NMB + mb]), 0, 0, 0));
+        }
+    };
+    auto dw_tail = [&]() {                      // the 16-channel round from E[nq & 1] (cell row 144 B)
+        const char* E = smem + (nq & 1) * G::EBYTES;
+        u32x2 A4[KS][2];
+        {
+            const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)nq * (2 * KS * 2) * 64 + lane;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) A4[ky][ks] = at[(ky * 2 + ks) * 64];
+        }
+        u32x2 wp4[NMB];
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+            wp4[mb] = *reinterpret_cast<const u32x2*>((const char*)p.wproj + (size_t)nq * NMB * 1024 + ((size_t)mb * 64 + lane) * 8);
+        const char* bb = E + qcell * (unsigned)CP4 + kg * 32;
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int st = 0; st < KS * 2; ++st) {
+            const char* bs = bb + ((st >> 1) * IWQ + (st & 1)) * CP4;
+            const u32x4 b0 = ld16(bs), b1 = ld16(bs + 16);
+            const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, A4[st >> 1][st & 1]);
+            u32x2 t0, t1, t2, t3; t0.x = b0.x; t0.y = b0.y; t1.x = b0.z; t1.y = b0.w; t2.x = b1.x; t2.y = b1.y; t3.x = b1.z; t3.y = b1.w;
+            CF_MX_MFMA(acc[0], av, __builtin_bit_cast(mfma_f16x4, t0), 0);
+            CF_MX_MFMA(acc[1], av, __builtin_bit_cast(mfma_f16x4, t1), 1);
+            CF_MX_MFMA(acc[2], av, __builtin_bit_cast(mfma_f16x4, t2), 2);
+            CF_MX_MFMA(acc[3], av, __builtin_bit_cast(mfma_f16x4, t3), 3);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+                const f32x2 y = swish2_pre(u);
+                acc[g][i] = y.x; acc[g][i + 1] = y.y;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 d; d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb)
+                st[i * NMB + mb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mfma_bf16x4, wp4[mb]), __builtin_bit_cast(mfma_bf16x4, d),
+                                                                                           __builtin_bit_cast(f32x4, st[i * NMB + mb]), 0, 0, 0));
+        }
+    };
+
+    // ---- pipeline: round r is expanded during step r - 1 (step -1 = the prologue) and consumed during step r
+    if (role == 0) stage_w(0); else { stage_a(0); load_wp(0); }
+    cf_sync_lds_dma();                                               // W(0), A(0) landed
+    if (role == 0) {
+        expand_round(0);                                             // nq >= 1 always
+        if (nq > 1) stage_w(1);
+    }
+    cf_sync_lds_dma();                                               // E[0] complete, W(1) landed
+    for (int r = 0; r < nrounds; ++r) {
+        if (role == 0) {
+            if (r + 1 < nq) {
+                expand_round(r + 1);
+                if (r + 2 < nq) stage_w(r + 2);                      // stage (r + 2) & 1 = r & 1: last read by expand_round(r), one step ago
+            } else if (TAIL16 && r + 1 == nq) {
+                expand_tail();
+            }
+        } else {
+            if (r < nq) {
+                if (r + 1 < nq) stage_a(r + 1);                      // stage (r + 1) & 1: last read by dw_round(r - 1), one step ago
+                dw_round(r);
+                if (r + 1 < nq) load_wp(r + 1);
+            } else {
+                dw_tail();
+            }
+        }
+        if (r + 1 < nrounds) cf_sync_lds_dma();                      // E[(r + 1) & 1] complete and E[r & 1] free; DMAs landed
+    }
+    if (role == 0) return;
+
+    // ---- epilogue (depthwise role): lane (kq = lane >> 4, quad slot): channels 8 kq .. + 7 (+ 32) of the four pixels of its quad
+    const int oy = (se >> 6) & 0x1ff, oxq = se & 63;
+    const int gy = oy0 + oy, gx0 = ox0 + 4 * oxq;
+    if ((se & 0x8000u) || gy >= p.Hout) return;
+    const size_t opix0 = ((size_t)b * p.Hout + gy) * p.Wout + gx0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (gx0 + i >= p.Wout) break;
+        const size_t opix = opix0 + i;
+#pragma unroll
+        for (int mp = 0; mp < NMB / 2; ++mp) {
+            const int ch = mp * 32 + kg * 8;
+            if (ch >= p.Cout) break;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = __builtin_bit_cast(f32x4, st[i * NMB + 2 * mp])[r]; v[4 + r] = __builtin_bit_cast(f32x4, st[i * NMB + 2 * mp + 1])[r]; }
+            if constexpr (RESID) {
+                float rr[8];
+                unpack16<bf16_t>(ld16((const char*)p.x + (opix * p.Cin + ch) * 2), rr);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = rr[r] + v[r];
+            }
+            st16((char*)p.y + (p.yblock ? blk_off(opix, p.Cout / 8, ch / 8) : (opix * p.Cout + ch) * 2), pack16b(v));
+        }
+    }
+}
+#undef xf
+#undef pacc
+
 // ================================================================== fully fused block, stride 2 (layer1.0, layer2.0)
 // The input halo of a stride-2 tile is four times the output tile, so the LDS budget allows 32 output quads = two sets per
 // workgroup.  Four waves = (set, channel half): every wave runs the depthwise of ITS four channels per group (4 x KS x 3
@@ -1103,6 +1378,24 @@ static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, q);
     return hipGetLastError();
 }
+template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, bool TAIL16>
+static hipError_t fz_launch_t(hipStream_t s, const MbParams& p) {
+    typedef Fz<KS, JX, NMB, TOH, TOW, TAIL16> G;
+    auto kfn = mbconv_mxs_kernel<KS, JX, NMB, RESID, TOH, TOW, TAIL16>;
+    static thread_local bool configured_dev[32] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool& configured = configured_dev[dev & 31];
+    if (G::LDS > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(512);
+    set_kernel_tag("void cf::mbconv_mxs_kernel<%d, %d, %d, %s, %d, %d, %s>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false", TOH, TOW,
+                   TAIL16 ? "true" : "false");
+    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
+    return hipGetLastError();
+}
 #define FXE(V, KS, JX, NMB, RES, TAIL, TOH, TOW, NW, XR, AL) \
     {KS, JX, NMB, RES, TAIL, TOH, TOW, NW, V, Fx<KS, JX, NMB, TOH, TOW, NW, (TAIL != 0), (AL != 0)>::LDS, \
      &fx_launch_t<KS, JX, NMB, (RES != 0), TOH, TOW, NW, (TAIL != 0), (XR != 0), (AL != 0)>}
@@ -1125,6 +1418,9 @@ static const FxEntry kFxTable[] = {
     {5, 2, 2, 1, 0, 16, 32, 8, 4, Fx<5, 2, 2, 16, 32, 8, false, true>::LDS, &fx_launch_t<5, 2, 2, true, 16, 32, 8, false, true, true, true>},
     {3, 2, 2, 1, 1, 16, 16, 4, 5, Fx<3, 2, 2, 16, 16, 4, true, true>::LDS, &fx_launch_t<3, 2, 2, true, 16, 16, 4, true, true, true, true>},
     {5, 2, 2, 1, 0, 16, 16, 4, 5, Fx<5, 2, 2, 16, 16, 4, false, true>::LDS, &fx_launch_t<5, 2, 2, true, 16, 16, 4, false, true, true, true>},
+    // role-specialised waves on a double-buffered tile (mbconv_mxs_kernel)
+    {3, 2, 2, 1, 1, 16, 16, 8, 6, Fz<3, 2, 2, 16, 16, true>::LDS, &fz_launch_t<3, 2, 2, true, 16, 16, true>},
+    {5, 2, 2, 1, 0, 16, 16, 8, 6, Fz<5, 2, 2, 16, 16, false>::LDS, &fz_launch_t<5, 2, 2, true, 16, 16, false>},
 };
 #undef FXE
 static const FxEntry* fx_find(int k, int jx, int nmb, int res, int tail) {
