@@ -167,6 +167,13 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
     const int b = blockIdx.x;
     const int HW = p.h * p.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CF_TOPK_TIMING
+    unsigned long long tm[12]; int tn = 0;
+#define CF_TT() tm[tn++] = __builtin_amdgcn_s_memtime()
+#else
+#define CF_TT()
+#endif
+    CF_TT();
     const int K = p.K;
     const float* hm = p.hm_plane ? p.hm_plane + (size_t)b * HW : p.heads + (size_t)b * HW * 16;
     const int hs = p.hm_plane ? 1 : 16;
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
         list = staged;
     }
     __syncthreads();
+    CF_TT();
     // ---- pass 0: histogram of the top 11 score bits over the list; positives = bins >= 1024 (the list never holds +0)
     {
         uint32_t mypos = 0;
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
         if (lane == 0 && mypos) atomicAdd(&npos_s, mypos);
     }
     __syncthreads();
+    CF_TT();
     const uint32_t Ppos = npos_s;
     const uint32_t Z = (uint32_t)(HW - L);              // cells whose kept score is exactly +0: ordered by index
     // how many list entries the result holds (M), how many zero cells (nz): positives, then zeros, then negatives
@@ -253,6 +262,7 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
         thresh = prefix;                                // keys >= thresh (masked bits only) are exactly the M survivors
     }
 
+    CF_TT();
     // ---- compaction of the M survivors (order irrelevant: sorted next)
     int sortn = 64;
     while (sortn < (int)M) sortn <<= 1;
@@ -271,6 +281,7 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
     }
     __syncthreads();
 
+    CF_TT();
     u64 mine = 0ull;
     if constexpr (!BIG) {
         mine = (tid < (int)M) ? sel[tid] : 0ull;
@@ -312,6 +323,7 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
         for (int t = tid; t < (int)M; t += NT) fin[(uint32_t)t < lead ? t : t + nz] = gbuf[t];
     }
 
+    CF_TT();
     // ---- the zero cells (kept score exactly +0.0), lowest index first: ordered scan in rounds of NT cells
     if (nz > 0) {
         if (tid == 0) zfound = 0;
@@ -341,6 +353,7 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
     __syncthreads();
     if (tid == 0) p.count[(size_t)b * kTopkCountStride] = 0;     // leave the list empty for the next launch
 
+    CF_TT();
     // ---- gather + box assembly (centerface_ext.py:60-82)
     for (int t = tid; t < K; t += NT) {
         const u64 key = BIG ? gbuf[sortn + t] : sel[t];
@@ -379,6 +392,12 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
             for (int j = 0; j < 10; ++j) r[6 + j] = rec[3 + j];
         }
     }
+#ifdef CF_TOPK_TIMING
+    CF_TT();
+    if (tid == 0 && b == 0) printf("topk L=%d M=%u nz=%u | init+stage %llu hist0 %llu select %llu compact %llu sort %llu zeros %llu gather %llu (memtime ticks)\n", L, M, nz,
+                                   tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5], tm[7] - tm[6]);
+#endif
+#undef CF_TT
 }
 
 size_t topk_big_stride(int K) {                           // u64 per image of TopkParams::big for K > 1024

@@ -30,7 +30,7 @@ struct PwParams {
     const void* low;      // [B][Ho/2][Wo/2][N] T or nullptr
     const float* upw;     // [4][N]  deconv tap * BN scale
     const float* upb;     // [N]     BN shift
-    int Ho, Wo;           // spatial dims of y (only for the IDAUp fusion)
+    int Ho, Wo;           // spatial dims of y per image (IDAUp fusion; the map size also picks pw_ksplit_kernel, cf_pw.hip)
     // channel-addressed output (ShuffleV2 concat, model/blocks.py:47-54): y rows have ldy elements and this conv
     // writes channels [yoff, yoff + N) of them; ldy = 0 means a dense [M][N] output.  Plain pw_kernel only.
     int ldy, yoff;

@@ -954,7 +954,7 @@ template <int KS, int JX, int NMB, int TOH, int TOW, bool TAIL16, bool XRELOAD, 
 __global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
     typedef Fs<KS, JX, NMB, TOH, TOW, TAIL16, ALDS> G;
     constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, MAXI = G::MAXI, CP8 = G::CP8, CP4 = G::CP4;
-    constexpr int WXB = G::WXB, NW = 4, KSTEPS = 3, NSTEP = G::NSTEP;
+    constexpr int WXB = G::WXB, NW = 4, KSTEPS = 3, NSTEP = G::NSTEP, HQ = (IWQ + 1) / 2;
     typedef __attribute__((ext_vector_type(4))) __bf16 mfma_bf16x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* E = smem;
@@ -985,7 +985,8 @@ __global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
         const int ib = wave + NW * t;
         const int ip = ib * 32 + pl;
         const int ipc = ip < IPX ? ip : IPX - 1;
-        const int iy = ipc / IWP, ix = ipc - iy * IWP;
+        const int cc = ipc >> 2, iy = cc / IWQ, pos = cc - iy * IWQ;                 // cell position -> x-quad: even quads first, then the odd ones
+        const int ix = 4 * (pos < HQ ? 2 * pos : 2 * (pos - HQ) + 1) + (ipc & 3);
         const int gy = oy0 * 2 - p.pad_lo + iy, gx = ox0 * 2 - p.pad_lo + ix;
         const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
         const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
@@ -1003,7 +1004,10 @@ __global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
     static constexpr SetMap<TOH, TOW, IWQ, 2> kSets{};
     const uint32_t se = kSets.v[set * 16 + (lane & 15)];
     const int soy = (se >> 6) & 0x1ff, soxq = se & 63;
-    const unsigned qcell = (unsigned)(2 * soy * IWQ + 2 * soxq);        // first input quad of this lane's output quad
+    // a row of cells holds its even x-quads first, then the odd ones: the three input quads 2 oxq + ks of an output quad sit at
+    // oxq, HQ + oxq, oxq + 1, and the 16 lanes of a ds_read_b128 group (cells 2 oy IWQ + oxq) can cover 16 distinct bank slots --
+    // with the plain row order every first cell is even and each read is a two-way conflict (0.63 conflict cycles per active cycle)
+    const unsigned qcell = (unsigned)(2 * soy * IWQ + soxq);
 
     f32x4 pacc[4][NMB];
 #pragma unroll
@@ -1109,7 +1113,8 @@ __global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
         for (int sb = wave; sb < NIB * 2; sb += NW) {               // 16-pixel sub-blocks = 4 quads each
             const int ip = sb * 16 + (lane & 15), kc = lane >> 4;
             const int ipc = ip < IPX ? ip : IPX - 1;
-            const int iy = ipc / IWP, ix = ipc - iy * IWP;
+            const int cc = ipc >> 2, iy = cc / IWQ, pos = cc - iy * IWQ;
+            const int ix = 4 * (pos < HQ ? 2 * pos : 2 * (pos - HQ) + 1) + (ipc & 3);
             const int gy = oy0 * 2 - p.pad_lo + iy, gx = ox0 * 2 - p.pad_lo + ix;
             const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win && kc * 8 < p.Cin;
             const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
             for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
-                const char* bs = bb + ((st / KSTEPS) * IWQ + (st % KSTEPS)) * CP4;
+                const char* bs = bb + ((st / KSTEPS) * IWQ + ((st % KSTEPS) & 1) * HQ + ((st % KSTEPS) >> 1)) * CP4;
                 const u32x4 b0 = ld16(bs), b1 = ld16(bs + 16);
                 const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, A4[st / KSTEPS][st % KSTEPS]);
                 u32x2 t0, t1, t2, t3; t0.x = b0.x; t0.y = b0.y; t1.x = b0.z; t1.y = b0.w; t2.x = b1.x; t2.y = b1.y; t3.x = b1.z; t3.y = b1.w;

@@ -60,7 +60,7 @@ struct SetMap {
     uint16_t v[NSLOT];
     constexpr SetMap() : v() {
         int bucket[16][NOQ] = {}; int cnt[16] = {}, used[16] = {};
-        for (int r = 0; r < NOQ; ++r) { const int b = (S * (r / OWQ) * IWQ + S * (r % OWQ)) & 15; bucket[b][cnt[b]++] = r; }     // class of the quad's first INPUT quad
+        for (int r = 0; r < NOQ; ++r) { const int b = (S * (r / OWQ) * IWQ + (r % OWQ)) & 15; bucket[b][cnt[b]++] = r; }     // class of the quad's first INPUT cell (stride 2: rows keep even x-quads first, so cell = x-quad / 2)
         int slot[NSLOT] = {};
         for (int s = 0; s < NSET; ++s)
             for (int q = 0; q < 16; ++q) {
@@ -207,8 +207,9 @@ __device__ __forceinline__ void mx_depthwise_half(const char* bb, const char* at
     for (int st = 0; st < NSTEP; ++st) {
         if (st + 1 < NSTEP) {
             const int ky = (st + 1) / KSTEPS, ks = (st + 1) % KSTEPS;
-            bq[(st + 1) & 1][0] = ld16(bb + (ky * IWQ + ks) * CP);
-            bq[(st + 1) & 1][1] = ld16(bb + (ky * IWQ + ks) * CP + 16);
+            constexpr int HQ = (IWQ + 1) / 2;                      // cell rows: even x-quads, then odd ones
+            bq[(st + 1) & 1][0] = ld16(bb + (ky * IWQ + (ks & 1) * HQ + (ks >> 1)) * CP);
+            bq[(st + 1) & 1][1] = ld16(bb + (ky * IWQ + (ks & 1) * HQ + (ks >> 1)) * CP + 16);
             aq[(st + 1) & 1] = *reinterpret_cast<const u32x2*>(at + (st + 1) * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -236,8 +237,9 @@ __device__ __forceinline__ void mx_depthwise_half_reg(const char* bb, const u32x
     for (int st = 0; st < NSTEP; ++st) {
         if (st + 1 < NSTEP) {
             const int ky = (st + 1) / KSTEPS, ks = (st + 1) % KSTEPS;
-            bq[(st + 1) & 1][0] = ld16(bb + (ky * IWQ + ks) * CP);
-            bq[(st + 1) & 1][1] = ld16(bb + (ky * IWQ + ks) * CP + 16);
+            constexpr int HQ = (IWQ + 1) / 2;
+            bq[(st + 1) & 1][0] = ld16(bb + (ky * IWQ + (ks & 1) * HQ + (ks >> 1)) * CP);
+            bq[(st + 1) & 1][1] = ld16(bb + (ky * IWQ + (ks & 1) * HQ + (ks >> 1)) * CP + 16);
         }
         __builtin_amdgcn_sched_barrier(0);
         const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, A[st / KSTEPS][st % KSTEPS]);

@@ -130,7 +130,7 @@ int cf_op_pwconv(int device, int dtype, const float* x, const float* w, const fl
     p.bias = bias ? (const float*)sc.up(bias, (size_t)Cout * 4) : nullptr;
     p.res = residual ? sc.to_nhwc(dtype, residual, B, Cout, H, W) : nullptr;
     p.y = sc.alloc((size_t)B * H * W * Cout * elem_size(dtype));
-    p.M = (long long)B * H * W; p.K = Cin; p.N = Cout; p.act = act;
+    p.M = (long long)B * H * W; p.K = Cin; p.N = Cout; p.act = act; p.Ho = H; p.Wo = W;      // the map size picks the kernel (cf_pw.hip)
     if (sc.err == hipSuccess) sc.chk(launch_pw(sc.s, dtype, p));
     sc.to_host_nchw(dtype, p.y, y, B, Cout, H, W);
     return sc.result("cf_op_pwconv");

@@ -302,6 +302,118 @@ __global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
     }
 }
 
+// ------------------------------------------------------------------ K split over the four waves of a workgroup
+// Small batches of the late layers (K up to 960 on 40x40 / 20x20 maps; configs[4]'s four images per GPU): M / 128 workgroups
+// leave most CUs idle and the kernel time is the latency of one wave's K chain (15 tiles of loads, ~2 us each).  Here a
+// workgroup owns 32 pixels instead of 128 and its four waves each walk a QUARTER of K (weights straight from L2: the fragment
+// stream of a wave is contiguous), so there are four times as many workgroups and the chain is a quarter as long.  The four
+// partial accumulators meet in LDS and are added in wave order 0, 1, 2, 3 (deterministic), each wave finishing a quarter of the
+// accumulator registers (4 channels x 32 pixels x NBW n-blocks).
+template <int NBW, int ACT, int RES>
+__global__ __launch_bounds__(256) void pw_ksplit_kernel(PwParams p) {
+    typedef bf16_t T;                                                // bf16 storage only (the fp32 parity mode keeps pw_wlds_kernel)
+    constexpr int DEPTH = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [wave][NBW][4 register quads][64 lanes] x 16 B
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const long long pb = blockIdx.x;
+    const long long m = pb * 32 + pl;
+    const bool mvalid = m < p.M;
+    const long long mr = mvalid ? m : p.M - 1;
+    const int NC = (int)((size_t)p.K * sizeof(T) / 16), NCh = (NC + 1) >> 1;
+    const int NB = (p.N + 31) >> 5;
+    const int nb0 = blockIdx.y * NBW;
+    const size_t xs = p.xblock ? 512 : 16;
+    const char* xrow = p.xblock ? (const char*)p.x + (((size_t)pb * NC + (size_t)h * NCh) * 32 + pl) * 16
+                                : (const char*)p.x + (size_t)mr * p.K * sizeof(T) + (size_t)h * NCh * 16;
+    const int jmax = (h == 0) ? NCh : NC - NCh;
+    const int per = (NCh + 3) >> 2;                                   // k-steps per wave
+    const int j0 = wave * per, j1 = min(j0 + per, NCh);
+    // n-blocks past NB (last group of a layer whose NB is not a multiple of NBW) read the layer's last block: finite values, never stored
+    size_t woff[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) woff[i] = ((size_t)min(nb0 + i, NB - 1) * NCh * 64 + lane) * 16;
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    u32x4 xr[DEPTH], wr[DEPTH][NBW];
+    auto fetch = [&](int j, int slot) {
+        // a chunk past this half's share is read from a clamped address and meets zero weights (pw_pack_weights)
+        xr[slot] = ld16(xrow + (size_t)(j < jmax ? j : 0) * xs);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) wr[slot][i] = ld16((const char*)p.wp + woff[i] + (size_t)j * 1024);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)
+        if (j0 + d < j1) fetch(j0 + d, d);
+    for (int jb = j0; jb < j1; jb += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            const int j = jb + u;
+            if (j >= j1) break;
+            if (j + DEPTH - 1 < j1) fetch(j + DEPTH - 1, (u + DEPTH - 1) % DEPTH);
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) Mma<T>::run(acc[i], wr[u][i], xr[u]);
+        }
+    }
+    // ---- partial sums -> LDS, then wave w finishes register quad w of every n-block
+    {
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v; v[0] = acc[i][4 * q]; v[1] = acc[i][4 * q + 1]; v[2] = acc[i][4 * q + 2]; v[3] = acc[i][4 * q + 3];
+                red[((wave * NBW + i) * 4 + q) * 64 + lane] = v;
+            }
+    }
+    __syncthreads();
+    if (!mvalid) return;
+    const f32x4* red = reinterpret_cast<const f32x4*>(smem);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        if (nb0 + i >= NB) break;
+        const int ch = (nb0 + i) * 32 + h * 16 + wave * 4;            // channels of register quad `wave`
+        if (ch >= p.N) continue;
+        f32x4 v = red[((0 * NBW + i) * 4 + wave) * 64 + lane];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) v += red[((w2 * NBW + i) * 4 + wave) * 64 + lane];
+        float o[4] = {v[0], v[1], v[2], v[3]};
+        act_arr<ACT, 4>(o);
+        // 8-byte element group inside the 16-byte group of eight channels (row-major or pixel-block order)
+        const size_t off = (p.yblock ? blk_off((size_t)m, p.N / 8, ch / 8) : ((size_t)m * p.N + (ch & ~7)) * sizeof(T)) + (ch & 4) * sizeof(T);
+        if constexpr (RES == 1) {
+            const size_t roff = (p.resblock ? blk_off((size_t)m, p.N / 8, ch / 8) : ((size_t)m * p.N + (ch & ~7)) * sizeof(T)) + (ch & 4) * sizeof(T);
+            const u32x2 rv = *reinterpret_cast<const u32x2*>((const char*)p.res + roff);
+            o[0] += bf16_to_f32((uint16_t)(rv.x & 0xffffu)); o[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+            o[2] += bf16_to_f32((uint16_t)(rv.y & 0xffffu)); o[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+        }
+        u32x2 pk; pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
+        *reinterpret_cast<u32x2*>((char*)p.y + off) = pk;
+    }
+}
+
+template <int NBW>
+static hipError_t dispatch_ksplit(hipStream_t s, const PwParams& p) {
+    const int NB = (p.N + 31) / 32;
+    dim3 grid((unsigned)((p.M + 31) / 32), (unsigned)((NB + NBW - 1) / NBW)), blk(256);
+    const size_t lds = (size_t)4 * NBW * 4 * 64 * 16;
+    const int res = p.res ? 1 : 0;
+#define CF_PWK_LAUNCH(ACT, RES) \
+    set_kernel_tag("void cf::pw_ksplit_kernel<%d, %d, %d>(cf::PwParams)", NBW, ACT, RES); \
+    hipLaunchKernelGGL((pw_ksplit_kernel<NBW, ACT, RES>), grid, blk, lds, s, p); return hipGetLastError();
+    if (p.act == 1 && res == 0) { CF_PWK_LAUNCH(1, 0) }
+    if (p.act == 0 && res == 0) { CF_PWK_LAUNCH(0, 0) }
+    if (p.act == 0 && res == 1) { CF_PWK_LAUNCH(0, 1) }
+#undef CF_PWK_LAUNCH
+    return hipErrorInvalidValue;
+}
+
 template <typename T, int NBW, int NST>
 static hipError_t dispatch_wlds(hipStream_t s, const PwParams& p, dim3 grid) {
     dim3 blk(256);
@@ -344,6 +456,15 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
     static const int wl_env = getenv("CF_PW_WLDS") ? atoi(getenv("CF_PW_WLDS")) : -1;     // A/B: 0 off, N = force NBW
     if (wl_env != 0 && !p.bias && !p.low && !p.ldy && p.K >= 64 && NB >= 3 && (p.act == 1 || p.act == 0)) {
         (void)wl_env;                          // NBW = 4 measured best of {4,5,6,8} on every late layer
+        if constexpr (sizeof(T) == 2) {
+            // K split over the waves on the >= 32x32 late maps of 1280-class inputs (configs[4]: four images per GPU leave M / 128 =
+            // 50 workgroups).  Chosen by the LAYER's shape, never by the batch: the two kernels sum K in different orders, and an
+            // image's result must not depend on the batch it travels in.  B = 4, 1280x1280: 13.7 -> 8.8, 20.6 -> 10.8, 24.0 -> 14.6 us
+            // (layer5.0 / 5.1 / 6.0 project); slower than pw_wlds_kernel on 20x20 maps at B = 64 (16 -> 19, 23 -> 29, 30 -> 49 us)
+            static const int ks_env = getenv("CF_PW_KSPLIT") ? atoi(getenv("CF_PW_KSPLIT")) : -1;   // A/B: 0 off, 1 force
+            if (ks_env != 0 && p.K >= 256 && (ks_env > 0 || (p.K >= 512 && (long long)p.Ho * p.Wo >= 1024 && (long long)p.Ho * p.Wo < 4096)))
+                return (NB % 3 == 0 || NB == 5) ? dispatch_ksplit<3>(s, p) : dispatch_ksplit<2>(s, p);
+        }
         static const int nst_env = getenv("CF_PW_NST") ? atoi(getenv("CF_PW_NST")) : 0;       // A/B: ring depth 2..4
         static const int nbw_env = getenv("CF_PW_NBW") ? atoi(getenv("CF_PW_NBW")) : 0;
         // N = 320: five n-blocks per wave (activations read twice); N = 160: 3 + 2 (two workgroup rows: 200 -> 400 workgroups on

@@ -109,6 +109,24 @@ def test_production_project_gemm_at_batch64(prefix):
     _assert_close(o, E.pw_op(y, wp, residual=res), prefix + " project B=64")
 
 
+@pytest.mark.parametrize("prefix", ["layer5.0", "layer5.1", "layer6.0"])
+def test_project_gemm_k_split_instances_at_1280_maps(prefix):
+    """On the 40x40 late maps of 1280x1280 inputs (BASELINE configs[4], four images per GPU) the project GEMMs run as
+    ``pw_ksplit_kernel`` (K split over the four waves of a workgroup, partial sums added in wave order): against the
+    emulation, and -- the kernel is chosen by the LAYER's map size, not by the batch -- an image's rows must not change
+    with the batch it travels in."""
+    _, cin, cout, k, s, h = [b for b in BLOCKS if b[0] == prefix][0]
+    ho = 2 * (h // s)                                      # the 1280x1280 instance of the layer
+    rng = np.random.default_rng(cout + 1)
+    we, wd, wp = _w(prefix)
+    y = _bf16_normal(rng, (4, we.shape[0], ho, ho), 0.7)
+    res = _bf16_normal(rng, (4, cout, ho, ho), 1.0) if (cin == cout and s == 1) else None
+    o = ops.conv_pw(y, wp, residual=res, dtype="bf16")
+    _assert_close(o, E.pw_op(y, wp, residual=res), prefix + " project, 40x40 map, B=4")
+    o1 = ops.conv_pw(y[2:3], wp, residual=None if res is None else res[2:3], dtype="bf16")
+    assert np.array_equal(o1[0], o[2])
+
+
 # ------------------------------------------------------------------------------- the engine itself, layer by layer
 def _trace_all(eng, x):
     plan = eng.plan()
