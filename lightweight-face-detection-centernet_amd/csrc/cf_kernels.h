@@ -96,6 +96,12 @@ hipError_t mb2_launch(hipStream_t s, const MbParams& p);
 MbGeom expdw_geometry(int dtype, int Cin, int hid, int k, int s);
 hipError_t expdw_launch(hipStream_t s, const MbParams& p);
 
+// cf_mbconv4.hip: the fp32 parity mode's fused block, second generation (MbGeom::kind = 7): wave = 64 pixels, SGPR taps, permlane32
+// swap into the project MFMA; expand fragments as cf_mbconv.hip, taps and project fragments repacked by mb4_repack
+bool mb4_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s);
+void mb4_repack(const MbGeom& g, int hid, int Cout, int k, const float* wd, const float* wp, float* wdw_host, void* wproj_host);
+hipError_t mb4_launch(hipStream_t s, const MbParams& p);
+
 // cf_mbconv3.hip: depthwise on the matrix cores (v_mfma_f32_4x4x4_16b_f16, Toeplitz operands), stride 1, bf16 storage.
 // MbGeom::kind 4 = expand + depthwise (project stays a GEMM launch)
 MbGeom expdw_mx_geometry(int dtype, int Cin, int hid, int k, int s);

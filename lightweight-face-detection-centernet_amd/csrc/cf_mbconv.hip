@@ -61,6 +61,12 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
     if (g.kind == 4) { mx_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 5) { mx_fused_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 6) { mx_fused2_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
+    if (g.kind == 7) {                       // cf_mbconv4.hip: this file's expand fragments, its own tap table and project fragments
+        MbGeom g0 = g; g0.kind = 0;
+        mb_pack_weights(dtype, g0, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host);
+        mb4_repack(g, hid, Cout, k, wd, wp, wdw_host, wproj_host);
+        return;
+    }
     const int P = per16(dtype);
     const int NCx = Cin * (int)elem_size(dtype) / 16;
     __builtin_memset(wexp_host, 0, g.wexp_bytes);
@@ -402,15 +408,16 @@ static const MbEntry kMbTable[] = {
     // experimental variants (CF_MB_VARIANT=n), kept for A/B runs through tools/profile_ops.py
     MB_VARIANT(1, bf16_t, 1, 3, 1, 4, 32, 2, 1, 8, 20, 0, 10),  // 3.1  8x20
     MB_VARIANT(1, bf16_t, 1, 3, 2, 2, 32, 2, 0, 8, 20, 0, 5),   // 3.0  8x20
-    // fp32 storage (parity mode)
-    MB_ENTRY(float, 0, 3, 2, 2, 32, 1, 0, 8, 16, 1, 4),
-    MB_ENTRY(float, 0, 3, 1, 3, 48, 1, 1, 8, 16, 1, 4),
-    MB_ENTRY(float, 0, 5, 2, 3, 48, 1, 0, 8, 16, 1, 8),
-    MB_ENTRY(float, 0, 5, 1, 4, 32, 1, 1, 8, 16, 1, 8),
-    MB_ENTRY(float, 0, 3, 2, 4, 32, 2, 0, 8, 16, 1, 4),
-    MB_ENTRY(float, 0, 3, 1, 8, 32, 2, 1, 8, 16, 1, 4),
-    MB_ENTRY(float, 0, 5, 1, 8, 32, 3, 0, 8, 16, 1, 8),
-    MB_ENTRY(float, 0, 5, 1, 12, 32, 3, 1, 8, 16, 1, 8),
+    // fp32 storage (parity mode).  Round-3 A/B over hidden chunk / tile / k-groups (B = 64, 640x640, ms; previous entry in brackets):
+    // what matters is the LDS footprint of the fp32 tile (1.0 at 8x16 / HC 32 = 87 KB = ONE four-wave workgroup per CU)
+    MB_ENTRY(float, 0, 3, 2, 2, 32, 1, 0, 4, 16, 1, 4),    // 1.0  4x16 tile, two k-groups, 49 KB: 0.564 [8x16: 0.786; 8x16 HC 16: 0.635]
+    MB_ENTRY(float, 0, 3, 1, 3, 48, 1, 1, 8, 16, 1, 8),    // 1.1  two k-groups: 0.497 [0.505; HC 16: 0.590; 16x16: 0.589]
+    MB_ENTRY(float, 0, 5, 2, 3, 16, 1, 0, 8, 16, 1, 8),    // 2.0  HC 16, 62 KB: 0.428 [HC 48, 138 KB: 0.441; 4x16: 0.454 / 0.636]
+    MB_ENTRY(float, 0, 5, 1, 4, 48, 1, 1, 8, 16, 1, 8),    // 2.1  HC 48: 0.319 [HC 32: 0.365; HC 16: 0.363]
+    MB_ENTRY(float, 0, 3, 2, 4, 32, 2, 0, 8, 16, 1, 8),    // 3.0  two k-groups: 0.150 [0.170; HC 16: 0.203]
+    MB_ENTRY(float, 0, 3, 1, 8, 32, 2, 1, 8, 16, 1, 4),    // 3.1  0.192 [two k-groups: 0.191; HC 64: 0.220; HC 48: 0.232]
+    MB_ENTRY(float, 0, 5, 1, 8, 32, 3, 0, 8, 16, 1, 8),    // 4.0  0.277 [HC 16: 0.363; HC 48: 0.344; one k-group: 0.378]
+    MB_ENTRY(float, 0, 5, 1, 12, 32, 3, 1, 8, 16, 1, 4),   // 4.1  one k-group: 0.512 [0.534; HC 16: 0.724; HC 48: 0.596]
 };
 #undef MB_ENTRY
 
@@ -432,6 +439,7 @@ MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
     if (dtype == 1 && mx_fused_geometry(g, Cin, hid, Cout, k, s)) return g;      // stride 1: depthwise on the matrix cores
     if (dtype == 1 && mx_fused2_geometry(g, Cin, hid, Cout, k, s)) return g;     // stride 2
     if (dtype == 1 && mb2_geometry(g, Cin, hid, Cout, k, s)) return g;
+    if (dtype == 0 && mb4_geometry(g, Cin, hid, Cout, k, s)) return g;
     g.JX = (Cin * sz / 16 + 1) / 2;
     g.NBO = (Cout + 31) / 32;
     const MbEntry* e = mb_find(dtype, k, s, g.JX, g.NBO, (Cin == Cout && s == 1) ? 1 : 0);
@@ -455,6 +463,7 @@ hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p) {
     if (p.kind == 4) return dtype == 1 ? mx_launch(s, p) : hipErrorInvalidValue;
     if (p.kind == 5) return dtype == 1 ? mx_fused_launch(s, p) : hipErrorInvalidValue;
     if (p.kind == 6) return dtype == 1 ? mx_fused2_launch(s, p) : hipErrorInvalidValue;
+    if (p.kind == 7) return dtype == 0 ? mb4_launch(s, p) : hipErrorInvalidValue;
     const MbEntry* e = mb_find(dtype, p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
     if (!e || e->hc != p.HC) return hipErrorInvalidValue;
     return e->fn(s, p);
