@@ -27,7 +27,9 @@ __device__ __forceinline__ f32x16 uh_mma(f32x16 acc, const u32x4& w, const u32x4
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w), __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
 }
 
+template <bool COALESCE>
 __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
+    __shared__ __attribute__((aligned(16))) char Rs[COALESCE ? 4 * 2048 : 16];   // one row of 32 records per wave, staged for full-line stores
     __shared__ __attribute__((aligned(16))) char T3[UH_NIB * 32 * UH_PIT];      // neck tile incl. halo, bf16
     __shared__ __attribute__((aligned(16))) char Wh[UH_WHB];                   // head weight fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
             }
         }
         const int gy = oy0 + oy, gx = ox0 + ox;
-        if (gy >= p.h || gx >= p.w) continue;
+        if constexpr (!COALESCE) { if (gy >= p.h || gx >= p.w) continue; }
         // head_pack_weights(collapsed = 2): MFMA row = record slot, so lane half h holds slots 4h..4h+3 (acc 0-3) and
         // 8+4h..8+4h+3 (acc 4-7) of its pixel: every lane stores two 16-byte pieces and a 64-byte record is written by
         // two store instructions of the wave instead of four half-empty ones.  Slot 15 = the raw hm logit (slot 0's
@@ -124,16 +126,37 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { out[r] = acc[r] + p.b0[h * 4 + r]; out[4 + r] = acc[4 + r] + p.b0[8 + h * 4 + r]; }
         const size_t m = ((size_t)b * p.h + gy) * p.w + gx;
+        const bool inmap = gy < p.h && gx < p.w;
         if (h == 0) {
             // centerface.py:43: clamp(sigmoid(hm), 1e-4, 1 - 1e-4); precise exp + IEEE divide
             float sg = 1.0f / (1.0f + expf(-out[0]));
             sg = fminf(fmaxf(sg, 1e-4f), 1.0f - 1e-4f);
             out[0] = sg;
-            if (p.hm_plane) p.hm_plane[m] = sg;
+            if (p.hm_plane && inmap) p.hm_plane[m] = sg;
         }
-        float* dst = p.heads + m * 16 + h * 4;
-        st16(dst, pack16<float>(&out[0]));
-        st16(dst + 8, pack16<float>(&out[4]));
+        if constexpr (COALESCE) {
+            // a pixel block is one tile row of 32 cells = 2 KB of consecutive records: staged through LDS so that every store
+            // instruction of the wave writes 1 KB of consecutive bytes instead of 64 16-byte pieces 64 bytes apart
+            char* rs = Rs + wave * 2048;
+            st16(rs + pl * 64 + h * 16, pack16<float>(&out[0]));
+            st16(rs + pl * 64 + 32 + h * 16, pack16<float>(&out[4]));
+            __builtin_amdgcn_wave_barrier();
+            if (gy < p.h) {                                                     // wave-uniform (oy is)
+                char* row0 = (char*)(p.heads + (((size_t)b * p.h + gy) * p.w + ox0) * 16);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int q = lane + 64 * k;                                // 16-byte piece q of the row: record q / 4
+                    const u32x4 v = ld16(rs + q * 16);
+                    if (ox0 + (q >> 2) < p.w) st16(row0 + q * 16, v);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (!COALESCE) {
+            float* dst = p.heads + m * 16 + h * 4;
+            st16(dst, pack16<float>(&out[0]));
+            st16(dst + 8, pack16<float>(&out[4]));
+        }
     }
 }
 
@@ -143,7 +166,9 @@ hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p) {
     set_kernel_tag("cf::uphead_kernel(cf::UpHeadParams)");
     static const bool xcd_on = getenv("CF_XCD_ORDER") && atoi(getenv("CF_XCD_ORDER")) >= 1;      // A/B only: 0.090 -> 0.094 ms with it
     UpHeadParams q = p; q.xcd = xcd_on ? 1 : 0;
-    hipLaunchKernelGGL(uphead_kernel, grid, blk, 0, s, q);
+    static const bool coalesce = !(getenv("CF_UH_COALESCE") && atoi(getenv("CF_UH_COALESCE")) == 0);      // A/B
+    if (coalesce) hipLaunchKernelGGL(uphead_kernel<true>, grid, blk, 0, s, q);
+    else hipLaunchKernelGGL(uphead_kernel<false>, grid, blk, 0, s, q);
     return hipGetLastError();
 }
 
