@@ -117,10 +117,12 @@ def cpu_baseline(seconds, size, topk, imgs):
         return n / el, n, el
     v16, n16, t16 = measure(min(16, len(imgs)), seconds * 0.6)
     v1, n1, t1 = measure(1, seconds * 0.4)
-    return {"value": round(v16, 2), "unit": "images/s", "cores": torch.get_num_threads(), "host_cores": host_cores,
-            "kind": "port", "value_b1": round(v1, 2),
-            "sample": "B=16: %d images in %.1f s; B=1: %d images in %.1f s (%dx%d, fp32 torch-CPU oracle forward + top-%d decode, "
-                      "%d threads of %d host cores)" % (n16, t16, n1, t1, size, size, topk, torch.get_num_threads(), host_cores)}
+    # the reported value is the better of the two batch sizes (oneDNN on a many-core host is often faster one image at a time)
+    return {"value": round(max(v16, v1), 2), "unit": "images/s", "cores": torch.get_num_threads(), "host_cores": host_cores,
+            "kind": "port", "value_b16": round(v16, 2), "value_b1": round(v1, 2),
+            "sample": "B=16: %d images in %.1f s; B=1: %d images in %.1f s (%dx%d, fp32 torch-CPU oracle forward + top-%d decode; "
+                      "%d threads = the fastest of {8, 16, 32, 64, 128} on a B=4 probe, %d host cores; value = the better batch size)"
+                      % (n16, t16, n1, t1, size, size, topk, torch.get_num_threads(), host_cores)}
 
 
 def flush_c_stdio():

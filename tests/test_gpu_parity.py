@@ -10,6 +10,9 @@ Tolerances (BASELINE.json north_star): top-k indices bit-exact, box/score fp32 w
     one bf16 ulp + flip noise per kernel; the production instances and the engine layer by layer are in
     tests/test_bf16_parity.py.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -120,7 +123,8 @@ def test_fused_mbconv_vs_reference(golden, dtype):
 
 
 @pytest.mark.parametrize("cfg", [(16, 24, 3, 2, 70, 90), (24, 24, 3, 1, 41, 37), (24, 32, 5, 2, 64, 48),
-                                 (32, 32, 5, 1, 33, 50), (64, 96, 5, 1, 40, 40), (96, 96, 5, 1, 24, 17)])
+                                 (32, 32, 5, 1, 33, 50), (32, 64, 3, 2, 45, 38), (64, 64, 3, 1, 21, 30),
+                                 (64, 96, 5, 1, 40, 40), (96, 96, 5, 1, 24, 17)])
 def test_fused_mbconv_multi_tile_vs_oracle(cfg):
     """Interior + edge tiles, odd sizes, batch > 1, against the oracle's MBConv restatement (fp32)."""
     cin, cout, k, s, H, W = cfg
@@ -137,6 +141,19 @@ def test_fused_mbconv_multi_tile_vs_oracle(cfg):
     emu = E.mbconv_fused(E.q_bf16(torch.from_numpy(x)), sd["b.conv.0.1.weight"].reshape(hid, cin), sd["b.conv.1.1.weight"],
                          sd["b.conv.2.weight"].reshape(cout, hid), k, s, cin == cout and s == 1)
     _emu_close(yb, emu, cfg)
+
+
+def test_fp32_second_generation_kernel_on_every_block_shape():
+    """``mbconv_f32_kernel`` (cf_mbconv4.hip: SGPR taps, permlane32 swap into the project MFMA) runs layer2.1 by default;
+    ``CF_F4_VARIANT=1`` puts all eight backbone block shapes on it.  The variant is read once per process, so the multi-tile
+    oracle comparison above is re-run in a child process with it set -- the kernel the table does not pick must stay correct."""
+    import subprocess
+    env = dict(os.environ, CF_F4_VARIANT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_fused_mbconv_multi_tile_vs_oracle or test_network_fp32_vs_reference_goldens"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "9 passed" in r.stdout, r.stdout[-1000:]
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
