@@ -459,10 +459,11 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
         if constexpr (sizeof(T) == 2) {
             // K split over the waves on the >= 32x32 late maps of 1280-class inputs (configs[4]: four images per GPU leave M / 128 =
             // 50 workgroups).  Chosen by the LAYER's shape, never by the batch: the two kernels sum K in different orders, and an
-            // image's result must not depend on the batch it travels in.  B = 4, 1280x1280: 13.7 -> 8.8, 20.6 -> 10.8, 24.0 -> 14.6 us
-            // (layer5.0 / 5.1 / 6.0 project); slower than pw_wlds_kernel on 20x20 maps at B = 64 (16 -> 19, 23 -> 29, 30 -> 49 us)
+            // image's result must not depend on the batch it travels in.  B = 4, 1280x1280: 20.6 -> 10.8, 24.0 -> 14.6 us (layer5.1 /
+            // 6.0 project, K = 960); slower than pw_wlds_kernel at B = 64, 640x640 (20x20 maps: 23 -> 29, 30 -> 49 us; layer4.1's K = 576
+            // on its 40x40 map: 32 -> 35 us), hence K >= 768: at 1280x1280 layer5.0 (K = 576, 13.7 vs 8.8 us) stays on pw_wlds_kernel
             static const int ks_env = getenv("CF_PW_KSPLIT") ? atoi(getenv("CF_PW_KSPLIT")) : -1;   // A/B: 0 off, 1 force
-            if (ks_env != 0 && p.K >= 256 && (ks_env > 0 || (p.K >= 512 && (long long)p.Ho * p.Wo >= 1024 && (long long)p.Ho * p.Wo < 4096)))
+            if (ks_env != 0 && p.K >= 256 && (ks_env > 0 || (p.K >= 768 && (long long)p.Ho * p.Wo >= 1024 && (long long)p.Ho * p.Wo < 4096)))
                 return (NB % 3 == 0 || NB == 5) ? dispatch_ksplit<3>(s, p) : dispatch_ksplit<2>(s, p);
         }
         static const int nst_env = getenv("CF_PW_NST") ? atoi(getenv("CF_PW_NST")) : 0;       // A/B: ring depth 2..4
