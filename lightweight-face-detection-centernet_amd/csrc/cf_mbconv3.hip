@@ -1378,7 +1378,7 @@ static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
     static const int abl = getenv("CF_FX_ABL") ? atoi(getenv("CF_FX_ABL")) : 0;      // timing experiments only: results invalid
     MbParams q = p; q.nw = abl;
     set_kernel_tag(SB ? "void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s, true>(cf::MbParams)"
-                      : "void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false",
+                      : "void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s, false>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false",
                    TOH, TOW, NW, TAIL16 ? "true" : "false", XRELOAD ? "true" : "false", ALDS ? "true" : "false");
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, q);
     return hipGetLastError();
