@@ -65,12 +65,24 @@ def unique_id():
     return bytes(buf.raw)
 
 
-def broadcast_unique_id(src=0, group=None):
-    """Rank ``src`` creates the id, every rank of the (initialised) torch.distributed group receives it."""
+_uid_calls = 0
+
+
+def broadcast_unique_id(src=0, group=None, store=None):
+    """Rank ``src`` creates the id, every rank of the (initialised) torch.distributed group receives it -- through the
+    group's key-value store (TCP), not through a collective: no NCCL communicator has to exist (or work) for the bootstrap of
+    this one.  Collective in the sense that every rank must call it the same number of times (the key carries a call counter)."""
+    global _uid_calls
     import torch.distributed as dist
-    obj = [unique_id() if dist.get_rank(group) == src else None]
-    dist.broadcast_object_list(obj, src=src, group=group)
-    return obj[0]
+    del group                                        # the default store serves every group of the process
+    store = store or dist.distributed_c10d._get_default_store()
+    key = "cf_comm_uid/%d" % _uid_calls
+    _uid_calls += 1
+    if dist.get_rank() == src:
+        uid = unique_id()
+        store.set(key, uid)
+        return uid
+    return bytes(store.get(key))                     # blocks until rank src has published it (store timeout applies)
 
 
 class Comm(object):

@@ -25,6 +25,13 @@ out = cfa.distributed.gather_records(rec)
 ref = np.concatenate([full_d, full_l], axis=2)
 assert out.shape == (B, K, 16), out.shape
 assert np.array_equal(out.numpy(), ref)
+# bootstrap helpers of the RCCL path: the communicator id and the go / no-go verdicts travel through the TCP store
+# (a real id needs librccl; the store plumbing is what is under test here)
+cfa.distributed.unique_id = lambda: bytes([rank + 7]) * 128
+u1 = cfa.distributed.broadcast_unique_id(); u2 = cfa.distributed.broadcast_unique_id()
+assert u1 == bytes([7]) * 128 == u2 and len(u1) == cfa.distributed.COMM_ID_BYTES
+assert cfa.distributed.agree(1, rank, world, "t_ok") is True
+assert cfa.distributed.agree(1 if rank == 0 else 0, rank, world, "t_bad") is False
 dist.barrier()
 dist.destroy_process_group()
 print("rank %%d ok" %% rank)
