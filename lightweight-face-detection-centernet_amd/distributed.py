@@ -79,10 +79,17 @@ def broadcast_unique_id(src=0, group=None, store=None):
     key = "cf_comm_uid/%d" % _uid_calls
     _uid_calls += 1
     if dist.get_rank() == src:
-        uid = unique_id()
+        try:
+            uid = unique_id()
+        except Exception:
+            store.set(key, b"failed")                # the other ranks must not wait for an id that will never come
+            raise
         store.set(key, uid)
         return uid
-    return bytes(store.get(key))                     # blocks until rank src has published it (store timeout applies)
+    uid = bytes(store.get(key))                      # blocks until rank src has published it (store timeout applies)
+    if len(uid) != COMM_ID_BYTES:
+        raise RuntimeError("rank %d could not create the RCCL unique id" % src)
+    return uid
 
 
 class Comm(object):
