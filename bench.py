@@ -273,6 +273,7 @@ def main():
     engs = ring.engines
     eng = engs[0]
     gather, comms = "none", []
+    hard_exit = False            # a helper thread is stuck inside ncclCommInitRank: leave through os._exit after the JSON line
 
     def close_comms():
         for cm in comms:
@@ -288,7 +289,26 @@ def main():
             ok = 1
             try:
                 uid = cfa.distributed.broadcast_unique_id() if world > 1 else cfa.distributed.unique_id()
-                comms.append(cfa.distributed.Comm(engs[0], rank, world, uid))
+                # ncclCommInitRank blocks until every rank has joined: run it on a helper thread against the same deadline, so a
+                # rank that never arrives costs a fallback, not the run (the stuck thread is abandoned; see hard_exit below)
+                import threading
+                box = {}
+
+                def create():
+                    try:
+                        box["comm"] = cfa.distributed.Comm(engs[0], rank, world, uid)
+                    except Exception as exc2:                          # noqa: BLE001
+                        box["err"] = exc2
+                th = threading.Thread(target=create, daemon=True)
+                th.start()
+                th.join(max(5.0, abs(args.gather_timeout)))
+                if th.is_alive():
+                    ok, hard_exit = 0, True
+                    print("rank %d: cf_comm_create did not return within %.0f s" % (rank, max(5.0, abs(args.gather_timeout))), file=sys.stderr)
+                elif "err" in box:
+                    raise box["err"]
+                else:
+                    comms.append(box["comm"])
             except Exception as exc:                                   # noqa: BLE001
                 ok = 0
                 print("rank %d: cf_comm_create failed (%s)" % (rank, exc), file=sys.stderr)
@@ -499,6 +519,9 @@ def main():
             result["cpu_baseline"] = None
         flush_c_stdio()
         print(json.dumps(result), flush=True)       # the one JSON line, last on stdout
+    if hard_exit:                                   # a thread is still blocked inside ncclCommInitRank: skip interpreter teardown
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
