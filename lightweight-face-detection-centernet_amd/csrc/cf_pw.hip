@@ -461,9 +461,9 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
             // 50 workgroups).  Chosen by the LAYER's shape, never by the batch: the two kernels sum K in different orders, and an
             // image's result must not depend on the batch it travels in.  B = 4, 1280x1280: 20.6 -> 10.8, 24.0 -> 14.6 us (layer5.1 /
             // 6.0 project, K = 960); slower than pw_wlds_kernel at B = 64, 640x640 (20x20 maps: 23 -> 29, 30 -> 49 us; layer4.1's K = 576
-            // on its 40x40 map: 32 -> 35 us), hence K >= 768: at 1280x1280 layer5.0 (K = 576, 13.7 vs 8.8 us) stays on pw_wlds_kernel
+            // on its 40x40 map: 32 -> 35 us, N = 96), hence K >= 512 AND N >= 128: layer5.0 / 5.1 / 6.0 of 1280-class inputs (13.7 -> 8.8 us for 5.0)
             static const int ks_env = getenv("CF_PW_KSPLIT") ? atoi(getenv("CF_PW_KSPLIT")) : -1;   // A/B: 0 off, 1 force
-            if (ks_env != 0 && p.K >= 256 && (ks_env > 0 || (p.K >= 768 && (long long)p.Ho * p.Wo >= 1024 && (long long)p.Ho * p.Wo < 4096)))
+            if (ks_env != 0 && p.K >= 256 && (ks_env > 0 || (p.K >= 512 && p.N >= 128 && (long long)p.Ho * p.Wo >= 1024 && (long long)p.Ho * p.Wo < 4096)))
                 return (NB % 3 == 0 || NB == 5) ? dispatch_ksplit<3>(s, p) : dispatch_ksplit<2>(s, p);
         }
         static const int nst_env = getenv("CF_PW_NST") ? atoi(getenv("CF_PW_NST")) : 0;       // A/B: ring depth 2..4

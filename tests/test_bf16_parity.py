@@ -109,7 +109,7 @@ def test_production_project_gemm_at_batch64(prefix):
     _assert_close(o, E.pw_op(y, wp, residual=res), prefix + " project B=64")
 
 
-@pytest.mark.parametrize("prefix", ["layer5.1", "layer6.0"])
+@pytest.mark.parametrize("prefix", ["layer5.0", "layer5.1", "layer6.0"])
 def test_project_gemm_k_split_instances_at_1280_maps(prefix):
     """On the 40x40 late maps of 1280x1280 inputs (BASELINE configs[4], four images per GPU) the project GEMMs run as
     ``pw_ksplit_kernel`` (K split over the four waves of a workgroup, partial sums added in wave order): against the
