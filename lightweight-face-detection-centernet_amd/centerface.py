@@ -112,6 +112,23 @@ class Engine(object):
         self._chk(self._L.cf_forward(self._h, p, int(in_format), 1 if on_device else 0, int(B)))
         self.last_B = int(B)
 
+    def forward_lanes_enqueue(self, prev, x, B, in_format=None):
+        """Two-lane schedule (``cf_forward_lanes``, experimental): enqueue the front of a new batch (device pointer ``x``) on this
+        engine and the back half of the batch pending on ``prev`` (another Engine of the same device, or None) underneath its
+        mid-size blocks.  Afterwards ``prev`` holds a decodable result; this engine does not until it has been ``prev`` of a
+        later call or ``forward_lanes_flush()`` was called."""
+        fmt = _lib.CF_IN_U8_HWC_BGR if in_format is None else int(in_format)
+        self._chk(self._L.cf_forward_lanes(self._h, prev._h if prev is not None else None, C.c_void_p(int(x)), fmt, 1, int(B)))
+        self.last_B = 0
+        if prev is not None and getattr(prev, "_lane_B", 0):
+            prev.last_B, prev._lane_B = prev._lane_B, 0
+        self._lane_B = int(B)
+
+    def forward_lanes_flush(self):
+        self._chk(self._L.cf_forward_lanes_flush(self._h))
+        if getattr(self, "_lane_B", 0):
+            self.last_B, self._lane_B = self._lane_B, 0
+
     def forward_resized_enqueue(self, imgs_u8):
         """cv2.resize + forward (centerface.py:30-41): uint8 [B,h,w,3] BGR images of any (common) size are
         stretch-resized on the device to (H, W) and fed to the network."""
