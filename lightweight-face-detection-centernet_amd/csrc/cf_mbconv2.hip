@@ -469,6 +469,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
 }
 
 
+#ifndef CF_ILP_TU        // expand+depthwise kernel, tables and host side: main translation unit only
 // ================================================================== expand + depthwise only
 // The blocks whose output is too wide for the accumulator budget (layer5.0 .. layer6.0: Cout 160 / 320 on
 // 20x20 maps) keep their project 1x1 as a GEMM launch (cf_pw.hip), but expand + Swish + depthwise + Swish
@@ -722,8 +723,9 @@ struct Mb2Entry {
     hipError_t (*fn)(hipStream_t, const MbParams&);
 };
 
+#endif  // !CF_ILP_TU
 template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW>
-static hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
+hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
     auto kfn = mbconv_px_kernel<KS, S, NBO, RESID, NW, JX, HC, TOH, TOW>;
     constexpr int LDS = Px<KS, S, HC, TOH, TOW, JX, NW>::LDS;
     static thread_local bool configured_dev[32] = {};               // function attributes are per device
@@ -746,6 +748,24 @@ static hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
     return hipGetLastError();
 }
 
+// Two instances are compiled in their own translation unit (cf_mbconv2_ilp.hip = this file with CF_ILP_TU defined) under
+// `-mllvm -amdgpu-sched-strategy=max-ilp`: the ILP-first machine scheduler gains 1-2 % on them (same box, two runs each: layer1.0 0.2460 -> 0.2435 ms,
+// layer3.0 0.0563 -> 0.0552; 0.243 -> 0.236 with the whole file under it) but costs the other kernels of this file their occupancy (layer3.1 +6 us,
+// layer5.0's expand+dw +33 us: 74 -> 256 VGPRs), and the option is per translation unit.  bench.py: 52.29 -> 52.56 k img/s together with layer2.1.
+#define CF_MB2_ILP_INSTANCES(X) \
+    X(3, 2, 1, false, 4, 1, 32, 8, 16)  /* layer1.0 */ \
+    X(3, 2, 2, false, 4, 2, 32, 8, 16)  /* layer3.0 */
+#ifdef CF_ILP_TU
+#define CF_X(KS, S, NBO, RES, NW, JX, HC, TOH, TOW) template hipError_t mb2_launch_t<KS, S, NBO, RES, NW, JX, HC, TOH, TOW>(hipStream_t, const MbParams&);
+CF_MB2_ILP_INSTANCES(CF_X)
+#undef CF_X
+#else
+#define CF_X(KS, S, NBO, RES, NW, JX, HC, TOH, TOW) extern template hipError_t mb2_launch_t<KS, S, NBO, RES, NW, JX, HC, TOH, TOW>(hipStream_t, const MbParams&);
+CF_MB2_ILP_INSTANCES(CF_X)
+#undef CF_X
+#endif
+
+#ifndef CF_ILP_TU
 #define MB2(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW)                                                               \
     {KS, S, JX, HC, NBO, RES, TOH, TOW, NW, V, Px<KS, S, HC, TOH, TOW, JX, NW>::LDS, Px<KS, S, HC, TOH, TOW, JX, NW>::NT, \
      Px<KS, S, HC, TOH, TOW, JX, NW>::NPARW, Px<KS, S, HC, TOH, TOW, JX, NW>::NBE, Px<KS, S, HC, TOH, TOW, JX, NW>::HALF,  \
@@ -873,4 +893,5 @@ hipError_t mb2_launch(hipStream_t s, const MbParams& p) {
     return e->fn(s, p);
 }
 
+#endif  // !CF_ILP_TU
 }  // namespace cf

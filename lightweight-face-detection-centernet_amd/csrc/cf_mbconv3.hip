@@ -1200,6 +1200,7 @@ __global__ __launch_bounds__(256) void mbconv_mx2_kernel(MbParams p) {
         }
     }
 }
+#ifndef CF_ILP_TU        // expand+depthwise host side: main translation unit only
 
 // ---------------------------------------------------------------- host side
 struct MxEntry {
@@ -1358,12 +1359,13 @@ hipError_t mx_launch(hipStream_t s, const MbParams& p) {
 
 
 // ---------------------------------------------------------------- fused block, host side (MbGeom::kind = 5)
+#endif  // !CF_ILP_TU
 struct FxEntry {
     int k, jx, nmb, res, tail, toh, tow, nw, var, lds_bytes;
     hipError_t (*fn)(hipStream_t, const MbParams&);
 };
 template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, int NW, bool TAIL16, bool XRELOAD, bool ALDS, bool SB = false>
-static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
+hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
     typedef Fx<KS, JX, NMB, TOH, TOW, NW, TAIL16, ALDS> G;
     auto kfn = mbconv_mx_kernel<KS, JX, NMB, RESID, TOH, TOW, NW, TAIL16, XRELOAD, ALDS, SB>;
     static thread_local bool configured_dev[32] = {};
@@ -1383,6 +1385,22 @@ static hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, q);
     return hipGetLastError();
 }
+// layer2.1 is compiled in its own translation unit (cf_mbconv3_ilp.hip = this file with CF_ILP_TU defined) under
+// `-mllvm -amdgpu-sched-strategy=max-ilp`: 0.0806 -> 0.0792 ms (same box, two runs each); layer1.1 is unchanged by it (0.1799 / 0.1805) and
+// the same option costs mbconv_mx2_kernel a wave per SIMD (0.140 -> 0.159), and the option is per translation unit
+#define CF_FX_ILP_INSTANCES(X) \
+    X(5, 2, 2, true, 16, 16, 4, false, false, true)  /* layer2.1 */
+#ifdef CF_ILP_TU
+#define CF_X(KS, JX, NMB, RES, TOH, TOW, NW, TAIL, XR, AL) template hipError_t fx_launch_t<KS, JX, NMB, RES, TOH, TOW, NW, TAIL, XR, AL, false>(hipStream_t, const MbParams&);
+CF_FX_ILP_INSTANCES(CF_X)
+#undef CF_X
+#else
+#define CF_X(KS, JX, NMB, RES, TOH, TOW, NW, TAIL, XR, AL) extern template hipError_t fx_launch_t<KS, JX, NMB, RES, TOH, TOW, NW, TAIL, XR, AL, false>(hipStream_t, const MbParams&);
+CF_FX_ILP_INSTANCES(CF_X)
+#undef CF_X
+#endif
+
+#ifndef CF_ILP_TU
 template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, bool TAIL16>
 static hipError_t fz_launch_t(hipStream_t s, const MbParams& p) {
     typedef Fz<KS, JX, NMB, TOH, TOW, TAIL16> G;
@@ -1650,4 +1668,5 @@ hipError_t mx_fused2_launch(hipStream_t s, const MbParams& p) {
     return e->fn(s, p);
 }
 
+#endif  // !CF_ILP_TU
 }  // namespace cf
