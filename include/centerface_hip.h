@@ -53,6 +53,8 @@ extern "C" {
                                         instead of the fused kernel that keeps the 6x tensor in LDS */
 #define CF_FLAG_NO_UPHEAD       8u   /* keep the last IDAUp stage and the heads as two kernels (bf16 +
                                         collapsed heads fuse them, the neck output stays in LDS) */
+#define CF_FLAG_NO_NECK        16u   /* keep conv_last and the first two IDAUp stages as three kernels (bf16 fuses them
+                                        into one: the 1/32 and 1/16 neck maps stay in LDS) */
 
 typedef struct cf_ctx cf_ctx;
 

@@ -29,7 +29,7 @@ class Engine(object):
     """One cf_ctx: one GPU, one stream, fixed (H, W), batch up to ``max_batch``."""
 
     def __init__(self, height, width, max_batch=1, dtype="fp32", device=0, weights=None,
-                 collapse_heads=None, fuse=True, graph=True, uphead=True):
+                 collapse_heads=None, fuse=True, graph=True, uphead=True, neck=True):
         L = _lib.lib()
         if dtype not in _DTYPES:
             raise ValueError("dtype must be one of %s" % sorted(_DTYPES))
@@ -42,7 +42,8 @@ class Engine(object):
             # collapse_heads=False for the two-stage kernel that keeps the reference's operation order
             collapse_heads = True
         flags = ((_lib.CF_FLAG_COLLAPSE_HEADS if collapse_heads else 0) | (0 if fuse else _lib.CF_FLAG_NO_FUSE)
-                 | (0 if graph else _lib.CF_FLAG_NO_GRAPH) | (0 if uphead else _lib.CF_FLAG_NO_UPHEAD))
+                 | (0 if graph else _lib.CF_FLAG_NO_GRAPH) | (0 if uphead else _lib.CF_FLAG_NO_UPHEAD)
+                 | (0 if neck else _lib.CF_FLAG_NO_NECK))
         handle = C.c_void_p()
         _lib.check(L.cf_create(self.device, self.max_batch, self.H, self.W, _DTYPES[dtype], flags, C.byref(handle)))
         self._h = handle

@@ -212,6 +212,20 @@ struct UpHeadParams {
 };
 hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p);
 
+// conv_last + up1 + up2 as one kernel (cf_neck.hip, bf16): the 1/32 and 1/16 neck maps exist only in LDS
+struct NeckParams {
+    const void* x;        // layer6 output [B][h][w][320] bf16 (rows, or pixel-block order with x_blk)
+    const void* skip1;    // layer4 output [B][2h][2w][96]
+    const void* skip2;    // layer2 output [B][4h][4w][32]
+    int x_blk, skip1_blk, skip2_blk;
+    const void* w0; const float* b0;                                      // conv_last: pw_pack_weights(320 -> 24, BN folded), shift
+    const void* w1; const float* b1; const float* upw1; const float* upb1; // up1: conv (96 -> 24), [4][24] tap * scale, [24] shift
+    const void* w2; const float* b2; const float* upw2; const float* upb2; // up2: conv (32 -> 24)
+    void* y;              // up2 output [B][4h][4w][24] bf16 rows
+    int B, h, w;          // h, w: the 1/32 map
+};
+hipError_t launch_neck(hipStream_t s, const NeckParams& p);
+
 // ------------------------------------------------------------------ decode
 // D3: 3x3 peak test + top-K (radix select + bitonic sort) + gather: a multi-workgroup collect kernel + one select
 // workgroup per image (cf_decode.hip).

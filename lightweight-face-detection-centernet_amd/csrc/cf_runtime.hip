@@ -58,6 +58,8 @@ struct Op {
     // IDAUp stage 3 fused into the head kernel (cf_uphead.hip): the OP_PW op keeps its weights but is not
     // launched (fused_away); the OP_HEAD op launches the fused kernel with its partner's operands
     bool fused_away = false; int partner = -1;
+    int neck_cl = -1, neck_u1 = -1;                   // on the up2 op: conv_last and up1 are computed by its (fused) launch
+    bool neck_part = false;                           // conv_last / up1 when fused into up2's launch
     // expand+dw -> project pairs (bf16): the depthwise tensor between them is kept in pixel-block order
     // [m / 32][hid / 8][m % 32][8] (MbParams::yblock / PwParams::xblock): the project GEMM's activation loads coalesce
     // The same order for the block outputs of layer3.1 ... layer6.0 (layout_pass): in / out / res say which operands of
@@ -153,7 +155,8 @@ void layout_pass(cf_ctx* c) {
             if (r.in == buf && !(r.kind == OP_EXPDW || r.kind == OP_PW) ) ok = false;
             if (r.kind == OP_MB && r.in == buf) ok = false;
             if (r.kind == OP_HEAD && r.partner >= 0 && (ops[r.partner].in == buf || ops[r.partner].low == buf)) ok = false;
-            if (r.fused_away && (r.in == buf || r.low == buf)) ok = false;          // read by the fused up3+heads kernel
+            if (r.fused_away && !r.neck_part && (r.in == buf || r.low == buf)) ok = false;          // read by the fused up3+heads kernel
+            if (r.neck_part && r.low == buf) ok = false;                                             // (the fused neck kernel reads either order)
         }
         if (!ok) continue;
         pr.out_blk = true;
@@ -291,6 +294,21 @@ void build_plan(cf_ctx* c) {
         c->ops[ih].partner = iu;
         c->ops[ih].name = "up3+heads";
         c->ops[ih].macs += c->ops[iu].macs;
+    }
+    if (fuse && !(c->flags & CF_FLAG_NO_NECK) && c->dtype == CF_BF16 && cin == 320) {
+        int icl = -1, iu1 = -1, iu2 = -1;
+        for (size_t i = 0; i < c->ops.size(); ++i) {
+            if (c->ops[i].name == "conv_last") icl = (int)i;
+            if (c->ops[i].name == "up1") iu1 = (int)i;
+            if (c->ops[i].name == "up2") iu2 = (int)i;
+        }
+        if (icl >= 0 && iu1 == icl + 1 && iu2 == iu1 + 1 && c->ops[iu1].Cin == 96 && c->ops[iu2].Cin == 32) {
+            c->ops[icl].fused_away = c->ops[iu1].fused_away = true;
+            c->ops[icl].neck_part = c->ops[iu1].neck_part = true;
+            c->ops[iu2].neck_cl = icl; c->ops[iu2].neck_u1 = iu1;
+            c->ops[iu2].name = "conv_last+up1+up2";
+            c->ops[iu2].macs += c->ops[icl].macs + c->ops[iu1].macs;
+        }
     }
     layout_pass(c);
 }
@@ -689,6 +707,16 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
         p.w0p = op.wp; p.b0 = op.bias; p.heads = (float*)bp(op.out); p.hm_plane = c->hm_plane; p.B = B; p.h = op.Hout; p.w = op.Wout;
         return launch_uphead(c->stream, p);
     }
+    if (op.neck_cl >= 0) {
+        const Op& cl = c->ops[op.neck_cl]; const Op& u1 = c->ops[op.neck_u1];
+        NeckParams p{}; p.x = bp(cl.in); p.skip1 = bp(u1.in); p.skip2 = bp(op.in);
+        p.x_blk = cl.in_blk ? 1 : 0; p.skip1_blk = u1.in_blk ? 1 : 0; p.skip2_blk = op.in_blk ? 1 : 0;
+        p.w0 = cl.wp; p.b0 = cl.bias;
+        p.w1 = u1.wp; p.b1 = u1.bias; p.upw1 = u1.upw; p.upb1 = u1.upb;
+        p.w2 = op.wp; p.b2 = op.bias; p.upw2 = op.upw; p.upb2 = op.upb;
+        p.y = bp(op.out); p.B = B; p.h = cl.Hout; p.w = cl.Wout;
+        return launch_neck(c->stream, p);
+    }
     switch (op.kind) {
         case OP_STEM: {
             StemParams p{}; p.x = net_in; p.in_format = in_format; p.w = op.wp; p.y = bp(op.out);
@@ -741,6 +769,11 @@ double op_bytes(const cf_ctx* c, const Op& op, int in_format, int B) {
     if (op.kind == OP_HEAD) out_b = (double)op.Hout * op.Wout * 16 * 4;
     else out_b = (double)op.Hout * op.Wout * op.Cout * es;
     if (op.kind == OP_HEAD && op.partner >= 0) in_b += (double)(op.Hout / 2) * (op.Wout / 2) * 24 * es;   // + the low IDAUp input
+    if (op.neck_cl >= 0) {                                   // fused neck: layer6 + layer4 skip + layer2 skip in, up2 out (no low input from HBM)
+        const Op& cl = c->ops[op.neck_cl]; const Op& u1 = c->ops[op.neck_u1];
+        in_b += (double)cl.Hin * cl.Win * cl.Cin * es + (double)u1.Hin * u1.Win * u1.Cin * es;
+        return (in_b + out_b) * B;
+    }
     if (op.res >= 0) in_b += (double)op.Hout * op.Wout * op.Cout * es;
     if (op.low >= 0) in_b += (double)(op.Hout / 2) * (op.Wout / 2) * op.Cout * es;
     return (in_b + out_b) * B;

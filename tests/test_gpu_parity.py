@@ -803,6 +803,31 @@ def test_variable_size_buckets_product_configuration_128_images():
     pool.close()
 
 
+@pytest.mark.parametrize("size,B", [((96, 128), 3), ((160, 224), 2), ((352, 640), 2), ((32, 32), 1), ((64, 416), 2)])
+def test_fused_neck_bit_equal_to_three_kernels(size, B):
+    """cf_neck.hip (conv_last + up1 + up2 as one launch, the 1/32 and 1/16 maps only in LDS) performs the same arithmetic in the
+    same order as three pw_kernel launches: the up2 tensor and everything after it are bit-identical (maps that are not multiples
+    of the 2x4-cell tile, a one-cell map, batches)."""
+    H, W = size
+    rng = np.random.default_rng(H * 7 + W)
+    x = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    ef = cfa.Engine(H, W, max_batch=B, dtype="bf16", neck=True)
+    e3 = cfa.Engine(H, W, max_batch=B, dtype="bf16", neck=False)
+    pf, p3 = ef.plan(), e3.plan()
+    assert [o["name"] for o in pf if not o["fused_away"]].count("conv_last+up1+up2") == 1
+    assert any(o["name"] == "conv_last" and not o["fused_away"] for o in p3)
+    i_f = [o["index"] for o in pf if o["name"] == "conv_last+up1+up2"][0]
+    i_3 = [o["index"] for o in p3 if o["name"] == "up2"][0]
+    assert np.array_equal(ef.trace(x, i_f), e3.trace(x, i_3))
+    ef.forward_enqueue(x); e3.forward_enqueue(x)
+    hf, h3 = ef.heads(), e3.heads()
+    for k in hf:
+        assert np.array_equal(hf[k], h3[k]), k
+    for a, b2 in zip(ef.decode_topk(20), e3.decode_topk(20)):
+        assert np.array_equal(a, b2)
+    ef.close(); e3.close()
+
+
 @pytest.mark.parametrize("size", [(96, 128), (160, 224), (352, 640)])
 def test_fused_up3_heads_bit_equal_to_two_kernels(size):
     """cf_uphead.hip (last IDAUp stage + collapsed heads, neck output only in LDS) performs the same arithmetic
