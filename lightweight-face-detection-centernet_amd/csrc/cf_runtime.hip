@@ -295,7 +295,8 @@ void build_plan(cf_ctx* c) {
         c->ops[ih].name = "up3+heads";
         c->ops[ih].macs += c->ops[iu].macs;
     }
-    if (fuse && !(c->flags & CF_FLAG_NO_NECK) && c->dtype == CF_BF16 && cin == 320) {
+    static const bool neck_off = getenv("CF_NECK") && atoi(getenv("CF_NECK")) == 0;      // A/B
+    if (fuse && !neck_off && !(c->flags & CF_FLAG_NO_NECK) && c->dtype == CF_BF16 && cin == 320) {
         int icl = -1, iu1 = -1, iu2 = -1;
         for (size_t i = 0; i < c->ops.size(); ++i) {
             if (c->ops[i].name == "conv_last") icl = (int)i;
