@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
         }
     };
 #ifdef CF_ABLATION
-    const int abl = p.nw;            // timing experiments only (-DCF_ABLATION, CF_MX_ABL): 1 no depthwise MFMAs, 2 no output Swish, 4 no expand Swish, 8 one X load, 16 no stores
+    const int abl = p.nw;            // timing experiments only (-DCF_ABLATION, CF_MX_ABL): 1 no depthwise MFMAs, 2 no output Swish, 4 no expand Swish, 8 one X load, 16 no stores, 32 stores as 1 KB runs
 #else
     constexpr int abl = 0;           // (the run-time tests cost the production kernel 4-7 %: compiled out)
 #endif
@@ -203,6 +203,11 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
             o.x = packb(acc[0][i], acc[1][i]); o.y = packb(acc[2][i], acc[3][i]);
             o.z = packb(acc[4][i], acc[5][i]); o.w = packb(acc[6][i], acc[7][i]);
             const size_t opix = opix0 + i;
+            if (abl & 32) {         // timing experiment (results invalid): the same bytes, 1 KB of consecutive addresses per store instruction
+                const size_t region = (((size_t)b * gridDim.x + blockIdx.x) * gridDim.y + grp) * (size_t)(TOH * TOW * 64);
+                st16((char*)p.y + region + ((size_t)((set * 4 + i) * 1024 + lane * 16)) % (size_t)(TOH * TOW * 64), o);
+                continue;
+            }
             st16((char*)p.y + (p.yblock ? blk_off(opix, p.hid / 8, chunk) : (opix * p.hid + (size_t)chunk * 8) * 2), o);
         }
     }
