@@ -67,6 +67,9 @@ def parse(argv=None):
     ap.add_argument("--gather-timeout", type=float, default=60.0,
                     help="seconds the first (warm-up) RCCL gather may take; on expiry on ANY rank every rank aborts its communicator "
                          "and the run continues with --gather torch --depth 1 (agreed over the TCP store, not over NCCL)")
+    ap.add_argument("--debug-stall-gather-ms", type=int, default=0,
+                    help="test hook: park the rank's gather stream behind a spin kernel of this many ms before the warm-up gather "
+                         "(a first collective that does not complete in time; tests/test_multigpu.py)")
     ap.add_argument("--exercise-gather-path", action="store_true",
                     help="run the N>1 step (decode-stream gather, identity at world 1) on one GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -316,6 +319,10 @@ def main():
                 fallback = "cf_comm_create failed on some rank"
             else:
                 try:
+                    if args.debug_stall_gather_ms > 0:
+                        comms[0].debug(0, args.debug_stall_gather_ms)
+                    # cf_gather_topk(out_on_device=1) never waits on the host (the shard agreement in front of every gather is
+                    # checked on the device and reported by query()), so the FIRST RCCL collective too is only ever polled
                     for e, o in zip(engs, outs):               # warm-up gather of every context, in step order
                         e.forward_enqueue(d_in.data_ptr(), on_device=True, B=B, in_format=cfa._lib.CF_IN_U8_HWC_BGR)
                         comms[0].gather_topk_device(K, o["all"].data_ptr(), engine=e)
@@ -513,7 +520,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:                # rank 0, every N: the other ranks have left by now and the host cores are idle
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds, S, K, host_imgs)
         else:
             result["cpu_baseline"] = None

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -381,6 +382,21 @@ int expect_bn(cf_ctx* c, const WeightSet& ws, const std::string& pre, int C) {
 __global__ void cf_spin_kernel(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) { }
+}
+
+// shard agreement of cf_gather_topk: publish this rank's (B, K) ...
+__global__ void cf_comm_publish_kernel(int* mine, int B, int K) { mine[0] = B; mine[1] = K; }
+// ... and, behind the all-gather of those pairs, compare every rank's against ours; a mismatch is latched in host-visible memory
+__global__ void cf_comm_compare_kernel(const int* all, int world, int B, int K, int* flag) {
+    if (threadIdx.x != 0 || flag[0]) return;
+    for (int r = 0; r < world; ++r)
+        if (all[2 * r] != B || all[2 * r + 1] != K) {
+            flag[1] = r; flag[2] = all[2 * r]; flag[3] = all[2 * r + 1]; flag[4] = B; flag[5] = K;
+            __threadfence_system();
+            flag[0] = 1;
+            __threadfence_system();
+            return;
+        }
 }
 
 // One host-to-device copy stream per DEVICE, shared by every context on it.  Two contexts with a copy stream each
@@ -1528,7 +1544,12 @@ struct cf_comm {
     hipStream_t stream = nullptr;                       // THE gather stream of this rank: every all-gather of every context goes here, in call order
     hipEvent_t ev_done = nullptr;                       // recorded after the last enqueued all-gather (cf_comm_query / _synchronize)
     float* recv = nullptr; size_t recv_elems = 0;       // staging for host destinations
-    int* d_chk = nullptr; int checked_B = -1;           // batch-size agreement check (one int per rank), last B verified
+    // shard agreement (B, K of every rank), checked on EVERY gather by a device-side compare behind a 2-int all-gather: the
+    // decision to issue that collective never depends on per-rank state, and the host never waits for it
+    int* d_chk = nullptr;                               // [world][2] gathered (B, K) + [2] this rank's pair
+    int* h_flag = nullptr; int* d_flag = nullptr;       // pinned + mapped: {mismatch seen, peer rank, peer B, peer K, my B, my K} (sticky)
+    hipEvent_t ev_chk = nullptr;                        // behind the compare kernel (blocking gathers wait for it)
+    int debug_skew = 0;                                 // cf_comm_debug(1, v): the next gather publishes B + v (tests of the mismatch path)
     std::string err;
 };
 
@@ -1576,7 +1597,11 @@ int comm_resources(cf_ctx* c, cf_comm* m) {
     HIPCHK(c, hipSetDevice(m->device));
     HIPCHK(c, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
-    HIPCHK(c, hipMalloc((void**)&m->d_chk, (size_t)(m->world + 1) * sizeof(int)));
+    HIPCHK(c, hipEventCreateWithFlags(&m->ev_chk, hipEventDisableTiming));
+    HIPCHK(c, hipMalloc((void**)&m->d_chk, (size_t)(m->world + 1) * 2 * sizeof(int)));
+    HIPCHK(c, hipHostMalloc((void**)&m->h_flag, 8 * sizeof(int), hipHostMallocMapped));
+    memset(m->h_flag, 0, 8 * sizeof(int));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&m->d_flag, m->h_flag, 0));
     return CF_OK;
 }
 
@@ -1650,8 +1675,10 @@ int cf_comm_destroy(cf_comm* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     if (m->recv) hipFree(m->recv);
     if (m->d_chk) hipFree(m->d_chk);
+    if (m->h_flag) hipHostFree(m->h_flag);
     if (m->comm) rccl()->CommDestroy(m->comm);
     if (m->ev_done) hipEventDestroy(m->ev_done);
+    if (m->ev_chk) hipEventDestroy(m->ev_chk);
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
     return CF_OK;
@@ -1666,23 +1693,56 @@ int cf_comm_abort(cf_comm* m) {
     return cf_comm_destroy(m);
 }
 
-// 0: every enqueued gather has completed, 1: still running, < 0: error.  Never blocks.
+// the latched verdict of the device-side shard comparison (cf_gather_topk): CF_EINVAL + text once any gather saw unequal shards
+static int comm_mismatch(cf_comm* m) {
+    volatile int* f = m->h_flag;
+    if (!f || !f[0]) return CF_OK;
+    char buf[256];
+    snprintf(buf, sizeof buf, "cf_gather_topk: rank %d has (B=%d, K=%d), rank %d has (B=%d, K=%d) -- the gather needs equal shards (pad the last one)",
+             m->rank, f[4], f[5], f[1], f[2], f[3]);
+    m->err = buf;
+    return CF_EINVAL;
+}
+
+// 0: every enqueued gather has completed, 1: still running, < 0: error (CF_EINVAL: a gather saw unequal shards on the ranks --
+// reported as soon as the 2-int agreement collective in front of it has run, whether or not the record gather behind it
+// ever completes).  Never blocks.
 int cf_comm_query(cf_comm* m) {
     if (!m) return CF_EINVAL;
     hipSetDevice(m->device);
+    int mm = comm_mismatch(m); if (mm) return mm;
     hipError_t e = hipStreamQuery(m->stream);
-    if (e == hipSuccess) return 0;
+    if (e == hipSuccess) return comm_mismatch(m);
     if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
     m->err = std::string("hipStreamQuery: ") + hipGetErrorString(e);
     return CF_EHIP;
 }
 
+// Waits for the gather stream by POLLING, so that a latched shard mismatch ends the wait even when the record gather behind
+// it hangs (unequal counts): CF_EINVAL then, and cf_comm_abort is the way out.
 int cf_comm_synchronize(cf_comm* m) {
     if (!m) return CF_EINVAL;
+    for (unsigned spins = 0;; ++spins) {
+        int q = cf_comm_query(m);
+        if (q <= 0) return q;
+        if (spins > 200) usleep(20);
+    }
+}
+
+const char* cf_comm_last_error(cf_comm* m) { return m ? m->err.c_str() : "null communicator"; }
+
+// Test hooks.  what = 0: park the gather stream behind a spin kernel of `value` milliseconds (a collective that does not
+// complete in time, for the deadline tests); what = 1: the next gather publishes B + value (the mismatch path at world 1).
+int cf_comm_debug(cf_comm* m, int what, int value) {
+    if (!m) return CF_EINVAL;
     hipSetDevice(m->device);
-    hipError_t e = hipStreamSynchronize(m->stream);
-    if (e != hipSuccess) { m->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); return CF_EHIP; }
-    return CF_OK;
+    if (what == 0) {
+        if (value < 0 || value > 60000) return CF_EINVAL;
+        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, m->stream, (long long)value * 100000LL);
+        return hipGetLastError() == hipSuccess ? CF_OK : CF_EHIP;
+    }
+    if (what == 1) { m->debug_skew = value; return CF_OK; }
+    return CF_EINVAL;
 }
 
 void* cf_comm_stream(cf_comm* m) { return m ? (void*)m->stream : nullptr; }
@@ -1697,19 +1757,33 @@ int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, in
     HIPCHK(c, hipSetDevice(c->device));
     int r = ensure_topk_ws(c, K); if (r) return r;
     if (!c->ev_gather) HIPCHK(c, hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
-    // ncclAllGather takes ONE count for all ranks: ranks with different batch sizes would hang or mis-place records without
-    // any error.  The first gather at a new B all-gathers the B of every rank and compares (one extra small collective + sync).
-    if (m->checked_B != B) {
-        std::vector<int> hb(m->world + 1, 0);
-        hb[m->world] = B;
-        HIPCHK(c, hipMemcpyAsync(m->d_chk + m->world, &hb[m->world], sizeof(int), hipMemcpyHostToDevice, m->stream));
-        ncclResult_t e = rccl()->AllGather(m->d_chk + m->world, m->d_chk, 1, ncclInt32, m->comm, m->stream);
-        if (e != ncclSuccess) return c->fail(CF_EHIP, "ncclAllGather (batch-size check): %s", rccl()->GetErrorString(e));
-        HIPCHK(c, hipMemcpyAsync(hb.data(), m->d_chk, (size_t)m->world * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(c, hipStreamSynchronize(m->stream));
-        for (int i = 0; i < m->world; ++i)
-            if (hb[i] != B) return c->fail(CF_EINVAL, "cf_gather_topk: rank %d has batch %d, rank %d has %d -- the gather needs equal shards (pad the last one)", m->rank, B, i, hb[i]);
-        m->checked_B = B;
+    { int mm = comm_mismatch(m); if (mm) return c->fail(CF_EINVAL, "%s", m->err.c_str()); }
+    // ncclAllGather takes ONE count for all ranks: ranks with different shards would hang or mis-place records without any
+    // error.  EVERY gather is therefore preceded, on the gather stream, by an all-gather of each rank's (B, K) and a device-side
+    // compare that latches a mismatch in host-visible memory.  Rank-invariant (no rank decides from local state whether to issue
+    // the extra collective, so the collective sequence is identical everywhere) and asynchronous (the host never waits for it:
+    // cf_comm_query / cf_comm_synchronize / the next cf_gather_topk report the latch).
+    {
+        int* mine = m->d_chk + 2 * m->world;
+        hipLaunchKernelGGL(cf_comm_publish_kernel, dim3(1), dim3(1), 0, m->stream, mine, B + m->debug_skew, K);
+        m->debug_skew = 0;
+        HIPCHK(c, hipGetLastError());
+        ncclResult_t e = rccl()->AllGather(mine, m->d_chk, 2, ncclInt32, m->comm, m->stream);
+        if (e != ncclSuccess) return c->fail(CF_EHIP, "ncclAllGather (shard agreement): %s", rccl()->GetErrorString(e));
+        hipLaunchKernelGGL(cf_comm_compare_kernel, dim3(1), dim3(64), 0, m->stream, (const int*)m->d_chk, m->world, B, K, m->d_flag);
+        HIPCHK(c, hipGetLastError());
+        if (!out_on_device) {
+            // the blocking form may wait: the verdict is known before the record gather is enqueued
+            HIPCHK(c, hipEventRecord(m->ev_chk, m->stream));
+            for (unsigned spins = 0;; ++spins) {
+                hipError_t q = hipEventQuery(m->ev_chk);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return c->fail(CF_EHIP, "hipEventQuery (shard agreement): %s", hipGetErrorString(q));
+                (void)hipGetLastError();
+                if (spins > 200) usleep(20);
+            }
+            int mm = comm_mismatch(m); if (mm) return c->fail(CF_EINVAL, "%s", m->err.c_str());
+        }
     }
     const size_t n = (size_t)B * K * 16;
     float* dst = records;

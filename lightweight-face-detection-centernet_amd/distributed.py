@@ -65,20 +65,33 @@ def unique_id():
     return bytes(buf.raw)
 
 
-_uid_calls = 0
+_calls = {}
+
+
+def _group_tag(group):
+    """Key namespace of a process group: the global ranks of its members (two disjoint subgroups bootstrapping at the same
+    time must not share store keys) + a per-namespace call counter (a second call must not read the first one's values)."""
+    import torch.distributed as dist
+    ranks = list(range(dist.get_world_size())) if group is None else [int(r) for r in dist.get_process_group_ranks(group)]
+    return "g" + "_".join(str(r) for r in ranks)
+
+
+def _next_key(prefix):
+    n = _calls.get(prefix, 0)
+    _calls[prefix] = n + 1
+    return "%s/%d" % (prefix, n)
 
 
 def broadcast_unique_id(src=0, group=None, store=None):
-    """Rank ``src`` creates the id, every rank of the (initialised) torch.distributed group receives it -- through the
-    group's key-value store (TCP), not through a collective: no NCCL communicator has to exist (or work) for the bootstrap of
-    this one.  Collective in the sense that every rank must call it the same number of times (the key carries a call counter)."""
-    global _uid_calls
+    """Rank ``src`` (a rank OF ``group``, group-relative like torch.distributed.broadcast's ``group_src``) creates the id,
+    every rank of the (initialised) torch.distributed group receives it -- through the key-value store (TCP), not through a
+    collective: no NCCL communicator has to exist (or work) for the bootstrap of this one.  Collective in the sense that every
+    rank of the group must call it the same number of times (the key carries the group's ranks and a call counter)."""
     import torch.distributed as dist
-    del group                                        # the default store serves every group of the process
     store = store or dist.distributed_c10d._get_default_store()
-    key = "cf_comm_uid/%d" % _uid_calls
-    _uid_calls += 1
-    if dist.get_rank() == src:
+    key = _next_key("cf_comm_uid/" + _group_tag(group))
+    src_global = int(src) if group is None else int(dist.get_global_rank(group, int(src)))
+    if dist.get_rank() == src_global:
         try:
             uid = unique_id()
         except Exception:
@@ -138,8 +151,17 @@ class Comm(object):
         """True while an enqueued gather is still running (never blocks)."""
         r = _lib.lib().cf_comm_query(self._h)
         if r < 0:
-            raise RuntimeError("cf_comm_query failed (%d)" % r)
+            raise RuntimeError("cf_comm_query failed (%d): %s" % (r, self.last_error()))
         return r == 1
+
+    def last_error(self):
+        return (_lib.lib().cf_comm_last_error(self._h) or b"").decode()
+
+    def debug(self, what, value):
+        """Test hooks of ``cf_comm_debug``: (0, ms) parks the gather stream behind a spin kernel, (1, d) skews the B the next
+        gather publishes in its agreement step."""
+        if _lib.lib().cf_comm_debug(self._h, int(what), int(value)) != 0:
+            raise RuntimeError("cf_comm_debug(%d, %d) failed" % (what, value))
 
     def wait(self, timeout_s, poll_s=0.002):
         """Poll ``query`` until the gather stream is idle; False if it is still busy after ``timeout_s`` seconds
@@ -153,8 +175,9 @@ class Comm(object):
         return True
 
     def synchronize(self):
-        if _lib.lib().cf_comm_synchronize(self._h) != 0:
-            raise RuntimeError("cf_comm_synchronize failed")
+        r = _lib.lib().cf_comm_synchronize(self._h)
+        if r != 0:
+            raise RuntimeError("cf_comm_synchronize failed (%d): %s" % (r, self.last_error()))
 
     def stream(self):
         return int(_lib.lib().cf_comm_stream(self._h) or 0)
@@ -179,10 +202,12 @@ class Comm(object):
 
 def agree(ok, rank, world, key, store=None):
     """Every rank publishes ``ok`` under ``key`` in the torch.distributed key-value store (TCP, NOT a NCCL collective: it
-    works while a RCCL collective is hung) and reads everybody's: True only if all ranks said ok."""
+    works while a RCCL collective is hung) and reads everybody's: True only if all ranks said ok.  Every rank must call it the
+    same number of times per key (the store keys carry a call counter, so a repeat never reads an earlier call's verdicts)."""
     if world == 1:
         return bool(ok)
     import torch.distributed as dist
     store = store or dist.distributed_c10d._get_default_store()
-    store.set("%s/%d" % (key, rank), b"1" if ok else b"0")
-    return all(store.get("%s/%d" % (key, r)) == b"1" for r in range(world))
+    k = _next_key("cf_agree/%s/w%d" % (key, world))
+    store.set("%s/%d" % (k, rank), b"1" if ok else b"0")
+    return all(store.get("%s/%d" % (k, r)) == b"1" for r in range(world))

@@ -32,6 +32,13 @@ u1 = cfa.distributed.broadcast_unique_id(); u2 = cfa.distributed.broadcast_uniqu
 assert u1 == bytes([7]) * 128 == u2 and len(u1) == cfa.distributed.COMM_ID_BYTES
 assert cfa.distributed.agree(1, rank, world, "t_ok") is True
 assert cfa.distributed.agree(1 if rank == 0 else 0, rank, world, "t_bad") is False
+# the same key again: a second call must not read the first call's verdicts (keys carry a call counter)
+assert cfa.distributed.agree(0, rank, world, "t_ok") is False
+assert cfa.distributed.agree(1, rank, world, "t_ok") is True
+# a subgroup with a group-relative source rank: keys are namespaced by the group's ranks, src is translated
+g = dist.new_group([0, 1])
+u3 = cfa.distributed.broadcast_unique_id(src=1, group=g)
+assert u3 == bytes([8]) * 128, u3[:4]
 dist.barrier()
 dist.destroy_process_group()
 print("rank %%d ok" %% rank)

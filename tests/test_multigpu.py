@@ -157,6 +157,70 @@ def test_bench_gather_fallback_records_the_path():
     assert d["config"]["gather_fallback"] is None and "cf_gather_topk" in d["config"]["gather"] and d["config"]["contexts_per_gpu"] == 2
 
 
+def test_bench_first_gather_deadline_covers_the_first_collective():
+    """The very first RCCL collective of a run is the warm-up gather of bench.py.  With the rank's gather stream parked behind a
+    6 s spin kernel and --gather-timeout 1.5 the run must reach the fallback (polled, agreed, aborted) instead of blocking inside
+    cf_gather_topk: the shard agreement in front of the gather is asynchronous."""
+    import json
+    import time
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--repeats", "2",
+                          "--batch", "4", "--size", "160", "--topk", "20", "--no-cpu-baseline", "--no-extras", "--profile-reps", "1",
+                          "--exercise-gather-path", "--gather-timeout", "1.5", "--debug-stall-gather-ms", "6000"],
+                         capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["config"]["gather_fallback"] and "did not complete" in d["config"]["gather_fallback"]
+    assert "torch.distributed" in d["config"]["gather"] and d["config"]["contexts_per_gpu"] == 1
+    assert time.perf_counter() - t0 < 120
+
+
+def test_gather_is_asynchronous_and_latches_a_shard_mismatch():
+    """cf_gather_topk(out_on_device=1) returns while the gather stream is parked (no host wait on its agreement collective);
+    a (B, K) mismatch between ranks -- forced here by skewing the B this rank publishes -- is latched by the device-side
+    compare and reported by query / synchronize / the next gather, for the blocking form before the record gather is enqueued."""
+    import time
+    import torch
+    S, B, K = 96, 3, 20
+    imgs = np.random.default_rng(17).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    eng = cfa.Engine(S, S, max_batch=B, dtype="bf16")
+    comm = cfa.distributed.Comm(eng, 0, 1, cfa.distributed.unique_id())
+    out = torch.zeros((B, K, 16), dtype=torch.float32, device="cuda:0")
+    eng.forward_enqueue(imgs)
+    comm.gather_topk_device(K, out.data_ptr())          # warm-up (loads RCCL kernels)
+    assert comm.wait(60.0)
+    want = out.cpu().numpy().copy()
+    comm.debug(0, 1500)                                  # park the gather stream for 1.5 s
+    t0 = time.perf_counter()
+    eng.forward_enqueue(imgs)
+    comm.gather_topk_device(K, out.data_ptr())
+    dt = time.perf_counter() - t0
+    assert dt < 0.75, "cf_gather_topk waited %.2f s on the host behind a parked gather stream" % dt
+    assert comm.query()                                  # still running
+    assert comm.wait(30.0)
+    assert np.array_equal(out.cpu().numpy(), want)
+    # mismatch, asynchronous form: latched, reported by query and by synchronize and by the next gather
+    comm.debug(1, 1)
+    eng.forward_enqueue(imgs)
+    comm.gather_topk_device(K, out.data_ptr())
+    with pytest.raises(RuntimeError, match="equal shards"):
+        comm.wait(30.0)
+    with pytest.raises(RuntimeError, match="equal shards"):
+        comm.synchronize()
+    with pytest.raises((RuntimeError, ValueError), match="equal shards"):
+        comm.gather_topk_device(K, out.data_ptr())
+    comm.abort()
+    # blocking form on a fresh communicator: CF_EINVAL from the call itself
+    comm = cfa.distributed.Comm(eng, 0, 1, cfa.distributed.unique_id())
+    eng.forward_enqueue(imgs)
+    assert np.array_equal(comm.gather_topk(K), want)
+    comm.debug(1, -1)
+    with pytest.raises((RuntimeError, ValueError), match="equal shards"):
+        comm.gather_topk(K)
+    comm.abort()
+    eng.close()
+
+
 def test_engine_ring_matches_single_engine_bitwise():
     """EngineRing: batches submitted back to back on alternating contexts, collected out of order, different batch sizes
     and K -- every result equals the single-engine result of the same batch."""
