@@ -344,6 +344,13 @@ int cf_op_ctdet_post_process(int device, float* dets, const float* centers, cons
 /* CenterFace.nms alone (centerface.py:111-151): keep[] receives kept indices in keep order. */
 int cf_op_nms(int device, const float* boxes, const float* scores, int n, float nms_thresh,
               int32_t* keep, int32_t* n_keep);
+/* bbox_overlap (eval_widerface.py:48-74: the "+1" IoU of every detection against every annotation, float32 arithmetic as numpy
+ * computes it for float32 inputs) and the two counts evaluate (:195-206) takes from it, for n_img images in one call: rows of
+ * box_stride / query_stride floats (x1,y1,x2,y2 first), concatenated; box_off / query_off [n_img + 1] = first row of each image.
+ * overlaps (optional): the dense [N_i][K_i] float64 matrices back to back.  counts (optional) [n_img][2]: detections whose best
+ * overlap exceeds thresh (evaluate's "detected_num"), annotations whose best overlap does ("true_positives"). */
+int cf_op_box_match(int device, int n_img, const float* boxes, int box_stride, const int32_t* box_off, const float* query,
+                    int query_stride, const int32_t* query_off, float thresh, double* overlaps, int32_t* counts);
 
 #ifdef __cplusplus
 }

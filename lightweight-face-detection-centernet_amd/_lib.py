@@ -24,7 +24,7 @@ EXPORTS = (
     "cf_detect_topk", "cf_synchronize", "cf_event_record", "cf_event_elapsed_ms",
     "cf_profile_forward", "cf_plan_size", "cf_plan_op", "cf_forward_trace", "cf_graph_stats", "cf_get_streams", "cf_streams_share_queue", "cf_reroll_streams", "cf_ctdet_loss", "cf_comm_unique_id", "cf_comm_create", "cf_comm_create_all", "cf_comm_destroy", "cf_comm_abort", "cf_comm_query", "cf_comm_synchronize", "cf_comm_last_error", "cf_comm_debug", "cf_comm_stream", "cf_gather_topk", "cf_host_alloc", "cf_host_free", "cf_device_alloc", "cf_device_free", "cf_memcpy_h2d", "cf_memcpy_d2h",
     "cf_op_last_error", "cf_op_shufflev2", "cf_op_mbconv", "cf_op_expand_dw", "cf_op_ctdet_loss", "cf_op_encode_targets", "cf_op_dwconv", "cf_op_pwconv", "cf_op_stem", "cf_op_idaup", "cf_op_heads",
-    "cf_op_ctdet_decode", "cf_op_ctdet_post_process", "cf_op_decode_threshold", "cf_op_decode_threshold_ex", "cf_op_nms",
+    "cf_op_ctdet_decode", "cf_op_ctdet_post_process", "cf_op_decode_threshold", "cf_op_decode_threshold_ex", "cf_op_nms", "cf_op_box_match",
 )
 
 
@@ -138,6 +138,7 @@ def lib():
         L.cf_op_ctdet_decode.argtypes = [i, fp, fp, fp, fp, i, i, i, i, fp, fp, vp]
         L.cf_op_decode_threshold.argtypes = [i, fp, fp, fp, i, i, i, i, i, C.c_float, C.c_float, i, fp, fp, vp]
         L.cf_op_nms.argtypes = [i, fp, fp, i, C.c_float, vp, vp]
+        L.cf_op_box_match.argtypes = [i, i, fp, i, vp, fp, i, vp, C.c_float, vp, vp]
         _lib = L
     return _lib
 

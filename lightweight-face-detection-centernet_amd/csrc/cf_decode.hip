@@ -693,6 +693,56 @@ hipError_t launch_affine_boxes(hipStream_t s, float* dets, const double* trans, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- box match (eval_widerface.py:48-74, 172-211)
+// bbox_overlap's "+1" IoU between the detections of an image and its annotations, in the arithmetic numpy gives float32
+// inputs (every operation rounded to float32, no contraction; the quotient is a float32 division under NumPy >= 2, where
+// the python-float union is a weak scalar), and the two counts `evaluate` derives from it: rows (detections) whose best
+// overlap exceeds the threshold, columns (annotations) whose best overlap does.  One workgroup per image.
+__device__ __forceinline__ float overlap_pair(const float* b, const float* q, float qarea) {
+    const float iw = (fminf(b[2], q[2]) - fmaxf(b[0], q[0])) + 1.0f;
+    if (!(iw > 0.0f)) return 0.0f;
+    const float ih = (fminf(b[3], q[3]) - fmaxf(b[1], q[1])) + 1.0f;
+    if (!(ih > 0.0f)) return 0.0f;
+    const float ua = ((((b[2] - b[0]) + 1.0f) * ((b[3] - b[1]) + 1.0f)) + qarea) - iw * ih;
+    return (iw * ih) / ua;
+}
+__global__ __launch_bounds__(256) void box_match_kernel(OverlapParams p) {
+    const int img = blockIdx.x;
+    const int n0 = p.box_off[img], n1 = p.box_off[img + 1], k0 = p.query_off[img], k1 = p.query_off[img + 1];
+    const int N = n1 - n0, K = k1 - k0;
+    const float* B = p.boxes + (size_t)n0 * p.box_stride;
+    const float* Q = p.query + (size_t)k0 * p.query_stride;
+    int rows = 0, cols = 0;
+    for (int n = threadIdx.x; n < N; n += 256) {             // a detection against every annotation
+        const float* b = B + (size_t)n * p.box_stride;
+        float best = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float* q = Q + (size_t)k * p.query_stride;
+            const float qa = ((q[2] - q[0]) + 1.0f) * ((q[3] - q[1]) + 1.0f);
+            const float ov = overlap_pair(b, q, qa);
+            if (p.overlaps) p.overlaps[p.overlaps_off[img] + (size_t)n * K + k] = (double)ov;
+            best = fmaxf(best, ov);
+        }
+        rows += (K > 0 && best > p.thresh) ? 1 : 0;
+    }
+    if (p.counts) {
+        for (int k = threadIdx.x; k < K; k += 256) {         // an annotation against every detection
+            const float* q = Q + (size_t)k * p.query_stride;
+            const float qa = ((q[2] - q[0]) + 1.0f) * ((q[3] - q[1]) + 1.0f);
+            float best = 0.0f;
+            for (int n = 0; n < N; ++n) best = fmaxf(best, overlap_pair(B + (size_t)n * p.box_stride, q, qa));
+            cols += (N > 0 && best > p.thresh) ? 1 : 0;
+        }
+        if (rows) atomicAdd(&p.counts[2 * img], rows);
+        if (cols) atomicAdd(&p.counts[2 * img + 1], cols);
+    }
+}
+hipError_t launch_box_match(hipStream_t s, const OverlapParams& p) {
+    if (p.n_img <= 0) return hipSuccess;
+    hipLaunchKernelGGL(box_match_kernel, dim3(p.n_img), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // dynamic LDS of the sweep: removed / kept bitmaps and kept bases
 static size_t sweep_lds_bytes(int words) { return ((size_t)2 * words + (words + 1) / 2) * sizeof(unsigned long long); }
 static hipError_t sweep_configure() {                      // > 64 KB of dynamic LDS needs the function attribute, once per device

@@ -273,6 +273,20 @@ hipError_t launch_affine_boxes(hipStream_t s, float* dets, const double* trans, 
 // rank + suppression matrix + greedy sweep only (candidates already collected)
 hipError_t launch_nms_stages(hipStream_t s, const ThreshParams& p);
 
+// bbox_overlap + the two match counts of evaluate (eval_widerface.py:48-74, 172-211); images concatenated, one workgroup each
+struct OverlapParams {
+    const float* boxes;   // detections, rows of box_stride floats (x1,y1,x2,y2,...)
+    const float* query;   // annotations, rows of query_stride floats
+    const int* box_off;   // [n_img + 1] first row of each image in boxes
+    const int* query_off; // [n_img + 1]
+    int n_img, box_stride, query_stride;
+    float thresh;
+    double* overlaps;     // optional: per image a dense [N][K] block at overlaps_off[img]
+    const long long* overlaps_off;
+    int* counts;          // optional [n_img][2] (zeroed): detections with a best overlap > thresh, annotations with one
+};
+hipError_t launch_box_match(hipStream_t s, const OverlapParams& p);
+
 // bilinear stretch-resize of uint8 HWC images (cv2.resize(img, (W, H)) at centerface.py:30; half-pixel centres)
 hipError_t launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int B, int h, int w, int H, int W);
 

@@ -497,4 +497,38 @@ int cf_op_nms(int device, const float* boxes, const float* scores, int n, float 
     return CF_OK;
 }
 
+// bbox_overlap (eval_widerface.py:48-74) and the match counts of evaluate (:195-206) for n_img images at once: boxes / query are
+// the concatenated rows, box_off / query_off [n_img + 1] the first row of each image.  overlaps (optional): the dense [N_i][K_i]
+// float64 matrices back to back; counts (optional) [n_img][2].
+int cf_op_box_match(int device, int n_img, const float* boxes, int box_stride, const int32_t* box_off, const float* query, int query_stride,
+                    const int32_t* query_off, float thresh, double* overlaps, int32_t* counts) {
+    if (n_img < 0 || !box_off || !query_off || box_stride < 4 || query_stride < 4) return CF_EINVAL;
+    if (n_img == 0) return CF_OK;
+    const int NB = box_off[n_img], NQ = query_off[n_img];
+    if (box_off[0] != 0 || query_off[0] != 0 || (NB > 0 && !boxes) || (NQ > 0 && !query)) return CF_EINVAL;
+    std::vector<long long> ooff(n_img + 1, 0);
+    for (int i = 0; i < n_img; ++i) {
+        const int N = box_off[i + 1] - box_off[i], K = query_off[i + 1] - query_off[i];
+        if (N < 0 || K < 0) return CF_EINVAL;
+        ooff[i + 1] = ooff[i] + (long long)N * K;
+    }
+    Scope sc(device);
+    OverlapParams p{};
+    p.n_img = n_img; p.box_stride = box_stride; p.query_stride = query_stride; p.thresh = thresh;
+    float dummy[4] = {0, 0, 0, 0};
+    p.boxes = (const float*)sc.up(NB ? (const void*)boxes : (const void*)dummy, NB ? (size_t)NB * box_stride * 4 : 16);
+    p.query = (const float*)sc.up(NQ ? (const void*)query : (const void*)dummy, NQ ? (size_t)NQ * query_stride * 4 : 16);
+    p.box_off = (const int*)sc.up(box_off, (size_t)(n_img + 1) * 4);
+    p.query_off = (const int*)sc.up(query_off, (size_t)(n_img + 1) * 4);
+    if (overlaps && ooff[n_img] > 0) {
+        p.overlaps = (double*)sc.alloc((size_t)ooff[n_img] * 8);
+        p.overlaps_off = (const long long*)sc.up(ooff.data(), ooff.size() * 8);
+    }
+    if (counts) p.counts = (int*)sc.alloc((size_t)n_img * 2 * 4);
+    if (sc.err == hipSuccess) sc.chk(launch_box_match(sc.s, p));
+    if (sc.err == hipSuccess && p.overlaps) sc.chk(hipMemcpyAsync(overlaps, p.overlaps, (size_t)ooff[n_img] * 8, hipMemcpyDeviceToHost, sc.s));
+    if (sc.err == hipSuccess && counts) sc.chk(hipMemcpyAsync(counts, p.counts, (size_t)n_img * 2 * 4, hipMemcpyDeviceToHost, sc.s));
+    return sc.result("cf_op_box_match");
+}
+
 }  // extern "C"

@@ -5,7 +5,9 @@ reference: forward a batch, sigmoid/clamp the heat map, then per image ``decode`
 decoder: the threshold argument IS honoured, offsets are used -- reg channel 1 on x, channel 0 on
 y, plus 0.5 -- no landmarks) and the greedy ``nms`` (:112-152).  Here the forward, the threshold
 compaction, the box arithmetic and the NMS all run in HIP kernels; this module only marshals.
-The recall/precision code (:154-211) is out of scope (training-loop validation).
+``bbox_overlap`` (:48-74) and ``evaluate`` (:172-211) -- the recall / precision of a detection set against annotations, the
+"box match" of BASELINE.json's metric -- run their IoU matrix and match counts in ``box_match_kernel`` (csrc/cf_decode.hip,
+``cf_op_box_match``); ``box_match`` applies the same metric to two detection sets (bench.py: benchmarked mode vs exact mode).
 """
 import ctypes as C
 
@@ -64,3 +66,91 @@ def nms(boxes, scores, nms_thresh, device=0):
     nk = C.c_int32()
     _lib.check(L.cf_op_nms(device, _lib.ptr(boxes), _lib.ptr(scores), n, float(nms_thresh), _lib.ptr(keep), C.byref(nk)), op=True)
     return [int(k) for k in keep[:nk.value]]
+
+
+def _concat(rows_list, width):
+    off = np.zeros(len(rows_list) + 1, np.int32)
+    for i, r in enumerate(rows_list):
+        off[i + 1] = off[i] + (0 if r is None else len(r))
+    cat = np.zeros((max(int(off[-1]), 1), width), np.float32)
+    for i, r in enumerate(rows_list):
+        if r is not None and len(r):
+            cat[off[i]:off[i + 1]] = np.asarray(r, np.float32)[:, :width]
+    return np.ascontiguousarray(cat), off
+
+
+def bbox_overlap(boxes, query_boxes, device=0):
+    """eval_widerface.bbox_overlap (:48-74): float64 [N,K] "+1" IoU of every detection against every annotation (float32
+    arithmetic, as numpy computes it for the float32 arrays get_detections returns)."""
+    b = np.ascontiguousarray(np.asarray(boxes, np.float32).reshape(len(boxes), -1))
+    q = np.ascontiguousarray(np.asarray(query_boxes, np.float32).reshape(len(query_boxes), -1))
+    N, K = b.shape[0], q.shape[0]
+    out = np.zeros((N, K), np.float64)
+    if N == 0 or K == 0:
+        return out
+    boff, qoff = np.array([0, N], np.int32), np.array([0, K], np.int32)
+    _lib.check(_lib.lib().cf_op_box_match(device, 1, _lib.ptr(b), b.shape[1], _lib.ptr(boff), _lib.ptr(q), q.shape[1], _lib.ptr(qoff),
+                                          0.5, _lib.ptr(out), None), op=True)
+    return out
+
+
+def match_counts(picked_boxes, annot_boxes, threshold=0.5, device=0):
+    """For every image: (detections whose best overlap with an annotation exceeds ``threshold``, annotations whose best overlap
+    with a detection does) -- the two counts of evaluate (:195-206), all images in ONE device call.  int32 [n_img, 2]."""
+    n = len(picked_boxes)
+    counts = np.zeros((n, 2), np.int32)
+    if n == 0:
+        return counts
+    b, boff = _concat(picked_boxes, 4)
+    q, qoff = _concat(annot_boxes, 4)
+    _lib.check(_lib.lib().cf_op_box_match(device, n, _lib.ptr(b), 4, _lib.ptr(boff), _lib.ptr(q), 4, _lib.ptr(qoff),
+                                          float(threshold), None, _lib.ptr(counts)), op=True)
+    return counts
+
+
+def _accumulate(picked_boxes, annots, threshold, device, strip_padding=True):
+    """One batch of evaluate (:180-208): the reference's three empty cases, then the two ratios per image."""
+    annots = [np.asarray(a, np.float32).reshape(-1, np.asarray(a).shape[-1] if len(a) else 4) for a in annots]
+    if strip_padding:
+        annots = [a[a[:, 0] != -1] for a in annots]
+    counts = match_counts(picked_boxes, annots, threshold, device)
+    recall_iter = precision_iter = 0.0
+    for j, boxes in enumerate(picked_boxes):
+        na = annots[j].shape[0]
+        nb = 0 if boxes is None else len(boxes)
+        if boxes is None and na == 0:
+            continue
+        if nb < 1 and na != 0:
+            precision_iter += 1.0
+            continue
+        if na == 0:
+            recall_iter += 1.0
+            continue
+        recall_iter += int(counts[j, 0]) / na
+        precision_iter += int(counts[j, 1]) / nb
+    return recall_iter / len(picked_boxes), precision_iter / len(picked_boxes)
+
+
+def evaluate(val_data, model, threshold=0.5, device=0, detections=None):
+    """eval_widerface.evaluate (:172-211), same call shape: ``val_data`` iterates batches ``{'input': ..., 'meta': {'gt_det':
+    [per-image [M,4+] arrays, rows with x1 == -1 are padding]}}``, ``model`` a centerface_amd.Engine.  Returns (recall,
+    precision) as the reference accumulates them -- including its crossed naming: "recall" = detections matching an annotation
+    / annotations, "precision" = annotations matched by a detection / detections.  ``detections``: optional callable
+    ``(data, model) -> list`` replacing get_detections (precomputed boxes)."""
+    recall = precision = 0.0
+    n = 0
+    for data in val_data:
+        annots = data["meta"]["gt_det"]
+        picked = (detections or get_detections)(data, model)
+        r, p = _accumulate(picked, annots, threshold, device)
+        recall += r
+        precision += p
+        n += 1
+    return recall / n, precision / n
+
+
+def box_match(test_boxes, ref_boxes, threshold=0.5, device=0):
+    """The evaluate metric between two detection sets of the same images (``ref_boxes`` in the role of the annotations):
+    {"recall", "precision"} in the reference's sense (previous docstring).  Lists of float32 [n,4+] (or [] for no boxes)."""
+    r, p = _accumulate(list(test_boxes), list(ref_boxes), threshold, device, strip_padding=False)
+    return {"recall": r, "precision": p, "iou_threshold": threshold, "images": len(test_boxes)}

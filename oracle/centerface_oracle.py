@@ -445,6 +445,71 @@ def detect(sd, img_bgr_u8, threshold=0.2):
     return rescale(dets, lms, sh, sw)
 
 
+# ----------------------------------------------------------------------------- box match ---
+def bbox_overlap(boxes, query_boxes):
+    """eval_widerface.py:48-74: the "+1" IoU of every row of ``boxes`` against every row of ``query_boxes`` -> float64 [N,K].
+    The reference indexes float32 arrays element by element, so every operation is a float32 scalar operation; the union
+    goes through ``float(...)`` (a python float holding the float32 value) and the quotient ``iw * ih / ua`` is float32 /
+    python-float: a float32 division under NumPy >= 2 (NEP 50: the python float is weak), stored into the float64 matrix.
+    (NumPy 1.x promoted that one division to float64; the pin is this container's NumPy 2.2, tests/golden/eval_metrics.npz.)"""
+    b = np.asarray(boxes, np.float32)
+    q = np.asarray(query_boxes, np.float32)
+    N, K = b.shape[0], q.shape[0]
+    out = np.zeros((N, K), np.float64)
+    if N == 0 or K == 0:
+        return out
+    one = np.float32(1)
+    qarea = ((q[:, 2] - q[:, 0]) + one) * ((q[:, 3] - q[:, 1]) + one)                                   # [K]
+    iw = (np.minimum(b[:, None, 2], q[None, :, 2]) - np.maximum(b[:, None, 0], q[None, :, 0])) + one      # [N,K]
+    ih = (np.minimum(b[:, None, 3], q[None, :, 3]) - np.maximum(b[:, None, 1], q[None, :, 1])) + one
+    barea = ((b[:, 2] - b[:, 0]) + one) * ((b[:, 3] - b[:, 1]) + one)
+    inter = iw * ih
+    ua = (barea[:, None] + qarea[None, :]) - inter
+    ok = (iw > 0) & (ih > 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ov = (inter / ua).astype(np.float32)
+    out[ok] = ov[ok].astype(np.float64)
+    return out
+
+
+def evaluate_counts(boxes, annots, threshold=0.5):
+    """The two counts of eval_widerface.evaluate (:195-206) for one image with detections AND annotations: the number of
+    DETECTIONS whose best overlap exceeds the threshold (``max over dim 1``, divided by the annotation count = the reference's
+    "recall" term) and the number of ANNOTATIONS whose best overlap does (``max over dim 0``, divided by the detection count =
+    its "precision" term) -- the reference's naming is crossed, the arithmetic is reproduced as written.  The overlaps pass
+    through torch.FloatTensor (float32) and the comparison is a float32 one."""
+    ov = bbox_overlap(np.asarray(boxes)[:, :4], np.asarray(annots)[:, :4]).astype(np.float32)
+    thr = np.float32(threshold)
+    return int((ov.max(axis=1) > thr).sum()), int((ov.max(axis=0) > thr).sum())
+
+
+def evaluate(picked_batches, annot_batches, threshold=0.5):
+    """eval_widerface.evaluate (:172-211) on precomputed detections: ``picked_batches[i][j]`` = what get_detections returned
+    for image j of batch i (float32 [n,5] or []), ``annot_batches[i][j]`` = its gt_det rows (rows with x1 == -1 are padding).
+    Returns (recall, precision) exactly as the reference accumulates them (per-batch means, then the mean over batches)."""
+    recall = precision = 0.0
+    for picked, annots in zip(picked_batches, annot_batches):
+        r_it = p_it = 0.0
+        for boxes, annot in zip(picked, annots):
+            annot = np.asarray(annot)
+            annot = annot[annot[:, 0] != -1]
+            nb = 0 if boxes is None else len(boxes)
+            if boxes is None and annot.shape[0] == 0:
+                continue
+            if nb < 1 and annot.shape[0] != 0:
+                p_it += 1.0
+                continue
+            if annot.shape[0] == 0:                      # boxes is not None (an empty list included): recall 1, precision 0
+                r_it += 1.0
+                continue
+            det, tp = evaluate_counts(np.asarray(boxes), annot, threshold)
+            r_it += det / annot.shape[0]
+            p_it += tp / np.asarray(boxes).shape[0]
+        recall += r_it / len(picked)
+        precision += p_it / len(picked)
+    return recall / len(picked_batches), precision / len(picked_batches)
+
+
 # ----------------------------------------------------------------------------- training-side pieces (SURVEY 8f, N4)
 def gaussian_radius(det_size, min_overlap=0.7):
     """utils/image.py:95-115 (float64 numpy arithmetic)."""

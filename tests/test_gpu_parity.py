@@ -486,6 +486,57 @@ def test_decode_d2_and_get_detections(golden):
     eng.close()
 
 
+def test_bbox_overlap_and_evaluate_on_the_device(golden):
+    """SURVEY 8f N2, second half: eval_widerface.bbox_overlap / evaluate through cf_op_box_match -- the IoU matrix bit-exact
+    against the reference goldens, evaluate's (recall, precision) equal to the reference's to the last bit at both thresholds,
+    then the whole evaluate loop (forward + D2 decode + NMS + match, all on the device) against the oracle's bookkeeping on
+    the engine's own detections, and box_match of a detection set against itself."""
+    from centerface_amd import eval_widerface as ew
+    g = golden("eval_metrics")
+    for i in g["ov_cases"]:
+        ov = ew.bbox_overlap(g["ov%d_boxes" % i], g["ov%d_query" % i])
+        assert ov.dtype == np.float64 and np.array_equal(ov, g["ov%d_out" % i]), i
+    picked, annots = [], []
+    for bi, nimg in enumerate(g["eval_batches"]):
+        picked.append([g["eval_b%d_i%d_det" % (bi, j)] if len(g["eval_b%d_i%d_det" % (bi, j)]) else [] for j in range(int(nimg))])
+        annots.append([g["eval_b%d_i%d_gt" % (bi, j)] for j in range(int(nimg))])
+    val = [{"meta": {"gt_det": a}, "_picked": p} for a, p in zip(annots, picked)]
+    for thr, key in ((0.5, "eval_thr50"), (0.35, "eval_thr35")):
+        r, p = ew.evaluate(val, None, threshold=thr, detections=lambda data, model: data["_picked"])
+        assert (r, p) == tuple(g[key]), (thr, r, p)
+    # random sets vs the oracle (sizes beyond one workgroup pass, sub-pixel boxes, a 5- and an 8-float row stride)
+    rng = np.random.default_rng(9)
+    for n, k in ((300, 257), (1, 600), (513, 2)):
+        b = rng.uniform(0, 600, (n, 2)).astype(np.float32); b = np.concatenate([b, b + rng.uniform(1, 90, (n, 2)).astype(np.float32), rng.uniform(0, 1, (n, 1)).astype(np.float32)], 1)
+        q = rng.uniform(0, 600, (k, 2)).astype(np.float32); q = np.concatenate([q, q + rng.uniform(1, 90, (k, 2)).astype(np.float32), np.zeros((k, 4), np.float32)], 1)
+        assert np.array_equal(ew.bbox_overlap(b, q), O.bbox_overlap(b[:, :4], q[:, :4]))
+        for thr in (0.5, 0.1):
+            assert tuple(ew.match_counts([b], [q], thr)[0]) == O.evaluate_counts(b, q, thr)
+    # the whole loop on the device: synthetic annotations = jittered detections of the engine itself + distractors
+    S = 96
+    eng = cfa.Engine(S, S, max_batch=4, dtype="fp32")
+    batches = []
+    for bi in range(2):
+        x = rng.standard_normal((4, 3, S, S)).astype(np.float32)
+        dets = ew.get_detections({"input": x}, eng, threshold=0.3)
+        gts = []
+        for d in dets:
+            gt = np.full((16, 4), -1.0, np.float32)
+            if len(d):
+                m = min(len(d), 12)
+                gt[:m] = d[:m, :4] + rng.normal(0, 1.5, (m, 4)).astype(np.float32)
+            gts.append(gt)
+        batches.append({"input": x, "meta": {"gt_det": gts}})
+    r, p = ew.evaluate(batches, eng, threshold=0.5, detections=lambda data, model: ew.get_detections(data, model, threshold=0.3))
+    picked = [ew.get_detections(b, eng, threshold=0.3) for b in batches]
+    assert (r, p) == O.evaluate(picked, [b["meta"]["gt_det"] for b in batches], threshold=0.5)
+    assert 0.0 < r <= 1.0 and 0.0 < p <= 1.0
+    nonempty = [d for d in picked[0] if len(d)]
+    bm = ew.box_match(nonempty, nonempty)
+    assert bm["recall"] == 1.0 and bm["precision"] == 1.0 and bm["images"] == len(nonempty)
+    eng.close()
+
+
 def test_device_resize_and_non32_sizes(tmp_path):
     """centerface.py:30 on the device: cv2.resize's fixed-point INTER_LINEAR (integer arithmetic: BIT-EXACT against
     the oracle's restatement of OpenCV's published algorithm; parity with a cv2 binary is unpinned), up- and

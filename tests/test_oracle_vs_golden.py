@@ -163,6 +163,30 @@ def test_decode_d2_vs_reference(golden):
                        np.zeros((2, 4, 4), np.float32), (16, 16), threshold=0.5) == []
 
 
+def _eval_case(g):
+    """The evaluate fixture as lists of batches (detections as get_detections returns them: [] for an image without boxes)."""
+    picked, annots = [], []
+    for bi, nimg in enumerate(g["eval_batches"]):
+        picked.append([g["eval_b%d_i%d_det" % (bi, j)] if len(g["eval_b%d_i%d_det" % (bi, j)]) else [] for j in range(int(nimg))])
+        annots.append([g["eval_b%d_i%d_gt" % (bi, j)] for j in range(int(nimg))])
+    return picked, annots
+
+
+def test_bbox_overlap_and_evaluate_vs_reference(golden):
+    """eval_widerface.bbox_overlap (:48-74) bit-exact (float64 matrix of float32 quotients) and evaluate (:172-211) to the last
+    bit of its float64 accumulation, incl. touching / disjoint / nested boxes, padding rows and the three empty cases."""
+    g = golden("eval_metrics")
+    for i in g["ov_cases"]:
+        ov = O.bbox_overlap(g["ov%d_boxes" % i], g["ov%d_query" % i])
+        assert ov.dtype == np.float64 and np.array_equal(ov, g["ov%d_out" % i]), i
+    assert (g["ov2_out"][0, 0] == 1.0) and (g["ov2_out"][1, 1] == 0.0) and (0 < g["ov2_out"][2, 2] < 0.2)
+    picked, annots = _eval_case(g)
+    for thr, key in ((0.5, "eval_thr50"), (0.35, "eval_thr35")):
+        r, p = O.evaluate(picked, annots, threshold=thr)
+        assert (r, p) == tuple(g[key]), (thr, r, p, g[key])
+    assert O.bbox_overlap(np.zeros((0, 4), np.float32), g["ov0_query"]).shape == (0, len(g["ov0_query"]))
+
+
 # ----------------------------------------------------------------------------- N4: training-side pieces
 def test_target_encoding_and_losses_match_reference(golden):
     """oracle.encode_targets / gaussian_radius / ctdet_loss against outputs of the reference's
