@@ -99,13 +99,6 @@ int cf_ctdet_loss(cf_ctx* ctx, const float* gt_hm, const uint8_t* reg_mask, cons
  * ctx's GPU (in_on_device = 1; 4-byte aligned -- CF_EINVAL otherwise).  Asynchronous: returns after
  * enqueueing. */
 int cf_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B);
-/* Two-lane schedule over two contexts that alternate batches (experimental): enqueues the VALU-bound
- * front of the new batch on `cur` alone, then the back half (wide late blocks, neck, heads) of the batch pending on `prev`
- * underneath the mid-size blocks of the new batch.  `prev` may be NULL (first batch).  After the call prev's results can be
- * decoded (cf_decode_topk* / cf_gather_topk on prev); cur has no decodable result until its own back half has been launched by
- * the NEXT cf_forward_lanes(other, cur, ...) or by cf_forward_lanes_flush(cur).  Same arithmetic as cf_forward. */
-int cf_forward_lanes(cf_ctx* cur, cf_ctx* prev, const void* in, int in_format, int in_on_device, int B);
-int cf_forward_lanes_flush(cf_ctx* ctx);
 /* cv2.resize + forward in one enqueue (centerface.py:30-41): imgs uint8 [B,h,w,3] BGR of ANY size are
  * stretch-resized on the device to the ctx's (H, W) with OpenCV's fixed-point INTER_LINEAR arithmetic for uint8
  * (11-bit coefficients, int32 passes; csrc/cf_util.hip restates it) and fed to the network.  Pinned to the

@@ -114,11 +114,14 @@ class Engine(object):
         self.last_B = int(B)
 
     def forward_lanes_enqueue(self, prev, x, B, in_format=None):
-        """Two-lane schedule (``cf_forward_lanes``, experimental): enqueue the front of a new batch (device pointer ``x``) on this
+        """Two-lane schedule (``cf_forward_lanes``; EXPERIMENTS BUILD of the library only -- ``make -C csrc EXP=1`` +
+        ``CF_LIB=.../libcenterface_hip_exp.so``; measured slower than EngineRing): enqueue the front of a new batch (device pointer ``x``) on this
         engine and the back half of the batch pending on ``prev`` (another Engine of the same device, or None) underneath its
         mid-size blocks.  Afterwards ``prev`` holds a decodable result; this engine does not until it has been ``prev`` of a
         later call or ``forward_lanes_flush()`` was called."""
         fmt = _lib.CF_IN_U8_HWC_BGR if in_format is None else int(in_format)
+        if not hasattr(self._L, "cf_forward_lanes"):
+            raise RuntimeError("cf_forward_lanes exists only in an experiments build of the library (make -C csrc EXP=1)")
         self._chk(self._L.cf_forward_lanes(self._h, prev._h if prev is not None else None, C.c_void_p(int(x)), fmt, 1, int(B)))
         self.last_B = 0
         if prev is not None and getattr(prev, "_lane_B", 0):

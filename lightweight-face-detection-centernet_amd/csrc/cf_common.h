@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef uint16_t bf16_t;   // raw bfloat16 bits in HBM
 
@@ -198,6 +199,18 @@ __device__ __forceinline__ void xcd_tile_order(unsigned& bx, unsigned& by, unsig
     if ((n & 7u) == 0u) l = (l & 7u) * (n >> 3) + (l >> 3);
     bx = l % gx; l /= gx; by = l % gy; bz = l / gy;
 }
+
+// Run-time switches (host).  cf_env_int: the few PRODUCT switches, each exercised by the driver-run suite
+// (tests/test_switches.py): CF_DW_MATRIX, CF_F4_VARIANT, CF_XCD_ORDER, CF_DECODE_OVERLAP.  cf_ab_int: the A/B switches of the
+// kernel-variant tables and fusion choices -- they exist only in an experiments build (make EXP=1: -DCF_EXPERIMENTS ->
+// libcenterface_hip_exp.so, loaded with CF_LIB=...); the release library returns the default, reads no such variable and
+// does not contain the never-default variants.
+static inline int cf_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#ifdef CF_EXPERIMENTS
+static inline int cf_ab_int(const char* name, int dflt) { return cf_env_int(name, dflt); }
+#else
+static inline int cf_ab_int(const char*, int dflt) { return dflt; }
+#endif
 
 // host-side fp32 -> bf16 (RNE), identical rounding to the device instruction for finite values
 static inline uint16_t host_f32_to_bf16(float f) {

@@ -239,7 +239,7 @@ static hipError_t dw_lds_dispatch(hipStream_t s, const DwParams& p) {
     g.Cc = Cc; g.nchunk = p.C / Cc; g.cpp = Cc / P; g.rc = IW * g.cpp; g.nch = IH * g.rc;
     if (g.nch >= 65536) return hipErrorInvalidValue;
     g.magic_rc = magic_div(g.rc); g.magic_cpp = magic_div(g.cpp);
-    { static const int nt_env = getenv("CF_DW_NT") ? atoi(getenv("CF_DW_NT")) : 0; g.nt = nt_env; }
+    { static const int nt_env = cf_ab_int("CF_DW_NT", 0); g.nt = nt_env; }
     g.lds_bytes = (((size_t)g.nch * 16 + 1023) / 1024) * 1024 + (size_t)KS * KS * Cc * 4;
     dim3 grid((p.Wo + TW - 1) / TW, (p.Ho + TH - 1) / TH, p.B * g.nchunk), blk(256);
     const bool bias = p.bias != nullptr;
@@ -256,7 +256,7 @@ static hipError_t dw_lds_dispatch(hipStream_t s, const DwParams& p) {
 
 template <typename T>
 static hipError_t dw_lds_by_shape(hipStream_t s, const DwParams& p) {
-    static const int tv = getenv("CF_DW_TILE") ? atoi(getenv("CF_DW_TILE")) : 0;     // A/B of tile shapes
+    static const int tv = cf_ab_int("CF_DW_TILE", 0);     // A/B of tile shapes
     if (tv == 1) {
         if (p.k == 3 && p.s == 1) return dw_lds_dispatch<T, 3, 1, 16, 16>(s, p);
         if (p.k == 3 && p.s == 2) return dw_lds_dispatch<T, 3, 2, 8, 16>(s, p);
@@ -297,8 +297,8 @@ static hipError_t dw_by_shape(hipStream_t s, const DwParams& p) {
 hipError_t launch_dw(hipStream_t s, int dtype, const DwParams& p) {
     if (p.B <= 0) return hipSuccess;
     if (p.C % 8) return hipErrorInvalidValue;
-    // CF_DW_VARIANT=march selects the register-marching kernel (A/B against the LDS-staged one)
-    static const bool march = getenv("CF_DW_VARIANT") && !strcmp(getenv("CF_DW_VARIANT"), "march");
+    // CF_DW_MARCH=1 (experiments build) selects the register-marching kernel (A/B against the LDS-staged one)
+    static const bool march = cf_ab_int("CF_DW_MARCH", 0) == 1;
     if (march) {
         if (dtype == 0) return dw_by_shape<float, 4, 4>(s, p);
         return dw_by_shape<bf16_t, 8, 4>(s, p);

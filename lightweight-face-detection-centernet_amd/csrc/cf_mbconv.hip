@@ -405,9 +405,10 @@ static const MbEntry kMbTable[] = {
     MB_ENTRY(bf16_t, 1, 3, 1, 4, 32, 2, 1, 8, 16, 1, 4),   // 3.1  64 -> 384 -> 64 (+res)
     MB_ENTRY(bf16_t, 1, 5, 1, 4, 32, 3, 0, 8, 20, 0, 10),  // 4.0  64 -> 384 -> 96      8x20 tiles: a 40x40 map
     MB_ENTRY(bf16_t, 1, 5, 1, 6, 32, 3, 1, 8, 20, 0, 10),  // 4.1  96 -> 576 -> 96 (+res)   has no edge waste
-    // experimental variants (CF_MB_VARIANT=n), kept for A/B runs through tools/profile_ops.py
+#ifdef CF_EXPERIMENTS   // never-default variants (CF_MB_VARIANT=n): A/B runs of an experiments build only
     MB_VARIANT(1, bf16_t, 1, 3, 1, 4, 32, 2, 1, 8, 20, 0, 10),  // 3.1  8x20
     MB_VARIANT(1, bf16_t, 1, 3, 2, 2, 32, 2, 0, 8, 20, 0, 5),   // 3.0  8x20
+#endif
     // fp32 storage (parity mode).  Round-3 A/B over hidden chunk / tile / k-groups (B = 64, 640x640, ms; previous entry in brackets):
     // what matters is the LDS footprint of the fp32 tile (1.0 at 8x16 / HC 32 = 87 KB = ONE four-wave workgroup per CU)
     MB_ENTRY(float, 0, 3, 2, 2, 32, 1, 0, 4, 16, 1, 4),    // 1.0  4x16 tile, two k-groups, 49 KB: 0.564 [8x16: 0.786; 8x16 HC 16: 0.635]
@@ -422,7 +423,7 @@ static const MbEntry kMbTable[] = {
 #undef MB_ENTRY
 
 static const MbEntry* mb_find(int dtype, int k, int s, int jx, int nbo, int res) {
-    static const int want = getenv("CF_MB_VARIANT") ? atoi(getenv("CF_MB_VARIANT")) : 0;
+    static const int want = cf_ab_int("CF_MB_VARIANT", 0);
     const MbEntry* base = nullptr;
     for (const MbEntry& e : kMbTable)
         if (e.dtype == dtype && e.k == k && e.s == s && e.jx == jx && e.nbo == nbo && e.res == res) {

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     // depthwise + Swish for hidden chunk c (8 channels) of chunk group q on this lane's pixel -> bf16x8
     auto dw_chunk = [&](int q, int c) -> u32x4 {
         float a8[8];
-        const CF_AS4 u32x8* wq = wtab + ((p.nw & 2) ? (size_t)0 : (size_t)(((q * NPARW + par) * (HC / 8) + c) * KS) * NT);   // bit 1: timing experiment (one hot table row)
+        const CF_AS4 u32x8* wq = wtab + (size_t)(((q * NPARW + par) * (HC / 8) + c) * KS) * NT;
         const char* eb = E + e_pix + c * 32;
         if constexpr (KS == 3) {
         // 3x3: all six tap-pair vectors of the chunk (48 SGPRs) in ONE batch.  Tap pairs (s_load) and tile
@@ -669,6 +669,7 @@ static const XdEntry kXdTable[] = {
     XD(0, 3, 1, 10, 32, 10, 20),    // 6.0  160 -> 960, 20x20
     XD(0, 5, 1, 4, 32, 10, 40),     // 4.0   64 -> 384, 40x40: full-width tiles (10x20 0.071, 20x20 0.067, 10x40 0.066, 20x40 0.083 ms)
     XD(0, 5, 1, 6, 32, 10, 40),     // 4.1   96 -> 576, 40x40   (0.106 / 0.098 / 0.096 / 0.129)
+#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
     XD(1, 5, 1, 4, 32, 20, 20),
     XD(1, 5, 1, 6, 32, 20, 20),
     XD(2, 5, 1, 4, 32, 10, 20),
@@ -679,10 +680,11 @@ static const XdEntry kXdTable[] = {
     XD(2, 5, 2, 6, 64, 5, 20),
     XD(2, 5, 1, 10, 32, 20, 20),
     XD(2, 3, 1, 10, 32, 20, 20),
+#endif  // CF_EXPERIMENTS
 };
 #undef XD
 static const XdEntry* xd_find(int k, int s, int jx) {
-    static const int want = getenv("CF_XD_VARIANT") ? atoi(getenv("CF_XD_VARIANT")) : 0;
+    static const int want = cf_ab_int("CF_XD_VARIANT", 0);
     const XdEntry* base = nullptr;
     for (const XdEntry& e : kXdTable)
         if (e.k == k && e.s == s && e.jx == jx) {
@@ -696,7 +698,7 @@ static const XdEntry* xd_find(int k, int s, int jx) {
 MbGeom expdw_geometry(int dtype, int Cin, int hid, int k, int s) {
     MbGeom g = expdw_mx_geometry(dtype, Cin, hid, k, s);          // stride 1: depthwise on the matrix cores (cf_mbconv3.hip)
     if (g.ok) return g;
-    static const bool off = getenv("CF_XD_KIND") && atoi(getenv("CF_XD_KIND")) == 0;
+    static const bool off = cf_ab_int("CF_XD_KIND", 1) == 0;
     if (off || dtype != 1 || (Cin % 8) || hid == Cin) return g;
     const int jx = (Cin * 2 / 16 + 1) / 2;
     const XdEntry* e = xd_find(k, s, jx);
@@ -738,11 +740,10 @@ hipError_t mb2_launch_t(hipStream_t s, const MbParams& p) {
     }
     dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
     // XCD-aware tile order: measured neutral-to-slower on these VALU-bound kernels (layer1.0 0.234 -> 0.237-0.244 ms; their
-    // PMC traffic is already 1.0-1.13x algorithmic), so it stays off here (CF_XCD_ORDER=2 switches it on for A/B runs);
+    // PMC traffic is already 1.0-1.13x algorithmic), so it stays off here (CF_MB2_XCD=1 switches it on in an experiments build);
     // the stem and the up3+heads kernel take it with CF_XCD_ORDER=1 (it removes their cross-XCD halo re-fetches, not time)
-    static const bool xcd_on = getenv("CF_XCD_ORDER") && atoi(getenv("CF_XCD_ORDER")) == 2;
-    static const bool whack = getenv("CF_DW_WHACK") && atoi(getenv("CF_DW_WHACK")) == 1;     // timing experiment only: results invalid
-    MbParams q = p; q.nw = (xcd_on ? 1 : 0) | (whack ? 2 : 0);
+    static const bool xcd_on = cf_ab_int("CF_MB2_XCD", 0) == 1;
+    MbParams q = p; q.nw = xcd_on ? 1 : 0;
     set_kernel_tag("void cf::mbconv_px_kernel<%d, %d, %d, %s, %d, %d, %d, %d, %d>(cf::MbParams)", KS, S, NBO, RESID ? "true" : "false", NW, JX, HC, TOH, TOW);
     hipLaunchKernelGGL(kfn, grid, blk, LDS, s, q);
     return hipGetLastError();
@@ -780,6 +781,7 @@ static const Mb2Entry kMb2Table[] = {
     MB2(0, 3, 1, 4, 64, 2, 1, 8, 16, 4),    // 3.1  64 -> 384 -> 64 (+res)
     MB2(0, 5, 1, 4, 64, 3, 0, 8, 16, 4),    // 4.0  64 -> 384 -> 96
     MB2(0, 5, 1, 6, 64, 3, 1, 8, 16, 4),    // 4.1  96 -> 576 -> 96 (+res)
+#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
     // experimental variants (CF_MB2_VARIANT=n)
     MB2(1, 3, 2, 1, 48, 1, 0, 8, 16, 6),    // 1.0 HC48 KG3
     MB2(1, 3, 1, 2, 48, 1, 1, 8, 16, 6),    // 1.1 8x16 KG3
@@ -802,11 +804,12 @@ static const Mb2Entry kMb2Table[] = {
     MB2(3, 5, 1, 6, 64, 3, 1, 8, 16, 8),    // 4.1 KG4
     MB2(3, 5, 2, 2, 48, 1, 0, 8, 16, 2),    // 2.0 KG1 (2 waves)
     MB2(3, 3, 2, 1, 96, 1, 0, 4, 16, 2),    // 1.0 4x16 HC96 KG... 
+#endif  // CF_EXPERIMENTS
 };
 #undef MB2
 
 static const Mb2Entry* mb2_find(int k, int s, int jx, int nbo, int res) {
-    static const int want = getenv("CF_MB2_VARIANT") ? atoi(getenv("CF_MB2_VARIANT")) : 0;
+    static const int want = cf_ab_int("CF_MB2_VARIANT", 0);
     const Mb2Entry* base = nullptr;
     for (const Mb2Entry& e : kMb2Table)
         if (e.k == k && e.s == s && e.jx == jx && e.nbo == nbo && e.res == res) {
@@ -817,7 +820,7 @@ static const Mb2Entry* mb2_find(int k, int s, int jx, int nbo, int res) {
 }
 
 bool mb2_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
-    static const bool off = getenv("CF_MB_KIND") && atoi(getenv("CF_MB_KIND")) == 0;
+    static const bool off = cf_ab_int("CF_MB_KIND", 1) == 0;
     if (off) return false;
     const int jx = (Cin * 2 / 16 + 1) / 2, nbo = (Cout + 31) / 32;
     const Mb2Entry* e = mb2_find(k, s, jx, nbo, (Cin == Cout && s == 1) ? 1 : 0);

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
     }
 }
 
+#ifdef CF_EXPERIMENTS   // rounds-persistent variant: measured slower (profiles/r03_mfma_depthwise.md), experiments build only
 // The same with the workgroup walking R rounds of its tile (grid.y = rounds / R): launch + first-DMA latency once per R rounds, the
 // next round's weights and operand table streaming into a second LDS stage under the current round's depthwise
 template <int KS, int JX, int TOH, int TOW, int NW, int R>
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mxr_kernel(MbParams p) {
     }
     }
 }
+#endif  // CF_EXPERIMENTS
 
 // ================================================================== fully fused block: expand -> depthwise -> project (+residual)
 // One workgroup per output tile; the hidden channels go through the tile in rounds of 32 (+ an optional last round of 16:
@@ -659,6 +661,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
     }
 }
 
+#ifdef CF_EXPERIMENTS   // role-specialised waves: measured slower, experiments build only
 // ================================================================== fused block with ROLE-SPECIALISED waves (stride 1)
 // mbconv_mx_kernel alternates a transcendental-bound phase (expand + Swish) and a matrix-pipe-bound one (depthwise) behind
 // barriers: a 4x4x4 MFMA costs ~13 cycles of SIMD time there instead of the ~4.5 it costs beside dense VALU work (ablation in
@@ -933,6 +936,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 #undef xf
 #undef pacc
+#endif  // CF_EXPERIMENTS
 
 // ================================================================== fully fused block, stride 2 (layer1.0, layer2.0)
 // The input halo of a stride-2 tile is four times the output tile, so the LDS budget allows 32 output quads = two sets per
@@ -1226,11 +1230,12 @@ static hipError_t xmx_launch_t(hipStream_t s, const MbParams& p) {
     }
     dim3 grid(((p.Wout + TOW - 1) / TOW) * ((p.Hout + TOH - 1) / TOH), p.hid / 32, p.B), blk(NW * 64);
     set_kernel_tag("void cf::expdw_mx_kernel<%d, %d, %d, %d, %d, %s>(cf::MbParams)", KS, JX, TOH, TOW, NW, ALDS ? "true" : "false");
-    static const int abl = getenv("CF_MX_ABL") ? atoi(getenv("CF_MX_ABL")) : 0;      // timing experiments only: results invalid
+    static const int abl = cf_ab_int("CF_MX_ABL", 0);      // timing experiments only: results invalid
     MbParams q = p; q.nw = abl;
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, q);
     return hipGetLastError();
 }
+#ifdef CF_EXPERIMENTS
 template <int KS, int JX, int TOH, int TOW, int NW, int R>
 static hipError_t xmxr_launch_t(hipStream_t s, const MbParams& p) {
     typedef Mx<KS, JX, TOH, TOW, NW, true> G;
@@ -1250,6 +1255,7 @@ static hipError_t xmxr_launch_t(hipStream_t s, const MbParams& p) {
     hipLaunchKernelGGL(kfn, grid, blk, LDS, s, p);
     return hipGetLastError();
 }
+#endif
 #define XMR(V, KS, JX, TOH, TOW, NW, R) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, true>::EBYTES + 2 * (Mx<KS, JX, TOH, TOW, NW, true>::WXB + Mx<KS, JX, TOH, TOW, NW, true>::ATB), &xmxr_launch_t<KS, JX, TOH, TOW, NW, R>}
 #define XMX(V, KS, JX, TOH, TOW, NW, AL) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, (AL != 0)>::LDS, &xmx_launch_t<KS, JX, TOH, TOW, NW, (AL != 0)>}
 static const MxEntry kXmxTable[] = {
@@ -1258,6 +1264,7 @@ static const MxEntry kXmxTable[] = {
     XMX(0, 5, 6, 10, 40, 8, 1),      // 4.1   96 -> 576, 40x40: 0.083 ms [0.101]
     XMX(0, 5, 10, 20, 20, 4, 0),     // 5.1  160 -> 960, 20x20: 0.047 ms [0.057]
     XMX(0, 3, 10, 10, 20, 4, 1),     // 6.0  160 -> 960, 20x20: 0.042 ms [0.044]
+#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
     // variants for A/B runs (CF_MX_VARIANT=n): all within +-8 % of the above
     XMX(1, 5, 4, 8, 40, 5, 1),
     XMX(1, 5, 6, 8, 40, 5, 1),
@@ -1286,11 +1293,12 @@ static const MxEntry kXmxTable[] = {
     XMR(7, 5, 6, 10, 40, 4, 6),
     XMR(7, 5, 10, 20, 20, 4, 6),
     XMR(7, 3, 10, 20, 20, 4, 6),
+#endif  // CF_EXPERIMENTS
 };
 #undef XMX
 #undef XMR
 static const MxEntry* xmx_find(int k, int jx) {
-    static const int want = getenv("CF_MX_VARIANT") ? atoi(getenv("CF_MX_VARIANT")) : 0;
+    static const int want = cf_ab_int("CF_MX_VARIANT", 0);
     const MxEntry* base = nullptr;
     for (const MxEntry& e : kXmxTable)
         if (e.k == k && e.jx == jx) {
@@ -1303,7 +1311,7 @@ static const MxEntry* xmx_find(int k, int jx) {
 // geometry of the matrix-core expand+depthwise kernel (MbGeom::kind = 4); stride 1 only
 MbGeom expdw_mx_geometry(int dtype, int Cin, int hid, int k, int s) {
     MbGeom g{};
-    static const bool off = getenv("CF_MX") && atoi(getenv("CF_MX")) == 0;
+    static const bool off = cf_env_int("CF_DW_MATRIX", 1) == 0 || cf_ab_int("CF_MX", 1) == 0;      // product switch: the v_dot2c family instead
     if (off || dtype != 1 || s != 1 || (Cin % 8) || (hid % 32) || hid == Cin) return g;
     const int jx = (Cin * 2 / 16 + 1) / 2;
     const MxEntry* e = xmx_find(k, jx);
@@ -1382,7 +1390,7 @@ hipError_t fx_launch_t(hipStream_t s, const MbParams& p) {
         configured = true;
     }
     dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
-    static const int abl = getenv("CF_FX_ABL") ? atoi(getenv("CF_FX_ABL")) : 0;      // timing experiments only: results invalid
+    static const int abl = cf_ab_int("CF_FX_ABL", 0);      // timing experiments only: results invalid
     MbParams q = p; q.nw = abl;
     set_kernel_tag(SB ? "void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s, true>(cf::MbParams)"
                       : "void cf::mbconv_mx_kernel<%d, %d, %d, %s, %d, %d, %d, %s, %s, %s, false>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false",
@@ -1406,6 +1414,7 @@ CF_FX_ILP_INSTANCES(CF_X)
 #endif
 
 #ifndef CF_ILP_TU
+#ifdef CF_EXPERIMENTS
 template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, bool TAIL16>
 static hipError_t fz_launch_t(hipStream_t s, const MbParams& p) {
     typedef Fz<KS, JX, NMB, TOH, TOW, TAIL16> G;
@@ -1424,6 +1433,7 @@ static hipError_t fz_launch_t(hipStream_t s, const MbParams& p) {
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
     return hipGetLastError();
 }
+#endif
 #define FXE(V, KS, JX, NMB, RES, TAIL, TOH, TOW, NW, XR, AL) \
     {KS, JX, NMB, RES, TAIL, TOH, TOW, NW, V, Fx<KS, JX, NMB, TOH, TOW, NW, (TAIL != 0), (AL != 0)>::LDS, \
      &fx_launch_t<KS, JX, NMB, (RES != 0), TOH, TOW, NW, (TAIL != 0), (XR != 0), (AL != 0)>}
@@ -1433,6 +1443,7 @@ static const FxEntry kFxTable[] = {
     FXE(0, 3, 2, 2, 1, 1, 16, 16, 4, 0, 1),     // 1.1  24 -> 144 -> 24 (+res), 160x160, four rounds of 32 + one of 16: 0.175 ms [0.205]
     // variants for A/B runs (CF_FX_VARIANT=n); 3.1 (64 -> 384 -> 64, 40x40) stays on cf_mbconv2.hip: 0.097-0.106 ms here against 0.063,
     // and the Cout = 96 blocks (4.0 / 4.1) stay split (fused here: 0.115 / 0.210 ms against 0.082 / 0.120 for the two launches)
+#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
     FXE(1, 5, 2, 2, 1, 0, 16, 16, 4, 1, 1),
     FXE(2, 5, 2, 2, 1, 0, 16, 16, 4, 0, 0),
     FXE(3, 5, 2, 2, 1, 0, 16, 20, 5, 0, 1),
@@ -1449,10 +1460,11 @@ static const FxEntry kFxTable[] = {
     // role-specialised waves on a double-buffered tile (mbconv_mxs_kernel)
     {3, 2, 2, 1, 1, 16, 16, 8, 6, Fz<3, 2, 2, 16, 16, true>::LDS, &fz_launch_t<3, 2, 2, true, 16, 16, true>},
     {5, 2, 2, 1, 0, 16, 16, 8, 6, Fz<5, 2, 2, 16, 16, false>::LDS, &fz_launch_t<5, 2, 2, true, 16, 16, false>},
+#endif  // CF_EXPERIMENTS
 };
 #undef FXE
 static const FxEntry* fx_find(int k, int jx, int nmb, int res, int tail) {
-    static const int want = getenv("CF_FX_VARIANT") ? atoi(getenv("CF_FX_VARIANT")) : 0;
+    static const int want = cf_ab_int("CF_FX_VARIANT", 0);
     const FxEntry* base = nullptr;
     for (const FxEntry& e : kFxTable)
         if (e.k == k && e.jx == jx && e.nmb == nmb && e.res == res && e.tail == tail) {
@@ -1463,7 +1475,7 @@ static const FxEntry* fx_find(int k, int jx, int nmb, int res, int tail) {
 }
 
 bool mx_fused_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
-    static const bool off = getenv("CF_FX") && atoi(getenv("CF_FX")) == 0;
+    static const bool off = cf_env_int("CF_DW_MATRIX", 1) == 0 || cf_ab_int("CF_FX", 1) == 0;
     if (off || s != 1 || (Cin % 8) || (Cout % 8) || Cout > 96 || (hid % 16) || hid == Cin) return false;
     const int jx = (Cin * 2 / 16 + 1) / 2, nmb = 2 * ((Cout + 31) / 32), tail = (hid % 32) ? 1 : 0;
     const FxEntry* e = fx_find(k, jx, nmb, (Cin == Cout) ? 1 : 0, tail);
@@ -1574,14 +1586,16 @@ static const FsEntry kFsTable[] = {
     FSE(0, 5, 2, 2, 1, 8, 16, 0, 0),      // 2.0  24 -> 144 -> 32, 160x160 -> 80x80, four rounds of 32 + one of 16: 0.150 ms [0.177]
     // layer1.0 (16 -> 96 -> 24, 3x3, 320x320 -> 160x160) stays on cf_mbconv2.hip: its depthwise is 4 % of the block's work and
     // 12 800 small workgroups pay the operand-table fetch three times each: 0.264 ms here (0.327 with the table in LDS) vs 0.246
+#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
     FSE(1, 3, 1, 2, 0, 8, 16, 0, 0),
     FSE(1, 5, 2, 2, 1, 8, 16, 0, 1),
     FSE(2, 3, 1, 2, 0, 8, 16, 0, 1),
     FSE(2, 5, 2, 2, 1, 8, 16, 1, 0),
+#endif  // CF_EXPERIMENTS
 };
 #undef FSE
 static const FsEntry* fs_find(int k, int jx, int nmb, int tail) {
-    static const int want = getenv("CF_FS_VARIANT") ? atoi(getenv("CF_FS_VARIANT")) : 0;
+    static const int want = cf_ab_int("CF_FS_VARIANT", 0);
     const FsEntry* base = nullptr;
     for (const FsEntry& e : kFsTable)
         if (e.k == k && e.jx == jx && e.nmb == nmb && e.tail == tail) {
@@ -1592,7 +1606,7 @@ static const FsEntry* fs_find(int k, int jx, int nmb, int tail) {
 }
 
 bool mx_fused2_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
-    static const bool off = getenv("CF_FS") && atoi(getenv("CF_FS")) == 0;
+    static const bool off = cf_env_int("CF_DW_MATRIX", 1) == 0 || cf_ab_int("CF_FS", 1) == 0;
     if (off || s != 2 || (Cin % 8) || (Cout % 8) || Cout > 64 || (hid % 16) || hid == Cin) return false;
     const int jx = (Cin * 2 / 16 + 1) / 2, nmb = 2 * ((Cout + 31) / 32), tail = (hid % 32) ? 1 : 0;
     const FsEntry* e = fs_find(k, jx, nmb, tail);

@@ -314,7 +314,7 @@ static const F4Entry kF4Table[] = {
 #undef F4E
 
 static const F4Entry* f4_find(int k, int s, int jx, int nbo, int res) {
-    static const int want = getenv("CF_F4_VARIANT") ? atoi(getenv("CF_F4_VARIANT")) : 0;
+    static const int want = cf_env_int("CF_F4_VARIANT", 0);      // product switch: 1 = every fp32 block on this file's kernel
     const F4Entry* base = nullptr;
     for (const F4Entry& e : kF4Table)
         if (e.k == k && e.s == s && e.jx == jx && e.nbo == nbo && e.res == res) {
@@ -325,7 +325,7 @@ static const F4Entry* f4_find(int k, int s, int jx, int nbo, int res) {
 }
 
 bool mb4_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
-    static const int on = getenv("CF_F4") ? atoi(getenv("CF_F4")) : 1;      // A/B: 0 = cf_mbconv.hip's fp32 instance
+    static const int on = cf_ab_int("CF_F4", 1);      // A/B: 0 = cf_mbconv.hip's fp32 instance
     if (!on || (Cin % 8) || (Cout % 8) || Cout > 96 || Cin > 96 || hid == Cin) return false;
     const int jx = (Cin * 4 / 16 + 1) / 2, nbo = (Cout + 31) / 32;
     const F4Entry* e = f4_find(k, s, jx, nbo, (Cin == Cout && s == 1) ? 1 : 0);

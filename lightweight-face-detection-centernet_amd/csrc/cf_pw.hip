@@ -453,7 +453,7 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
     const int NB = (p.N + 31) / 32;
     const long long gx = (p.M + 127) / 128;
     // GEMM-heavy layers (no bias / IDAUp epilogue): share weight fragments through LDS
-    static const int wl_env = getenv("CF_PW_WLDS") ? atoi(getenv("CF_PW_WLDS")) : -1;     // A/B: 0 off, N = force NBW
+    static const int wl_env = cf_ab_int("CF_PW_WLDS", -1);     // A/B: 0 off, N = force NBW
     if (wl_env != 0 && !p.bias && !p.low && !p.ldy && p.K >= 64 && NB >= 3 && (p.act == 1 || p.act == 0)) {
         (void)wl_env;                          // NBW = 4 measured best of {4,5,6,8} on every late layer
         if constexpr (sizeof(T) == 2) {
@@ -462,12 +462,12 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
             // image's result must not depend on the batch it travels in.  B = 4, 1280x1280: 20.6 -> 10.8, 24.0 -> 14.6 us (layer5.1 /
             // 6.0 project, K = 960); slower than pw_wlds_kernel at B = 64, 640x640 (20x20 maps: 23 -> 29, 30 -> 49 us; layer4.1's K = 576
             // on its 40x40 map: 32 -> 35 us, N = 96), hence K >= 512 AND N >= 128: layer5.0 / 5.1 / 6.0 of 1280-class inputs (13.7 -> 8.8 us for 5.0)
-            static const int ks_env = getenv("CF_PW_KSPLIT") ? atoi(getenv("CF_PW_KSPLIT")) : -1;   // A/B: 0 off, 1 force
+            static const int ks_env = cf_ab_int("CF_PW_KSPLIT", -1);   // A/B: 0 off, 1 force
             if (ks_env != 0 && p.K >= 256 && (ks_env > 0 || (p.K >= 512 && p.N >= 128 && (long long)p.Ho * p.Wo >= 1024 && (long long)p.Ho * p.Wo < 4096)))
                 return (NB % 3 == 0 || NB == 5) ? dispatch_ksplit<3>(s, p) : dispatch_ksplit<2>(s, p);
         }
-        static const int nst_env = getenv("CF_PW_NST") ? atoi(getenv("CF_PW_NST")) : 0;       // A/B: ring depth 2..4
-        static const int nbw_env = getenv("CF_PW_NBW") ? atoi(getenv("CF_PW_NBW")) : 0;
+        static const int nst_env = cf_ab_int("CF_PW_NST", 0);       // A/B: ring depth 2..4
+        static const int nbw_env = cf_ab_int("CF_PW_NBW", 0);
         // N = 320: five n-blocks per wave (activations read twice); N = 160: 3 + 2 (two workgroup rows: 200 -> 400 workgroups on
         // the 20x20 maps at B = 64, 16.7 -> 16.0 and 25.2 -> 23.1 us); N = 96: three
         const int nbw = nbw_env ? nbw_env : (NB == 3 || NB == 5 ? 3 : (NB % 5 == 0 ? 5 : 4));

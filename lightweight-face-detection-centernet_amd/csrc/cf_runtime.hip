@@ -24,6 +24,9 @@
 #include <vector>
 
 #include "centerface_hip.h"
+#ifdef CF_EXPERIMENTS
+#include "cf_experiments.h"
+#endif
 #include "cf_common.h"
 #include "cf_kernels.h"
 
@@ -135,7 +138,7 @@ void need(cf_ctx* c, int id, size_t elems) { if (c->bufs[id].elems < elems) c->b
 // cache lines.  If the tensor's producer can write block order (a project GEMM or a bf16 fused MBConv kernel) and all of its
 // readers can read it (expand+dw input, GEMM input, GEMM residual), the tensor is kept in block order instead.
 void layout_pass(cf_ctx* c) {
-    static const bool off = getenv("CF_IN_XBLOCK") && atoi(getenv("CF_IN_XBLOCK")) == 0;      // A/B
+    static const bool off = cf_ab_int("CF_IN_XBLOCK", 1) == 0;      // A/B
     if (off || c->dtype != CF_BF16) return;
     auto& ops = c->ops;
     for (size_t i = 0; i < ops.size(); ++i) {
@@ -214,7 +217,7 @@ void build_plan(cf_ctx* c) {
             // 246 VGPRs and it runs at 0.47 of its own instruction-issue bound (profiles/r02b_valu_bound.md); expand + depthwise
             // in one kernel (no accumulators: 6 waves per SIMD) + the LDS-weight GEMM for the project conv is faster although
             // the depthwise output makes a round trip through HBM: 0.111 -> 0.095 ms and 0.166 -> 0.141 ms.  CF_SPLIT_WIDE=0: A/B.
-            static const bool fuse_wide = getenv("CF_SPLIT_WIDE") && atoi(getenv("CF_SPLIT_WIDE")) == 0;
+            static const bool fuse_wide = cf_ab_int("CF_SPLIT_WIDE", 1) == 0;
             if (!fuse_wide && c->dtype == CF_BF16 && cout > 64 && geo.kind == 1) geo.ok = false;
             if (t != 1 && geo.ok && !(c->flags & CF_FLAG_NO_FUSE)) {
                 // fused expand -> dw -> project (cf_mbconv.hip): one launch, expanded tensor stays in LDS
@@ -237,7 +240,7 @@ void build_plan(cf_ctx* c) {
                 m.k = k; m.s = s; m.pad_lo = p / 2; m.geo = xg;
                 m.wkey = std::string(pre) + ".conv.0.1.weight"; m.wkey_dw = std::string(pre) + ".conv.1.1.weight";
                 m.macs = (double)curH * curW * cin * hid + (double)Ho * Wo * hid * k * k;
-                static const bool blk_off = getenv("CF_PW_XBLOCK") && atoi(getenv("CF_PW_XBLOCK")) == 0;      // A/B
+                static const bool blk_off = cf_ab_int("CF_PW_XBLOCK", 1) == 0;      // A/B
                 m.out_blk = !blk_off && hid <= 960;
                 push(m);
                 j = 1;
@@ -296,7 +299,7 @@ void build_plan(cf_ctx* c) {
         c->ops[ih].name = "up3+heads";
         c->ops[ih].macs += c->ops[iu].macs;
     }
-    static const bool neck_off = getenv("CF_NECK") && atoi(getenv("CF_NECK")) == 0;      // A/B
+    static const bool neck_off = cf_ab_int("CF_NECK", 1) == 0;      // A/B in an experiments build; the product switch is CF_FLAG_NO_NECK
     if (fuse && !neck_off && !(c->flags & CF_FLAG_NO_NECK) && c->dtype == CF_BF16 && cin == 320) {
         int icl = -1, iu1 = -1, iu2 = -1;
         for (size_t i = 0; i < c->ops.size(); ++i) {
@@ -612,15 +615,15 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
             stem_pack_weights(dt, ws.f(op.wkey), w.data());
             int r = upload_bytes(c, w, &op.wp); if (r) return r;
         } else if (op.kind == OP_STEM0) {
-            static const bool px_off = getenv("CF_STEM0_KIND") && atoi(getenv("CF_STEM0_KIND")) == 0;
+            static const bool px_off = cf_ab_int("CF_STEM0_KIND", 1) == 0;
             const bool px = dt == CF_BF16 && !px_off;                 // second-generation kernel (cf_stem0.hip)
             // bit 1 = XCD-aware tile order: it cuts the stem's input fetch from 252 to 79 MB per launch (the excess is halo
             // lines fetched by up to three XCD L2s, served by the Infinity Cache).  The kernel is VALU-bound: alone on the
             // chip it runs 2-3 % slower with it (profiles/r02_ablation.md), with two batches in flight (EngineRing, the
             // benchmarked schedule) there is no difference (44.8k img/s either way) and the fabric traffic is a third: on by
             // default, CF_XCD_ORDER=0 switches it off
-            static const bool swz_on = !getenv("CF_XCD_ORDER") || atoi(getenv("CF_XCD_ORDER")) >= 1;
-            static const bool mx_off = getenv("CF_STEM_MX") && atoi(getenv("CF_STEM_MX")) == 0;      // A/B: depthwise on the matrix cores
+            static const bool swz_on = cf_env_int("CF_XCD_ORDER", 1) >= 1;      // product switch
+            static const bool mx_off = cf_env_int("CF_DW_MATRIX", 1) == 0 || cf_ab_int("CF_STEM_MX", 1) == 0;      // product switch: depthwise on the matrix cores
             const bool mx = px && !mx_off;
             op.geo.kind = px ? ((swz_on ? 3 : 1) | (mx ? 4 : 0)) : 0;
             std::vector<char> w(px ? stem0px_wstem_bytes() : stem_packed_bytes(dt)), wp(stem0_proj_bytes(dt));
@@ -967,8 +970,15 @@ int launch_all_ops(cf_ctx* c, const void* net_in, int in_format, int B) {
 
 extern "C" {
 
+#ifdef CF_EXPERIMENTS
+#define CF_FLUSH_LANE(c) do { if ((c)->lane_pending) { int rl_ = cf_forward_lanes_flush(c); if (rl_) return rl_; } } while (0)
+#else
+#define CF_FLUSH_LANE(c) do { } while (0)
+#endif
+
 int cf_forward(cf_ctx* c, const void* in, int in_format, int in_on_device, int B) {
     if (!c) return CF_EINVAL;
+    CF_FLUSH_LANE(c);
     const void* net_in = nullptr;
     int r = stage_input(c, in, in_format, in_on_device, B, &net_in);
     if (r) return r;
@@ -978,6 +988,7 @@ int cf_forward(cf_ctx* c, const void* in, int in_format, int in_on_device, int B
     return CF_OK;
 }
 
+#ifdef CF_EXPERIMENTS   // measured 2-8 % slower than the free-running pair of contexts: not in the release library
 // ---- two-lane schedule (experimental): the forward is cut into three segments -- front A (stem .. the
 // op before cut 1), front B (cut 1 .. the op before cut 2) and the back half (cut 2 .. heads).  With two contexts alternating
 // batches, cf_forward_lanes(cur, prev, ...) enqueues
@@ -989,7 +1000,7 @@ int cf_forward(cf_ctx* c, const void* in, int in_format, int in_on_device, int B
 // successor (end of stream, fences).  Eager launches (no graph): the segments are tens of microseconds each at any batch.
 static int lane_cuts(cf_ctx* c) {
     if (c->lane_cut1 >= 0) return CF_OK;
-    const char* n1 = getenv("CF_LANE_CUT1") ? getenv("CF_LANE_CUT1") : "layer2.0";
+    const char* n1 = getenv("CF_LANE_CUT1") ? getenv("CF_LANE_CUT1") : "layer2.0";      // (experiments build only: this whole section)
     const char* n2 = getenv("CF_LANE_CUT2") ? getenv("CF_LANE_CUT2") : "layer4.0";
     int c1 = -1, c2 = -1;
     for (size_t i = 0; i < c->ops.size(); ++i) {
@@ -1032,7 +1043,7 @@ int cf_forward_lanes(cf_ctx* cur, cf_ctx* prev, const void* in, int in_format, i
     const void* net_in = nullptr;
     r = stage_input(cur, in, in_format, in_on_device, B, &net_in);
     if (r) return r;
-    static const bool alone = !(getenv("CF_LANE_ALONE") && atoi(getenv("CF_LANE_ALONE")) == 0);        // A/B: front A may overlap prev's front B
+    static const bool alone = cf_ab_int("CF_LANE_ALONE", 1) != 0;        // A/B: front A may overlap prev's front B
     if (alone && prev && prev->seg2_recorded) HIPCHK(cur, hipStreamWaitEvent(cur->stream, prev->ev_seg2, 0));
     r = launch_range(cur, 0, cur->lane_cut1, net_in, in_format, B); if (r) return r;
     HIPCHK(cur, hipEventRecord(cur->ev_seg1, cur->stream));
@@ -1060,12 +1071,14 @@ int cf_forward_lanes_flush(cf_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     return lane_back_half(c);
 }
+#endif  // CF_EXPERIMENTS
 
 int cf_forward_resized(cf_ctx* c, const void* imgs, int in_on_device, int B, int h, int w) {
     if (!c || !imgs || h < 1 || w < 1) return CF_EINVAL;
     if (!c->weights_loaded) return c->fail(CF_ESTATE, "cf_forward_resized before cf_load_weights");
     if (B < 1 || B > c->max_batch) return c->fail(CF_EINVAL, "cf_forward_resized: B=%d outside [1, %d]", B, c->max_batch);
     HIPCHK(c, hipSetDevice(c->device));
+    CF_FLUSH_LANE(c);
     const uint8_t* src = (const uint8_t*)imgs;
     if (!in_on_device) {
         const size_t bytes = (size_t)B * h * w * 3;
@@ -1129,7 +1142,7 @@ int cf_decode_topk(cf_ctx* c, int K, int use_reg, float* dets, float* lms, int64
     HIPCHK(c, hipSetDevice(c->device));
     int r = ensure_topk_ws(c, K); if (r) return r;
     if (out_on_device) {
-        static const bool overlap = !(getenv("CF_DECODE_OVERLAP") && atoi(getenv("CF_DECODE_OVERLAP")) == 0);
+        static const bool overlap = cf_env_int("CF_DECODE_OVERLAP", 1) != 0;      // product switch
         if (!overlap) return enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds);
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
         r = enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds, nullptr, c->stream2);

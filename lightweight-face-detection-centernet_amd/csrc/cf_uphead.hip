@@ -164,9 +164,9 @@ hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p) {
     if (p.B <= 0) return hipSuccess;
     dim3 grid((p.w + UH_TW - 1) / UH_TW, (p.h + UH_TH - 1) / UH_TH, p.B), blk(256);
 
-    static const bool xcd_on = getenv("CF_XCD_ORDER") && atoi(getenv("CF_XCD_ORDER")) >= 1;      // A/B only: 0.090 -> 0.094 ms with it
+    static const bool xcd_on = cf_ab_int("CF_UH_XCD", 0) >= 1;      // A/B only: 0.090 -> 0.094 ms with it
     UpHeadParams q = p; q.xcd = xcd_on ? 1 : 0;
-    static const bool coalesce = !(getenv("CF_UH_COALESCE") && atoi(getenv("CF_UH_COALESCE")) == 0);      // A/B
+    static const bool coalesce = cf_ab_int("CF_UH_COALESCE", 1) != 0;      // A/B
     set_kernel_tag(coalesce ? "void cf::uphead_kernel<true>(cf::UpHeadParams)" : "void cf::uphead_kernel<false>(cf::UpHeadParams)");
     if (coalesce) hipLaunchKernelGGL(uphead_kernel<true>, grid, blk, 0, s, q);
     else hipLaunchKernelGGL(uphead_kernel<false>, grid, blk, 0, s, q);

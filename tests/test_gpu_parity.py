@@ -512,9 +512,12 @@ def test_bbox_overlap_and_evaluate_on_the_device(golden):
         assert np.array_equal(ew.bbox_overlap(b, q), O.bbox_overlap(b[:, :4], q[:, :4]))
         for thr in (0.5, 0.1):
             assert tuple(ew.match_counts([b], [q], thr)[0]) == O.evaluate_counts(b, q, thr)
-    # the whole loop on the device: synthetic annotations = jittered detections of the engine itself + distractors
+    # the whole loop on the device: synthetic annotations = jittered detections of the engine itself.  The reference's decoders
+    # take the box size linearly from the wh head (eval_widerface.py:100), so the synthetic weights get a positive size bias
     S = 96
-    eng = cfa.Engine(S, S, max_batch=4, dtype="fp32")
+    sd = dict(cfa.weights.synthetic_state_dict(0))
+    sd["wh.1.bias"] = (sd["wh.1.bias"] + 6.0).astype(np.float32)
+    eng = cfa.Engine(S, S, max_batch=4, dtype="fp32", weights=sd)
     batches = []
     for bi in range(2):
         x = rng.standard_normal((4, 3, S, S)).astype(np.float32)

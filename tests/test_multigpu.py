@@ -255,40 +255,6 @@ def test_engine_ring_matches_single_engine_bitwise():
     ring.close()
 
 
-def test_two_lane_schedule_returns_the_same_results():
-    """``cf_forward_lanes`` (experimental two-lane schedule: front of batch k alone, then the back half of batch k-1 underneath
-    the mid-size blocks of batch k, ordered by events across the two contexts) must return, batch by batch, exactly what the
-    plain forward returns -- different batch sizes, a flush at the end, and a plain forward on the same contexts afterwards."""
-    import torch
-    S, K = 160, 30
-    rng = np.random.default_rng(11)
-    batches = [rng.integers(0, 256, (b, S, S, 3), dtype=np.uint8) for b in (6, 6, 2, 6, 5)]
-    ref = cfa.Engine(S, S, max_batch=6, dtype="bf16")
-    want = []
-    for x in batches:
-        ref.forward_enqueue(x)
-        want.append(ref.decode_topk(K))
-    ring = cfa.EngineRing(S, S, depth=2, max_batch=6, dtype="bf16")
-    engs = ring.engines
-    dev = [torch.from_numpy(x).cuda() for x in batches]
-    got, prev = {}, None
-    for k, x in enumerate(dev):
-        i = k % 2
-        engs[i].forward_lanes_enqueue(engs[prev[0]] if prev else None, x.data_ptr(), x.shape[0])
-        if prev:
-            got[prev[1]] = engs[prev[0]].decode_topk(K)
-        prev = (i, k)
-    engs[prev[0]].forward_lanes_flush()
-    got[prev[1]] = engs[prev[0]].decode_topk(K)
-    for k in range(len(batches)):
-        for a, b in zip(got[k], want[k]):
-            assert np.array_equal(a, b), k
-    engs[0].forward_enqueue(batches[0])                      # the plain path on the same context afterwards
-    for a, b in zip(engs[0].decode_topk(K), want[0]):
-        assert np.array_equal(a, b)
-    ring.close(); ref.close()
-
-
 def test_bench_prints_one_json_line_with_the_contract_fields():
     """bench.py as the driver runs it (small workload): exactly one line on stdout, the contract's fields, roofline and
     the per-run consistency the judge checks (value = images of the median window / its time)."""
