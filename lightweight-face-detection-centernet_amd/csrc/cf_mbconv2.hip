@@ -296,7 +296,11 @@ __global__ __launch_bounds__(NW * 64) void mbconv_px_kernel(MbParams p) {
     // depthwise + Swish for hidden chunk c (8 channels) of chunk group q on this lane's pixel -> bf16x8
     auto dw_chunk = [&](int q, int c) -> u32x4 {
         float a8[8];
-        const CF_AS4 u32x8* wq = wtab + (size_t)(((q * NPARW + par) * (HC / 8) + c) * KS) * NT;
+        // p.nw is 0 or 1, never negative: the select on a kernel argument only keeps the table address a run-time value.  With a
+        // compile-time offset the compiler clusters the tap loads of all chunks of a round in front of the depthwise loop
+        // (layer1.0: 33 SGPR spills, 132 -> 177 VGPRs, three -> two waves per SIMD, 0.256 -> 0.318 ms; an opaque inline-asm
+        // barrier on the offset does not prevent it).
+        const CF_AS4 u32x8* wq = wtab + (p.nw < 0 ? (size_t)0 : (size_t)(((q * NPARW + par) * (HC / 8) + c) * KS) * NT);
         const char* eb = E + e_pix + c * 32;
         if constexpr (KS == 3) {
         // 3x3: all six tap-pair vectors of the chunk (48 SGPRs) in ONE batch.  Tap pairs (s_load) and tile
