@@ -38,6 +38,9 @@ extern "C" {
 /* storage dtype of activations and packed weights (accumulation is always fp32) */
 #define CF_F32   0               /* parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) */
 #define CF_BF16  1               /* throughput mode: bf16 storage, bf16 MFMA, fp32 accumulate */
+#define CF_F32_SPLIT 2           /* tolerance mode: fp32 storage, every GEMM product as a split-bf16 ("bf16x3") product on the bf16
+                                  * matrix pipe (hi.hi + lo.hi + hi.lo, fp32 accumulate): within north_star's 1e-3 of the reference
+                                  * like CF_F32 (products exact to ~2^-16 relative), several times its speed */
 
 /* network input formats accepted by cf_forward */
 #define CF_IN_U8_HWC_BGR  0      /* uint8 [B,H,W,3] BGR, as cv2 gives it; /255, -mean, /std fused

@@ -22,7 +22,9 @@ from . import _lib
 from . import weights as _weights
 
 _DTYPES = {"fp32": _lib.CF_F32, "float32": _lib.CF_F32, "f32": _lib.CF_F32,
-           "bf16": _lib.CF_BF16, "bfloat16": _lib.CF_BF16}
+           "bf16": _lib.CF_BF16, "bfloat16": _lib.CF_BF16,
+           # tolerance mode: fp32 storage, split-bf16 ("bf16x3") GEMM products -- within 1e-3 of the reference like "fp32"
+           "fp32_split": _lib.CF_F32_SPLIT, "bf16x3": _lib.CF_F32_SPLIT}
 
 
 class Engine(object):

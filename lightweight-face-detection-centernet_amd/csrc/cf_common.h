@@ -75,6 +75,17 @@ template <> struct Elem<bf16_t> {
     static constexpr int PER16 = 8;
 };
 
+// Third storage/arithmetic type: fp32 in HBM and LDS like `float`, but every GEMM product runs as a SPLIT-bf16 ("bf16x3")
+// product on the bf16 matrix pipe -- x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits kept), and
+// w.x ~= w_hi.x_hi + w_lo.x_hi + w_hi.x_lo (the dropped lo.lo term and the rounding of lo are ~2^-17 relative), accumulated
+// in fp32 by the MFMA.  The native fp32 MFMA (v_mfma_f32_32x32x2_f32: 64 cycles for 4 Kflop) runs at 1/16 of the bf16 pipe;
+// three v_mfma_f32_32x32x8_bf16_1k (32 cycles for 16 Kflop each) do the same product 2.7x faster, three 32x32x16 5.3x.
+// Storage, layouts and every non-GEMM operation (Swish, depthwise taps, residual adds, epilogues) are those of `float`.
+struct sp32_t { float v; };
+template <> struct Elem<sp32_t> {
+    static constexpr int PER16 = 4;
+};
+
 // unpack one 16-byte chunk to fp32 values
 template <typename T> __device__ __forceinline__ void unpack16(const u32x4& c, float* f);
 template <> __device__ __forceinline__ void unpack16<float>(const u32x4& c, float* f) {
@@ -85,15 +96,55 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4& c, flo
     f[0] = bf16lo(c.x); f[1] = bf16hi(c.x); f[2] = bf16lo(c.y); f[3] = bf16hi(c.y);
     f[4] = bf16lo(c.z); f[5] = bf16hi(c.z); f[6] = bf16lo(c.w); f[7] = bf16hi(c.w);
 }
+template <> __device__ __forceinline__ void unpack16<sp32_t>(const u32x4& c, float* f) { unpack16<float>(c, f); }
 template <typename T> __device__ __forceinline__ u32x4 pack16(const float* f);
 template <> __device__ __forceinline__ u32x4 pack16<float>(const float* f) {
     u32x4 c; c.x = __float_as_uint(f[0]); c.y = __float_as_uint(f[1]);
     c.z = __float_as_uint(f[2]); c.w = __float_as_uint(f[3]); return c;
 }
+template <> __device__ __forceinline__ u32x4 pack16<sp32_t>(const float* f) { return pack16<float>(f); }
 template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
     u32x4 c; c.x = pack_bf16x2(f[0], f[1]); c.y = pack_bf16x2(f[2], f[3]);
     c.z = pack_bf16x2(f[4], f[5]); c.w = pack_bf16x2(f[6], f[7]); return c;
 }
+
+// ---- the three MFMA flavours behind one call: acc[32x32] += W-fragment . X-fragment over one 16-byte operand chunk per lane
+// (lane half h supplies k-slot group h: 8 bf16, or 4 fp32 values)
+typedef __attribute__((ext_vector_type(8))) __bf16 cf_bf16x8;
+typedef __attribute__((ext_vector_type(4))) short cf_s16x4;
+// four fp32 values -> (hi, lo) bf16 quads
+__device__ __forceinline__ void split4(const u32x4& x, u32x2& hi, u32x2& lo) {
+    const float x0 = __uint_as_float(x.x), x1 = __uint_as_float(x.y), x2 = __uint_as_float(x.z), x3 = __uint_as_float(x.w);
+    hi.x = pack_bf16x2(x0, x1); hi.y = pack_bf16x2(x2, x3);
+    lo.x = pack_bf16x2(x0 - bf16lo(hi.x), x1 - bf16hi(hi.x));
+    lo.y = pack_bf16x2(x2 - bf16lo(hi.y), x3 - bf16hi(hi.y));
+}
+__device__ __forceinline__ void mma_split_parts(f32x16& acc, const u32x4& w, const u32x2& xh, const u32x2& xl) {
+    u32x2 wh, wl; wh.x = w.x; wh.y = w.y; wl.x = w.z; wl.y = w.w;               // host packing: [4 x hi | 4 x lo] (pack_split4)
+    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(cf_s16x4, wl), __builtin_bit_cast(cf_s16x4, xh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(cf_s16x4, wh), __builtin_bit_cast(cf_s16x4, xl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(cf_s16x4, wh), __builtin_bit_cast(cf_s16x4, xh), acc, 0, 0, 0);
+}
+template <typename T> struct CfMma;
+template <> struct CfMma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, w), __builtin_bit_cast(cf_bf16x8, x), acc, 0, 0, 0);
+    }
+};
+template <> struct CfMma<float> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+    }
+};
+template <> struct CfMma<sp32_t> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
+        u32x2 xh, xl; split4(x, xh, xl);
+        mma_split_parts(acc, w, xh, xl);
+    }
+};
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
@@ -221,4 +272,19 @@ static inline uint16_t host_f32_to_bf16(float f) {
 }
 static inline float host_bf16_to_f32(uint16_t b) {
     uint32_t u = (uint32_t)b << 16; float f; __builtin_memcpy(&f, &u, 4); return f;
+}
+// host: four fp32 weights -> one 16-byte split fragment [hi0..3 | lo0..3] (CfMma<sp32_t>)
+static inline void pack_split4(const float* src, void* dst16) {
+    uint16_t* d = (uint16_t*)dst16;
+    for (int e = 0; e < 4; ++e) {
+        const uint16_t hi = host_f32_to_bf16(src[e]);
+        d[e] = hi;
+        d[4 + e] = host_f32_to_bf16(src[e] - host_bf16_to_f32(hi));
+    }
+}
+// host: P elements of storage/operand type `dtype` (0 fp32, 1 bf16, 2 split) into a 16-byte fragment chunk
+static inline void pack_chunk(int dtype, const float* src, void* dst16) {
+    if (dtype == 0) __builtin_memcpy(dst16, src, 16);
+    else if (dtype == 2) pack_split4(src, dst16);
+    else for (int e = 0; e < 8; ++e) ((uint16_t*)dst16)[e] = host_f32_to_bf16(src[e]);
 }

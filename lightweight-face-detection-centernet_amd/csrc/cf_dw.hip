@@ -300,10 +300,10 @@ hipError_t launch_dw(hipStream_t s, int dtype, const DwParams& p) {
     // CF_DW_MARCH=1 (experiments build) selects the register-marching kernel (A/B against the LDS-staged one)
     static const bool march = cf_ab_int("CF_DW_MARCH", 0) == 1;
     if (march) {
-        if (dtype == 0) return dw_by_shape<float, 4, 4>(s, p);
+        if (dtype != 1) return dw_by_shape<float, 4, 4>(s, p);
         return dw_by_shape<bf16_t, 8, 4>(s, p);
     }
-    return dtype == 0 ? dw_lds_by_shape<float>(s, p) : dw_lds_by_shape<bf16_t>(s, p);
+    return dtype != 1 ? dw_lds_by_shape<float>(s, p) : dw_lds_by_shape<bf16_t>(s, p);      // dtype 2: fp32 storage, no GEMM here
 }
 
 }  // namespace cf

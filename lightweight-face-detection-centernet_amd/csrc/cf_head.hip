@@ -26,8 +26,8 @@ static inline int slot_channel(int nb, int i) {
     return nb * 32 + h * 16 + r;
 }
 // chunks per kernel row (3 pixels x 24 ch) and MFMA steps per kernel row
-static inline int cpd(int dtype) { return dtype == 0 ? 18 : 9; }
-static inline int spd(int dtype) { return dtype == 0 ? 9 : 5; }
+static inline int cpd(int dtype) { return dtype != 1 ? 18 : 9; }
+static inline int spd(int dtype) { return dtype != 1 ? 9 : 5; }
 
 size_t head_packed_bytes(int dtype, int collapsed) {
     int NB = collapsed ? 1 : 3;
@@ -76,13 +76,13 @@ void head_pack_weights(int dtype, int collapsed, const float* w0, const float* b
                     int c = h * SPD + j;
                     if (q >= NQ || c >= CPD) continue;
                     char* dst = (char*)w0p_host + ((((size_t)nb * 3 + dy) * SPD + j) * 64 + lane) * 16;
+                    float vv[8];
                     for (int e = 0; e < P; ++e) {
                         int idx = c * P + e;          // element within the 72-wide kernel row
                         int dx = idx / 24, ci = idx % 24;
-                        float v = (float)W[(size_t)q * 216 + (ci * 3 + dy) * 3 + dx];
-                        if (dtype == 0) ((float*)dst)[e] = v;
-                        else ((uint16_t*)dst)[e] = host_f32_to_bf16(v);
+                        vv[e] = (float)W[(size_t)q * 216 + (ci * 3 + dy) * 3 + dx];
                     }
+                    pack_chunk(dtype, vv, dst);
                 }
     for (int q = 0; q < (collapsed ? 16 : 96); ++q) b0_host[q] = q < NQ ? (float)bq[q] : 0.0f;
     if (collapsed == 2) b0_host[15] = (float)bq[0];
@@ -94,21 +94,7 @@ void head_pack_weights(int dtype, int collapsed, const float* w0, const float* b
     delete[] W;
 }
 
-template <typename T> struct HMma;
-template <> struct HMma<bf16_t> {
-    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w),
-                                                      __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
-    }
-};
-template <> struct HMma<float> {
-    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
-    }
-};
+template <typename T> using HMma = CfMma<T>;
 
 template <typename T, bool COLLAPSED>
 __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
@@ -208,10 +194,13 @@ hipError_t launch_heads(hipStream_t s, int dtype, const HeadParams& p) {
     const long long M = (long long)p.B * p.h * p.w;
     if (M <= 0) return hipSuccess;
     dim3 grid((unsigned)((M + 127) / 128)), blk(256);
-    set_kernel_tag("void cf::head_kernel<%s, %s>(cf::HeadParams)", dtype == 0 ? "float" : "unsigned short", p.collapsed ? "true" : "false");
+    set_kernel_tag("void cf::head_kernel<%s, %s>(cf::HeadParams)", dtype == 0 ? "float" : dtype == 2 ? "sp32_t" : "unsigned short", p.collapsed ? "true" : "false");
     if (dtype == 0) {
         if (p.collapsed) hipLaunchKernelGGL((head_kernel<float, true>), grid, blk, 0, s, p);
         else hipLaunchKernelGGL((head_kernel<float, false>), grid, blk, 0, s, p);
+    } else if (dtype == 2) {
+        if (p.collapsed) hipLaunchKernelGGL((head_kernel<sp32_t, true>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((head_kernel<sp32_t, false>), grid, blk, 0, s, p);
     } else {
         if (p.collapsed) hipLaunchKernelGGL((head_kernel<bf16_t, true>), grid, blk, 0, s, p);
         else hipLaunchKernelGGL((head_kernel<bf16_t, false>), grid, blk, 0, s, p);

@@ -1,8 +1,11 @@
-// Host-callable launchers for the gfx950 kernels + weight packers.  dtype: 0 = fp32, 1 = bf16.
+// Host-callable launchers for the gfx950 kernels + weight packers.  dtype: 0 = fp32, 1 = bf16, 2 = fp32 storage with split-bf16
+// GEMM products (sp32_t, cf_common.h): storage, layouts and sizes of 0.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+
+struct sp32_t;
 
 namespace cf {
 
@@ -11,9 +14,10 @@ namespace cf {
 const char* last_kernel_tag();
 void set_kernel_tag(const char* fmt, ...);
 template <typename T> inline const char* type_tag() { return sizeof(T) == 4 ? "float" : "unsigned short"; }
+template <> inline const char* type_tag<sp32_t>() { return "sp32_t"; }
 
-inline size_t elem_size(int dtype) { return dtype == 0 ? 4 : 2; }
-inline int per16(int dtype) { return dtype == 0 ? 4 : 8; }
+inline size_t elem_size(int dtype) { return dtype == 1 ? 2 : 4; }
+inline int per16(int dtype) { return dtype == 1 ? 8 : 4; }
 
 // ------------------------------------------------------------------ pointwise (1x1) conv, MFMA
 // y[m][n] = act( sum_k x[m][k] * w[n][k] + bias[n] ) (+ residual[m][n]) (+ IDAUp up-branch)
@@ -98,9 +102,9 @@ hipError_t expdw_launch(hipStream_t s, const MbParams& p);
 
 // cf_mbconv4.hip: the fp32 parity mode's fused block, second generation (MbGeom::kind = 7): wave = 64 pixels, SGPR taps, permlane32
 // swap into the project MFMA; expand fragments as cf_mbconv.hip, taps and project fragments repacked by mb4_repack
-bool mb4_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s);
-void mb4_repack(const MbGeom& g, int hid, int Cout, int k, const float* wd, const float* wp, float* wdw_host, void* wproj_host);
-hipError_t mb4_launch(hipStream_t s, const MbParams& p);
+bool mb4_geometry(int dtype, MbGeom& g, int Cin, int hid, int Cout, int k, int s);
+void mb4_repack(int dtype, const MbGeom& g, int hid, int Cout, int k, const float* wd, const float* wp, float* wdw_host, void* wproj_host);
+hipError_t mb4_launch(hipStream_t s, int dtype, const MbParams& p);
 
 // cf_mbconv3.hip: depthwise on the matrix cores (v_mfma_f32_4x4x4_16b_f16, Toeplitz operands), stride 1, bf16 storage.
 // MbGeom::kind 4 = expand + depthwise (project stays a GEMM launch)

@@ -37,21 +37,7 @@ static inline int slot_channel(int nb, int i) {
 
 
 
-template <typename T> struct MbMma;
-template <> struct MbMma<bf16_t> {
-    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w),
-                                                      __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
-    }
-};
-template <> struct MbMma<float> {
-    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
-    }
-};
+template <typename T> using MbMma = CfMma<T>;
 
 // ---------------------------------------------------------------- host: packing (geometry: mb_geometry below the kernel table)
 // we [hid][Cin], wd [hid][k*k], wp [Cout][hid]
@@ -64,17 +50,14 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
     if (g.kind == 7) {                       // cf_mbconv4.hip: this file's expand fragments, its own tap table and project fragments
         MbGeom g0 = g; g0.kind = 0;
         mb_pack_weights(dtype, g0, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host);
-        mb4_repack(g, hid, Cout, k, wd, wp, wdw_host, wproj_host);
+        mb4_repack(dtype, g, hid, Cout, k, wd, wp, wdw_host, wproj_host);
         return;
     }
     const int P = per16(dtype);
     const int NCx = Cin * (int)elem_size(dtype) / 16;
     __builtin_memset(wexp_host, 0, g.wexp_bytes);
     __builtin_memset(wproj_host, 0, g.wproj_bytes);
-    auto put = [&](char* dst, const float* src, int n) {
-        if (dtype == 0) for (int e = 0; e < n; ++e) ((float*)dst)[e] = src[e];
-        else for (int e = 0; e < n; ++e) ((uint16_t*)dst)[e] = host_f32_to_bf16(src[e]);
-    };
+    auto put = [&](char* dst, const float* src, int n) { (void)n; pack_chunk(dtype, src, dst); };      // n = P: one 16-byte chunk
     for (int q = 0; q < g.nq; ++q) {
         for (int nbl = 0; nbl < g.NBE; ++nbl)
             for (int j = 0; j < g.JX; ++j)
@@ -419,6 +402,15 @@ static const MbEntry kMbTable[] = {
     MB_ENTRY(float, 0, 3, 1, 8, 32, 2, 1, 8, 16, 1, 4),    // 3.1  0.192 [two k-groups: 0.191; HC 64: 0.220; HC 48: 0.232]
     MB_ENTRY(float, 0, 5, 1, 8, 32, 3, 0, 8, 16, 1, 8),    // 4.0  0.277 [HC 16: 0.363; HC 48: 0.344; one k-group: 0.378]
     MB_ENTRY(float, 0, 5, 1, 12, 32, 3, 1, 8, 16, 1, 4),   // 4.1  one k-group: 0.512 [0.534; HC 16: 0.724; HC 48: 0.596]
+    // fp32 storage + split-bf16 GEMM products (dtype 2): the fp32 geometries (same LDS tile, same epilogues)
+    MB_ENTRY(sp32_t, 2, 3, 2, 2, 32, 1, 0, 4, 16, 1, 4),   // 1.0
+    MB_ENTRY(sp32_t, 2, 3, 1, 3, 48, 1, 1, 8, 16, 1, 8),   // 1.1
+    MB_ENTRY(sp32_t, 2, 5, 2, 3, 16, 1, 0, 8, 16, 1, 8),   // 2.0
+    MB_ENTRY(sp32_t, 2, 5, 1, 4, 48, 1, 1, 8, 16, 1, 8),   // 2.1
+    MB_ENTRY(sp32_t, 2, 3, 2, 4, 32, 2, 0, 8, 16, 1, 8),   // 3.0
+    MB_ENTRY(sp32_t, 2, 3, 1, 8, 32, 2, 1, 8, 16, 1, 4),   // 3.1
+    MB_ENTRY(sp32_t, 2, 5, 1, 8, 32, 3, 0, 8, 16, 1, 8),   // 4.0
+    MB_ENTRY(sp32_t, 2, 5, 1, 12, 32, 3, 1, 8, 16, 1, 4),  // 4.1
 };
 #undef MB_ENTRY
 
@@ -440,7 +432,7 @@ MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
     if (dtype == 1 && mx_fused_geometry(g, Cin, hid, Cout, k, s)) return g;      // stride 1: depthwise on the matrix cores
     if (dtype == 1 && mx_fused2_geometry(g, Cin, hid, Cout, k, s)) return g;     // stride 2
     if (dtype == 1 && mb2_geometry(g, Cin, hid, Cout, k, s)) return g;
-    if (dtype == 0 && mb4_geometry(g, Cin, hid, Cout, k, s)) return g;
+    if (dtype != 1 && mb4_geometry(dtype, g, Cin, hid, Cout, k, s)) return g;
     g.JX = (Cin * sz / 16 + 1) / 2;
     g.NBO = (Cout + 31) / 32;
     const MbEntry* e = mb_find(dtype, k, s, g.JX, g.NBO, (Cin == Cout && s == 1) ? 1 : 0);
@@ -464,7 +456,7 @@ hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p) {
     if (p.kind == 4) return dtype == 1 ? mx_launch(s, p) : hipErrorInvalidValue;
     if (p.kind == 5) return dtype == 1 ? mx_fused_launch(s, p) : hipErrorInvalidValue;
     if (p.kind == 6) return dtype == 1 ? mx_fused2_launch(s, p) : hipErrorInvalidValue;
-    if (p.kind == 7) return dtype == 0 ? mb4_launch(s, p) : hipErrorInvalidValue;
+    if (p.kind == 7) return dtype != 1 ? mb4_launch(s, dtype, p) : hipErrorInvalidValue;
     const MbEntry* e = mb_find(dtype, p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
     if (!e || e->hc != p.HC) return hipErrorInvalidValue;
     return e->fn(s, p);

@@ -17,6 +17,7 @@
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace cf {
 
@@ -39,15 +40,10 @@ struct F4 {
     static_assert(HC % 8 == 0 && JS * KG == NPAIR, "hidden chunk / k-group geometry");
 };
 
-__device__ __forceinline__ void mma_f32(f32x16& acc, const u32x4& w, const u32x4& x) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
-}
-
-template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW, bool XRELOAD>
+// SP: GEMM products as split-bf16 (CfMma<sp32_t>, dtype 2) instead of the exact fp32 MFMA; everything else identical
+template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW, bool XRELOAD, bool SP = false>
 __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
+    typedef CfMma<typename std::conditional<SP, sp32_t, float>::type> MMA;
     typedef F4<KS, S, HC, TOH, TOW, JX, NW> G;
     constexpr int IW = G::IW, HW = G::HW, IPX = G::IPX, NIB = G::NIB, NPW = G::NPW, KG = G::KG, NBE = G::NBE, JS = G::JS;
     constexpr int ROWB = G::ROWB, WXB = G::WXB;
@@ -122,7 +118,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
             for (int r = 0; r < 16; ++r) a[r] = 0.0f;
             const char* wb = wx + (nbl * JX * 64 + lane) * 16;
 #pragma unroll
-            for (int j = 0; j < JX; ++j) mma_f32(a, ld16(wb + j * 1024), xfr[j]);
+            for (int j = 0; j < JX; ++j) MMA::run(a, ld16(wb + j * 1024), xfr[j]);
             const bool half_block = PART && nbl == NBE - 1;       // 8 channels on each lane half (mb_pack_weights)
             const int ch0 = half_block ? nbl * 32 + h * 8 : nbl * 32 + h * 16;
 #pragma unroll
@@ -198,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
                 auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0][3]), __float_as_uint(d[1][3]), false, false); x0.w = s3[0]; x1.w = s3[1];
             }
 #pragma unroll
-            for (int i = 0; i < NBO; ++i) { mma_f32(acc[0][i], wpc[i], x0); mma_f32(acc[1][i], wpc[i], x1); }
+            for (int i = 0; i < NBO; ++i) { MMA::run(acc[0][i], wpc[i], x0); MMA::run(acc[1][i], wpc[i], x1); }
         }
     }
 
@@ -271,11 +267,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
 struct F4Entry {
     int k, s, jx, hc, nbo, res, var, lds_bytes;
     hipError_t (*fn)(hipStream_t, const MbParams&);
+    hipError_t (*fn_sp)(hipStream_t, const MbParams&);      // split-bf16 products (dtype 2)
 };
-template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW>
+template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW, bool SP>
 static hipError_t f4_launch_t(hipStream_t s, const MbParams& p) {
     typedef F4<KS, S, HC, TOH, TOW, JX, NW> G;
-    auto kfn = mbconv_f32_kernel<KS, S, NBO, RESID, NW, JX, HC, TOH, TOW, (JX >= 8)>;
+    auto kfn = mbconv_f32_kernel<KS, S, NBO, RESID, NW, JX, HC, TOH, TOW, (JX >= 8), SP>;
     static thread_local bool configured_dev[32] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     bool& configured = configured_dev[dev & 31];
@@ -285,12 +282,14 @@ static hipError_t f4_launch_t(hipStream_t s, const MbParams& p) {
         configured = true;
     }
     dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
-    set_kernel_tag("void cf::mbconv_f32_kernel<%d, %d, %d, %s, %d, %d, %d, %d, %d>(cf::MbParams)", KS, S, NBO, RESID ? "true" : "false", NW, JX, HC, TOH, TOW);
+    set_kernel_tag("void cf::mbconv_f32_kernel<%d, %d, %d, %s, %d, %d, %d, %d, %d, %s, %s>(cf::MbParams)", KS, S, NBO, RESID ? "true" : "false", NW, JX, HC, TOH, TOW,
+                   JX >= 8 ? "true" : "false", SP ? "true" : "false");
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
     return hipGetLastError();
 }
 #define F4E(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW) \
-    {KS, S, JX, HC, NBO, RES, V, F4<KS, S, HC, TOH, TOW, JX, NW>::LDS, &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW>}
+    {KS, S, JX, HC, NBO, RES, V, F4<KS, S, HC, TOH, TOW, JX, NW>::LDS, &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, false>, \
+     &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, true>}
 static const F4Entry kF4Table[] = {
     // Measured against cf_mbconv.hip's fp32 instances (B = 64, 640x640, ms, HIP events of tools/profile_ops.py; this kernel / that one):
     //   1.0  0.706-0.786 / 0.565    1.1  0.492 / 0.497    2.0  0.471-0.485 / 0.439    2.1  0.259 / 0.325
@@ -324,7 +323,8 @@ static const F4Entry* f4_find(int k, int s, int jx, int nbo, int res) {
     return base;                           // nullptr: the block stays on cf_mbconv.hip
 }
 
-bool mb4_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
+bool mb4_geometry(int dtype, MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
+    (void)dtype;                       // fp32 and split mode share the table (same storage, same tile geometry)
     static const int on = cf_ab_int("CF_F4", 1);      // A/B: 0 = cf_mbconv.hip's fp32 instance
     if (!on || (Cin % 8) || (Cout % 8) || Cout > 96 || Cin > 96 || hid == Cin) return false;
     const int jx = (Cin * 4 / 16 + 1) / 2, nbo = (Cout + 31) / 32;
@@ -344,7 +344,7 @@ bool mb4_geometry(MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
 // depthwise taps [chunk][group of 4 channels][tap][4] and project fragments [n-block][chunk][pair][lane] x 16 B: lane (row slot
 // i, half h) holds w[co(i)][chunk base + 8 pair + 4 h + e], e = 0..3 -- k-slot h of the e-th MFMA = channel e of group A / B.
 // The expand fragments are cf_mbconv.hip's (mb_pack_weights packs them before calling this).
-void mb4_repack(const MbGeom& g, int hid, int Cout, int k, const float* wd, const float* wp, float* wdw_host, void* wproj_host) {
+void mb4_repack(int dtype, const MbGeom& g, int hid, int Cout, int k, const float* wd, const float* wp, float* wdw_host, void* wproj_host) {
     for (int q = 0; q < g.nq; ++q)
         for (int grp = 0; grp < g.HC / 4; ++grp)
             for (int t = 0; t < k * k; ++t)
@@ -359,15 +359,15 @@ void mb4_repack(const MbGeom& g, int hid, int Cout, int k, const float* wd, cons
                     const int hh = (i >> 2) & 1, rr = (i & 3) + 4 * (i >> 3);
                     const int co = nbo * 32 + hh * 16 + rr;                     // = slot_channel(nbo, i) of cf_mbconv.hip
                     if (co >= Cout) continue;
-                    float* dst = (float*)((char*)wproj_host + ((((size_t)nbo * g.nq + q) * g.HALF + jp) * 64 + lane) * 16);
-                    for (int e = 0; e < 4; ++e) dst[e] = wp[(size_t)co * hid + q * g.HC + 8 * jp + 4 * h + e];
+                    char* dst = (char*)wproj_host + ((((size_t)nbo * g.nq + q) * g.HALF + jp) * 64 + lane) * 16;
+                    pack_chunk(dtype, wp + (size_t)co * hid + q * g.HC + 8 * jp + 4 * h, dst);
                 }
 }
 
-hipError_t mb4_launch(hipStream_t s, const MbParams& p) {
+hipError_t mb4_launch(hipStream_t s, int dtype, const MbParams& p) {
     const F4Entry* e = f4_find(p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
     if (!e || e->hc != p.HC) return hipErrorInvalidValue;
-    return e->fn(s, p);
+    return dtype == 2 ? e->fn_sp(s, p) : e->fn(s, p);
 }
 
 }  // namespace cf

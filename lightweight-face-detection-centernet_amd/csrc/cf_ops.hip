@@ -68,7 +68,7 @@ struct Scope {
     }
 };
 
-bool bad_dtype(int d) { return d != CF_F32 && d != CF_BF16; }
+bool bad_dtype(int d) { return d != CF_F32 && d != CF_BF16 && d != CF_F32_SPLIT; }
 
 void fold(const float* bn /*[4][C]: weight,bias,mean,var*/, int C, float eps, std::vector<double>& sc, std::vector<double>& sh) {
     sc.resize(C); sh.resize(C);

@@ -57,30 +57,11 @@ void pw_pack_weights(int dtype, const float* w, int K, int N, void* out_host) {
                 if (ch >= N || c >= NC) continue;
                 char* dst = (char*)out_host + (((size_t)nb * NCh + j) * 64 + lane) * 16;
                 const float* src = w + (size_t)ch * K + (size_t)c * P;
-                if (dtype == 0) {
-                    __builtin_memcpy(dst, src, 16);
-                } else {
-                    uint16_t* d = (uint16_t*)dst;
-                    for (int e = 0; e < 8; ++e) d[e] = host_f32_to_bf16(src[e]);
-                }
+                pack_chunk(dtype, src, dst);
             }
 }
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w),
-                                                      __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
-    }
-};
+template <typename T> using Mma = CfMma<T>;      // bf16 / exact fp32 / split-bf16 MFMA over one 16-byte chunk (cf_common.h)
 
 // RES: 0 none, 1 residual add, 2 IDAUp up-branch add
 template <typename T, int NBW, int ACT, int RES, bool BIAS>
@@ -510,7 +491,7 @@ __global__ void shuffle_copy_kernel(const T* x, T* y, long long M, int C, int ph
 hipError_t launch_shuffle_copy(hipStream_t s, int dtype, const void* x, void* y, long long M, int C, int phase, int ldy, int yoff) {
     if (M <= 0 || C <= 0) return hipSuccess;
     long long g = (M * C + 255) / 256; if (g > 16384) g = 16384;
-    if (dtype == 0) hipLaunchKernelGGL(shuffle_copy_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, M, C, phase, ldy, yoff);
+    if (dtype != 1) hipLaunchKernelGGL(shuffle_copy_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, M, C, phase, ldy, yoff);
     else hipLaunchKernelGGL(shuffle_copy_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, M, C, phase, ldy, yoff);
     return hipGetLastError();
 }
@@ -519,7 +500,7 @@ hipError_t launch_pw(hipStream_t s, int dtype, const PwParams& p) {
     if (p.M <= 0) return hipSuccess;
     if (p.K % 8 || p.N % 8) return hipErrorInvalidValue;
     if (p.ldy && ((p.ldy * (int)elem_size(dtype)) % 16 || (p.yoff * (int)elem_size(dtype)) % 16 || p.yoff + p.N > p.ldy)) return hipErrorInvalidValue;
-    return dtype == 0 ? dispatch_nbw<float>(s, p) : dispatch_nbw<bf16_t>(s, p);
+    return dtype == 0 ? dispatch_nbw<float>(s, p) : dtype == 2 ? dispatch_nbw<sp32_t>(s, p) : dispatch_nbw<bf16_t>(s, p);
 }
 
 }  // namespace cf

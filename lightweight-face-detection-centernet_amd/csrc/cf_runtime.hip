@@ -462,8 +462,8 @@ int cf_device_count(int* n) {
 int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags, cf_ctx** out) {
     if (!out) return CF_EINVAL;
     *out = nullptr;
-    if (max_batch < 1 || H < 32 || W < 32 || (H % 32) || (W % 32) || (dtype != CF_F32 && dtype != CF_BF16)) {
-        g_create_error = "cf_create: H and W must be positive multiples of 32, max_batch >= 1, dtype CF_F32|CF_BF16";
+    if (max_batch < 1 || H < 32 || W < 32 || (H % 32) || (W % 32) || (dtype != CF_F32 && dtype != CF_BF16 && dtype != CF_F32_SPLIT)) {
+        g_create_error = "cf_create: H and W must be positive multiples of 32, max_batch >= 1, dtype CF_F32|CF_BF16|CF_F32_SPLIT";
         return CF_EINVAL;
     }
     hipError_t e = hipSetDevice(device);

@@ -24,18 +24,19 @@ static inline int slot_channel0(int i) {
     return h * 16 + r;
 }
 // tap index of lane-half h, slot s (16 slots per lane); taps >= 27 are zero padding
-static inline int tap_of(int dtype, int s, int h) { return dtype == 0 ? 2 * s + h : (s >> 3) * 16 + h * 8 + (s & 7); }
+static inline int tap_of(int dtype, int s, int h) { return dtype != 1 ? 2 * s + h : (s >> 3) * 16 + h * 8 + (s & 7); }
 
-size_t stem_packed_bytes(int dtype) { return (size_t)(dtype == 0 ? 4 : 2) * 64 * 16; }
+size_t stem_packed_bytes(int dtype) { return (size_t)(dtype != 1 ? 4 : 2) * 64 * 16; }
 
 // w [32][3][3][3] (co, ci, ky, kx)  ->  [chunk][lane][16 B]; tap t = ky*9 + kx*3 + ci
 void stem_pack_weights(int dtype, const float* w, void* out_host) {
-    const int P = per16(dtype), NCH = dtype == 0 ? 4 : 2;
+    const int P = per16(dtype), NCH = dtype != 1 ? 4 : 2;
     __builtin_memset(out_host, 0, stem_packed_bytes(dtype));
     for (int c = 0; c < NCH; ++c)
         for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 31, h = lane >> 5, co = slot_channel0(i);
             char* dst = (char*)out_host + ((size_t)c * 64 + lane) * 16;
+            float vv[8];
             for (int e = 0; e < P; ++e) {
                 const int t = tap_of(dtype, c * P + e, h);
                 float v = 0.0f;
@@ -43,8 +44,9 @@ void stem_pack_weights(int dtype, const float* w, void* out_host) {
                     const int ky = t / 9, kx = (t % 9) / 3, ci = t % 3;
                     v = w[((co * 3 + ci) * 3 + ky) * 3 + kx];
                 }
-                if (dtype == 0) ((float*)dst)[e] = v; else ((uint16_t*)dst)[e] = host_f32_to_bf16(v);
+                vv[e] = v;
             }
+            pack_chunk(dtype, vv, dst);
         }
 }
 
@@ -100,13 +102,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p) {
     const char* wbase = (const char*)p.w + (size_t)lane * 16;
     if constexpr (F32) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const u32x4 wc = ld16(wbase + (size_t)c * 1024);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wc.x), v[4 * c + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wc.y), v[4 * c + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wc.z), v[4 * c + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wc.w), v[4 * c + 3], acc, 0, 0, 0);
-        }
+        for (int c = 0; c < 4; ++c) CfMma<T>::run(acc, ld16(wbase + (size_t)c * 1024), pack16<float>(&v[4 * c]));
     } else {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -133,10 +129,13 @@ hipError_t launch_stem(hipStream_t s, int dtype, const StemParams& p) {
     if (p.B <= 0) return hipSuccess;
     const long long total = (long long)p.B * (p.H / 2) * (p.W / 2);
     dim3 grid((unsigned)((total + 127) / 128)), blk(256);
-    set_kernel_tag("void cf::stem_kernel<%s, %d>(cf::StemParams)", dtype == 0 ? "float" : "unsigned short", p.in_format);
+    set_kernel_tag("void cf::stem_kernel<%s, %d>(cf::StemParams)", dtype == 0 ? "float" : dtype == 2 ? "sp32_t" : "unsigned short", p.in_format);
     if (dtype == 0) {
         if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem_kernel<float, CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
         else hipLaunchKernelGGL((stem_kernel<float, CF_IN_F32_NCHW>), grid, blk, 0, s, p);
+    } else if (dtype == 2) {
+        if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem_kernel<sp32_t, CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((stem_kernel<sp32_t, CF_IN_F32_NCHW>), grid, blk, 0, s, p);
     } else {
         if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem_kernel<bf16_t, CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
         else hipLaunchKernelGGL((stem_kernel<bf16_t, CF_IN_F32_NCHW>), grid, blk, 0, s, p);

@@ -62,28 +62,11 @@ void stem0_pack_proj(int dtype, const float* wp, void* out_host) {
             const int i = lane & 31, h = lane >> 5, co = slot_channel(0, i);
             if (co >= 16) continue;
             char* dst = (char*)out_host + ((size_t)j * 64 + lane) * 16;
-            for (int e = 0; e < P; ++e) {
-                float v = wp[co * 32 + (h * HALF + j) * P + e];
-                if (dtype == 0) ((float*)dst)[e] = v; else ((uint16_t*)dst)[e] = host_f32_to_bf16(v);
-            }
+            pack_chunk(dtype, wp + co * 32 + (h * HALF + j) * P, dst);
         }
 }
 
-template <typename T> struct S0Mma;
-template <> struct S0Mma<bf16_t> {
-    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w),
-                                                      __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
-    }
-};
-template <> struct S0Mma<float> {
-    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
-    }
-};
+template <typename T> using S0Mma = CfMma<T>;
 
 template <typename T, int FMT>
 __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
@@ -151,7 +134,7 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
                 val = idx == 0xffffffffu ? 0.0f : lut[idx];
             }
             if (tact && r < S0_PH) {
-                if constexpr (F32) Xs[r * S0_PROW + e] = val;
+                if constexpr (F32) reinterpret_cast<float*>(Xs)[r * S0_PROW + e] = val;
                 else Xs[r * S0_PROW + e] = (T)(pack_bf16x2(val, 0.0f) & 0xffffu);
             }
         }
@@ -168,7 +151,8 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
         const int ty = ipc / S0_IW, tx = ipc - ty * S0_IW;           // tile pixel on the H/2 grid
         const int y = oy0 - 1 + ty, x = ox0 - 1 + tx;
         const bool inmap = (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo;
-        const T* xp = Xs + (2 * ty) * S0_PROW + (2 * tx) * 3;
+        typedef typename std::conditional<F32, float, T>::type XT;
+        const XT* xp = reinterpret_cast<const XT*>(Xs) + (2 * ty) * S0_PROW + (2 * tx) * 3;
         f32x16 a;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.0f;
@@ -839,10 +823,13 @@ hipError_t launch_stem0(hipStream_t s, int dtype, const Stem0Params& p) {
         return hipGetLastError();
     }
     dim3 grid((Wo + S0_TOW - 1) / S0_TOW, (Ho + S0_TOH - 1) / S0_TOH, p.B), blk(S0_NT);
-    set_kernel_tag("void cf::stem0_kernel<%s, %d>(cf::Stem0Params)", dtype == 0 ? "float" : "unsigned short", p.in_format);
+    set_kernel_tag("void cf::stem0_kernel<%s, %d>(cf::Stem0Params)", dtype == 0 ? "float" : dtype == 2 ? "sp32_t" : "unsigned short", p.in_format);
     if (dtype == 0) {
         if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem0_kernel<float, CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
         else hipLaunchKernelGGL((stem0_kernel<float, CF_IN_F32_NCHW>), grid, blk, 0, s, p);
+    } else if (dtype == 2) {
+        if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem0_kernel<sp32_t, CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((stem0_kernel<sp32_t, CF_IN_F32_NCHW>), grid, blk, 0, s, p);
     } else {
         if (p.in_format == CF_IN_U8_HWC_BGR) hipLaunchKernelGGL((stem0_kernel<bf16_t, CF_IN_U8_HWC_BGR>), grid, blk, 0, s, p);
         else hipLaunchKernelGGL((stem0_kernel<bf16_t, CF_IN_F32_NCHW>), grid, blk, 0, s, p);

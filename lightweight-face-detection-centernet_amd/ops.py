@@ -8,7 +8,7 @@ import numpy as np
 from . import _lib
 from ._lib import f32, ptr
 
-_DT = {"fp32": 0, "bf16": 1}
+_DT = {"fp32": 0, "bf16": 1, "fp32_split": 2, "bf16x3": 2}
 
 
 def conv_dw(x, w, k, stride, pad=None, act="swish", bias=None, dtype="fp32", device=0):
