@@ -30,7 +30,9 @@ Extra objects in the line:
   parity         -- the timed batch decoded by the benchmarked (bf16) engine against the fp32 parity engine (itself
                     within 1e-3 of the reference) and, on one image, against the bf16-emulating oracle.
   value_with_h2d -- the same step with the batch starting in pinned HOST memory every step (PCIe inclusive).
-  fp32_parity_mode -- images/s of the fp32 parity mode at the same batch.
+  tolerance_mode -- images/s of the fp32_split mode (fp32 storage, split-bf16 GEMM products: within 1e-3 of the reference) at the
+                    same batch and schedule, with its head / decode differences against the exact-fp32 engine on the timed batch.
+  exact_fp32_mode -- images/s of the exact-fp32-MFMA mode (bit-level test mode).
 """
 import argparse
 import json
@@ -60,7 +62,7 @@ def parse(argv=None):
                     help="contexts per GPU used round-robin (batches in flight); 1 = a single context, every step on one stream chain")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip value_with_h2d / fp32_parity_mode / parity (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_with_h2d / tolerance_mode / exact_fp32_mode / parity (profiling runs)")
     ap.add_argument("--gather", default="auto", choices=["auto", "cf", "torch"],
                     help="N > 1 gather of the final boxes: cf = cf_gather_topk (C ABI, RCCL), torch = torch.distributed; "
                          "auto = cf, falling back to torch if the communicator cannot be created")
@@ -280,6 +282,30 @@ def parity_block(cfa, eng16, host_imgs, d_in_ptr, B, S, K, dev_index):
                     "bit-identical, layer by layer) is asserted in tests/test_bf16_parity.py; end to end two bf16 pipelines drift apart "
                     "through 1-ulp rounding flips"},
     }
+
+
+def tolerance_block(cfa, d_in_ptr, B, S, K, dev_index):
+    """The timed batch through the tolerance mode (fp32_split) against the exact-fp32 engine: every head value and the decode."""
+    fmt = cfa._lib.CF_IN_U8_HWC_BGR
+    res = {}
+    for dt in ("fp32", "fp32_split"):
+        e = cfa.Engine(S, S, max_batch=B, dtype=dt, device=dev_index)
+        e.forward_enqueue(d_in_ptr, on_device=True, B=B, in_format=fmt)
+        res[dt] = (e.heads(sigmoid_hm=True), e.decode_topk(K))
+        e.close()
+    (h0, (d0, l0, i0)), (h1, (d1, l1, i1)) = res["fp32"], res["fp32_split"]
+    out = {"images": B, "topk": K}
+    for k in ("hm", "wh", "lm", "reg", "hm_sigmoid"):
+        out["max_abs_diff_" + k] = float("%.3g" % np.abs(h0[k] - h1[k]).max())
+    out["allclose_1e-3"] = bool(all(np.allclose(h1[k], h0[k], rtol=1e-3, atol=1e-3) for k in ("hm", "wh", "lm", "reg", "hm_sigmoid")))
+    same = i0 == i1
+    out["same_index_same_rank_frac"] = round(float(same.mean()), 5)
+    out["max_abs_box_diff_map_px"] = float("%.3g" % np.abs(d0[..., :4][same] - d1[..., :4][same]).max()) if same.any() else None
+    out["max_abs_score_diff"] = float("%.3g" % np.abs(d0[..., 4][same] - d1[..., 4][same]).max()) if same.any() else None
+    # ranks that differ: score ties within the head difference (the two modes' rounding decides the order)
+    if (~same).any():
+        out["score_gap_at_differing_ranks_max"] = float("%.3g" % np.abs(d0[..., 4][~same] - d1[..., 4][~same]).max())
+    return out
 
 
 def main():
@@ -543,26 +569,40 @@ def main():
         for e in engs:
             e.close()
         eng_closed = True
-        r32 = cfa.EngineRing(S, S, depth=D, max_batch=B, dtype="fp32", device=local_rank)      # the same two-batches-in-flight schedule
-        o32 = outs if len(outs) == len(r32.engines) else [outs[0]] * len(r32.engines)
-        st32 = make_step(cfa, r32.engines, d_in_ptrs, B, K, o32)
 
-        def fence32():
-            for e in r32.engines:
-                e.synchronize()
-            torch.cuda.synchronize()
-        for _ in range(3):
-            st32()
-        w32 = time_windows(st32, fence32, 6, 7)
-        st32b = make_step(cfa, r32.engines[0], d_in_ptrs, B, K, out)
-        for _ in range(2):
-            st32b()
-        w32b = time_windows(st32b, fence32, 5, 5)
-        result["fp32_parity_mode"] = {"value": round(B * 6 / float(np.median(w32)), 1), "unit": "images/s", "batch": B,
-                                      "value_one_context": round(B * 5 / float(np.median(w32b)), 1),
-                                      "note": "fp32 storage + exact-fp32 MFMA (heads within 1e-3 of the reference); %d context(s) "
-                                              "round-robin like the headline; median of 7 windows of 6 steps" % len(r32.engines)}
-        r32.close()
+        def mode_rate(dtype):
+            """The headline's schedule (two contexts round-robin, rotating inputs) and the one-context schedule in another mode."""
+            r2 = cfa.EngineRing(S, S, depth=D, max_batch=B, dtype=dtype, device=local_rank)
+            o2 = outs if len(outs) == len(r2.engines) else [outs[0]] * len(r2.engines)
+            st = make_step(cfa, r2.engines, d_in_ptrs, B, K, o2)
+
+            def fence2():
+                for e in r2.engines:
+                    e.synchronize()
+                torch.cuda.synchronize()
+            for _ in range(3):
+                st()
+            w = time_windows(st, fence2, 6, 7)
+            stb = make_step(cfa, r2.engines[0], d_in_ptrs, B, K, out)
+            for _ in range(2):
+                stb()
+            wb = time_windows(stb, fence2, 5, 5)
+            r2.close()
+            return round(B * 6 / float(np.median(w)), 1), round(B * 5 / float(np.median(wb)), 1), len(r2.engines)
+        # ---- tolerance mode: the mode that meets north_star's "box/score within 1e-3 of the reference" at speed
+        v, v1, nctx = mode_rate("fp32_split")
+        result["tolerance_mode"] = {
+            "value": v, "unit": "images/s", "batch": B, "value_one_context": v1, "dtype": "fp32_split",
+            "arithmetic": "fp32 storage in HBM and LDS; every GEMM product (stem, expand, project, neck, heads) as a split-bf16 product on the bf16 "
+                          "matrix pipe: x = hi + lo (bf16 pairs, 16 mantissa bits), w.x = w_hi.x_hi + w_lo.x_hi + w_hi.x_lo on v_mfma_f32_32x32x8_bf16_1k, fp32 "
+                          "accumulate; Swish, depthwise taps, residual adds and epilogues in fp32",
+            "vs_exact_fp32_engine": tolerance_block(cfa, d_in.data_ptr(), B, S, K, local_rank),
+            "note": "%d context(s) round-robin like the headline; median of 7 windows of 6 steps; the reference-golden and oracle tests at "
+                    "rtol = atol = 1e-3 run on this mode too (tests/test_gpu_parity.py, EXACT)" % nctx}
+        v, v1, nctx = mode_rate("fp32")
+        result["exact_fp32_mode"] = {"value": v, "unit": "images/s", "batch": B, "value_one_context": v1,
+                                     "note": "fp32 storage + exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bit-equal to an fmaf chain), the bit-level "
+                                             "test mode; %d context(s) round-robin; median of 7 windows of 6 steps" % nctx}
     if not eng_closed:
         close_comms()
         for e in engs:

@@ -112,12 +112,20 @@ template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
 // (lane half h supplies k-slot group h: 8 bf16, or 4 fp32 values)
 typedef __attribute__((ext_vector_type(8))) __bf16 cf_bf16x8;
 typedef __attribute__((ext_vector_type(4))) short cf_s16x4;
+// two fp32 -> packed bf16x2 (RNE) through the COMPILER's v_cvt_pk_bf16_f32 selection, not the inline-asm pack_bf16x2 above: the
+// packed dwords below are MFMA operands a few instructions later, and hipcc pads no VALU-write -> MFMA-read wait states for a
+// register written inside an asm statement (stale operands on part of the waves: profiles/r03_mfma_depthwise.md section 6)
+typedef __attribute__((ext_vector_type(2))) __bf16 cf_bf16x2;
+__device__ __forceinline__ uint32_t cvt_bf16x2(float lo, float hi) {
+    f32x2 v; v.x = lo; v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, cf_bf16x2));
+}
 // four fp32 values -> (hi, lo) bf16 quads
 __device__ __forceinline__ void split4(const u32x4& x, u32x2& hi, u32x2& lo) {
     const float x0 = __uint_as_float(x.x), x1 = __uint_as_float(x.y), x2 = __uint_as_float(x.z), x3 = __uint_as_float(x.w);
-    hi.x = pack_bf16x2(x0, x1); hi.y = pack_bf16x2(x2, x3);
-    lo.x = pack_bf16x2(x0 - bf16lo(hi.x), x1 - bf16hi(hi.x));
-    lo.y = pack_bf16x2(x2 - bf16lo(hi.y), x3 - bf16hi(hi.y));
+    hi.x = cvt_bf16x2(x0, x1); hi.y = cvt_bf16x2(x2, x3);
+    lo.x = cvt_bf16x2(x0 - bf16lo(hi.x), x1 - bf16hi(hi.x));
+    lo.y = cvt_bf16x2(x2 - bf16lo(hi.y), x3 - bf16hi(hi.y));
 }
 __device__ __forceinline__ void mma_split_parts(f32x16& acc, const u32x4& w, const u32x2& xh, const u32x2& xl) {
     u32x2 wh, wl; wh.x = w.x; wh.y = w.y; wl.x = w.z; wl.y = w.w;               // host packing: [4 x hi | 4 x lo] (pack_split4)
