@@ -129,21 +129,41 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
     const char* wbase = (const char*)p.w0p + (size_t)lane * 16;
+    // Branch-free operand loads: every chunk is read from a clamped (valid) address and zeroed afterwards when it lies outside
+    // the map (= the conv's zero padding) -- a predicated load ends in a full vmcnt(0) wait each, and the 27 chunks of a pixel
+    // would be 27 serial memory round trips.  All chunks of kernel row dy + 1 are in flight while row dy's MFMAs run.
+    const char* img = (const char*)p.x + (size_t)b * p.h * p.w * 24 * sizeof(T);
+    auto load_row = [&](int dy, u32x4* xc) {
+        const int iy = y + dy - 1;
+        const int cy = min(max(iy, 0), p.h - 1);
+#pragma unroll
+        for (int j = 0; j < SPD; ++j) {
+            const int c = min(h * SPD + j, CPD - 1);
+            const int cx = min(max(x - 1 + c / CPP, 0), p.w - 1);
+            xc[j] = ld16(img + ((size_t)cy * p.w + cx) * 24 * sizeof(T) + (size_t)(c % CPP) * 16);
+        }
+    };
+    u32x4 xn[SPD];
+    load_row(0, xn);
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int iy = y + dy - 1;
         const bool yok = (unsigned)iy < (unsigned)p.h;
-        const char* row = (const char*)p.x + (((size_t)b * p.h + (yok ? iy : 0)) * p.w + (x - 1)) * 24 * sizeof(T);
+        u32x4 xc[SPD];
 #pragma unroll
         for (int j = 0; j < SPD; ++j) {
-            const int c = h * SPD + j;                         // chunk within the kernel row
+            const int c = h * SPD + j;
             const int ix = x - 1 + c / CPP;
             const bool ok = yok && c < CPD && (unsigned)ix < (unsigned)p.w;
-            u32x4 xc = ok ? ld16(row + (size_t)c * 16) : zero16();
+            xc[j].x = ok ? xn[j].x : 0u; xc[j].y = ok ? xn[j].y : 0u; xc[j].z = ok ? xn[j].z : 0u; xc[j].w = ok ? xn[j].w : 0u;
+        }
+        if (dy + 1 < 3) load_row(dy + 1, xn);
+#pragma unroll
+        for (int j = 0; j < SPD; ++j) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 u32x4 wc = ld16(wbase + (((size_t)i * 3 + dy) * SPD + j) * 1024);
-                HMma<T>::run(acc[i], wc, xc);
+                HMma<T>::run(acc[i], wc, xc[j]);
             }
         }
     }

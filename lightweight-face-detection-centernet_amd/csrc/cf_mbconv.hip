@@ -407,10 +407,30 @@ static const MbEntry kMbTable[] = {
     MB_ENTRY(sp32_t, 2, 3, 1, 3, 48, 1, 1, 8, 16, 1, 8),   // 1.1
     MB_ENTRY(sp32_t, 2, 5, 2, 3, 16, 1, 0, 8, 16, 1, 8),   // 2.0
     MB_ENTRY(sp32_t, 2, 5, 1, 4, 48, 1, 1, 8, 16, 1, 8),   // 2.1
-    MB_ENTRY(sp32_t, 2, 3, 2, 4, 32, 2, 0, 8, 16, 1, 8),   // 3.0
-    MB_ENTRY(sp32_t, 2, 3, 1, 8, 32, 2, 1, 8, 16, 1, 4),   // 3.1
+    MB_ENTRY(sp32_t, 2, 3, 2, 4, 32, 2, 0, 4, 16, 1, 4),   // 3.0  4x16 tile: 0.111 -> 0.095 (tools/split_sweep.sh)
+    MB_ENTRY(sp32_t, 2, 3, 1, 8, 32, 2, 1, 8, 16, 1, 8),   // 3.1  two k-groups: 0.1275 -> 0.123
     MB_ENTRY(sp32_t, 2, 5, 1, 8, 32, 3, 0, 8, 16, 1, 8),   // 4.0
     MB_ENTRY(sp32_t, 2, 5, 1, 12, 32, 3, 1, 8, 16, 1, 4),  // 4.1
+#ifdef CF_EXPERIMENTS   // A/B sweep of the split mode (CF_MB_VARIANT=1..3)
+    MB_VARIANT(1, sp32_t, 2, 3, 2, 2, 48, 1, 0, 4, 16, 1, 4),    // 1.0 HC 48
+    MB_VARIANT(2, sp32_t, 2, 3, 2, 2, 96, 1, 0, 4, 16, 1, 4),    // 1.0 HC 96
+    MB_VARIANT(3, sp32_t, 2, 3, 2, 2, 32, 1, 0, 8, 16, 1, 8),    // 1.0 8x16
+    MB_VARIANT(1, sp32_t, 2, 5, 2, 3, 16, 1, 0, 4, 16, 1, 4),    // 2.0 4x16 HC 16
+    MB_VARIANT(2, sp32_t, 2, 5, 2, 3, 48, 1, 0, 4, 16, 1, 4),    // 2.0 4x16 HC 48
+    MB_VARIANT(3, sp32_t, 2, 5, 2, 3, 48, 1, 0, 8, 16, 1, 8),    // 2.0 8x16 HC 48
+    MB_VARIANT(1, sp32_t, 2, 3, 2, 4, 32, 2, 0, 4, 16, 1, 4),    // 3.0 4x16
+    MB_VARIANT(2, sp32_t, 2, 3, 2, 4, 64, 2, 0, 8, 16, 1, 8),    // 3.0 HC 64
+    MB_VARIANT(3, sp32_t, 2, 3, 2, 4, 32, 2, 0, 8, 16, 1, 4),    // 3.0 one k-group
+    MB_VARIANT(1, sp32_t, 2, 3, 1, 8, 64, 2, 1, 8, 16, 1, 8),    // 3.1 HC 64, 8 waves
+    MB_VARIANT(2, sp32_t, 2, 3, 1, 8, 32, 2, 1, 16, 16, 1, 8),   // 3.1 16x16
+    MB_VARIANT(3, sp32_t, 2, 3, 1, 8, 32, 2, 1, 8, 16, 1, 8),    // 3.1 two k-groups
+    MB_VARIANT(1, sp32_t, 2, 5, 1, 8, 64, 3, 0, 8, 16, 1, 8),    // 4.0 HC 64
+    MB_VARIANT(2, sp32_t, 2, 5, 1, 8, 32, 3, 0, 16, 16, 1, 8),   // 4.0 16x16
+    MB_VARIANT(3, sp32_t, 2, 5, 1, 8, 32, 3, 0, 8, 32, 1, 8),    // 4.0 8x32
+    MB_VARIANT(1, sp32_t, 2, 5, 1, 12, 32, 3, 1, 8, 16, 1, 8),   // 4.1 two k-groups
+    MB_VARIANT(2, sp32_t, 2, 5, 1, 12, 64, 3, 1, 8, 16, 1, 8),   // 4.1 HC 64
+    MB_VARIANT(3, sp32_t, 2, 5, 1, 12, 32, 3, 1, 8, 32, 1, 8),   // 4.1 8x32
+#endif
 };
 #undef MB_ENTRY
 

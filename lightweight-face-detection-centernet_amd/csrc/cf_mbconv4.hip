@@ -265,14 +265,14 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
 
 // ---------------------------------------------------------------- host side
 struct F4Entry {
-    int k, s, jx, hc, nbo, res, var, lds_bytes;
+    int k, s, jx, hc, nbo, res, var, lds_bytes;      // var 0: default (both modes), 1: CF_F4_VARIANT=1, 2: default in split mode only
     hipError_t (*fn)(hipStream_t, const MbParams&);
     hipError_t (*fn_sp)(hipStream_t, const MbParams&);      // split-bf16 products (dtype 2)
 };
-template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW, bool SP>
+template <int KS, int S, int NBO, bool RESID, int NW, int JX, int HC, int TOH, int TOW, bool SP, bool XR>
 static hipError_t f4_launch_t(hipStream_t s, const MbParams& p) {
     typedef F4<KS, S, HC, TOH, TOW, JX, NW> G;
-    auto kfn = mbconv_f32_kernel<KS, S, NBO, RESID, NW, JX, HC, TOH, TOW, (JX >= 8), SP>;
+    auto kfn = mbconv_f32_kernel<KS, S, NBO, RESID, NW, JX, HC, TOH, TOW, XR, SP>;
     static thread_local bool configured_dev[32] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     bool& configured = configured_dev[dev & 31];
@@ -283,13 +283,14 @@ static hipError_t f4_launch_t(hipStream_t s, const MbParams& p) {
     }
     dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(NW * 64);
     set_kernel_tag("void cf::mbconv_f32_kernel<%d, %d, %d, %s, %d, %d, %d, %d, %d, %s, %s>(cf::MbParams)", KS, S, NBO, RESID ? "true" : "false", NW, JX, HC, TOH, TOW,
-                   JX >= 8 ? "true" : "false", SP ? "true" : "false");
+                   XR ? "true" : "false", SP ? "true" : "false");
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
     return hipGetLastError();
 }
-#define F4E(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW) \
-    {KS, S, JX, HC, NBO, RES, V, F4<KS, S, HC, TOH, TOW, JX, NW>::LDS, &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, false>, \
-     &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, true>}
+#define F4X(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW, XR) \
+    {KS, S, JX, HC, NBO, RES, V, F4<KS, S, HC, TOH, TOW, JX, NW>::LDS, &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, false, (XR != 0)>, \
+     &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, true, (XR != 0)>}
+#define F4E(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW) F4X(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW, (JX >= 8))
 static const F4Entry kF4Table[] = {
     // Measured against cf_mbconv.hip's fp32 instances (B = 64, 640x640, ms, HIP events of tools/profile_ops.py; this kernel / that one):
     //   1.0  0.706-0.786 / 0.565    1.1  0.492 / 0.497    2.0  0.471-0.485 / 0.439    2.1  0.259 / 0.325
@@ -300,6 +301,12 @@ static const F4Entry kF4Table[] = {
     // extra accumulators (two pixel blocks per wave: 32 NBO registers more) cost occupancy.  Only layer2.1 runs here.
     //  var KS S JX HC NBO res tile   waves
     F4E(0, 5, 1, 4, 32, 1, 1, 8, 16, 4),     // 2.1  32 -> 192 -> 32
+    // split mode (dtype 2: the MFMA share of the block is 2.7x smaller, the LDS share decides): layer1.1 0.371 -> 0.337 ms here
+    F4E(2, 3, 1, 3, 48, 1, 1, 8, 16, 4),     // 1.1  24 -> 144 -> 24
+    // split-mode sweep (tools/split_sweep.sh, profiles/r04_split_sweep.txt): 4x16 stride-2 tiles with four k-groups for 1.0
+    // (0.438 on cf_mbconv.hip -> 0.414), eight waves / HC 64 for 2.1 (0.2175 -> 0.2056)
+    F4X(2, 3, 2, 2, 32, 1, 0, 4, 16, 4, 0),  // 1.0  16 ->  96 -> 24
+    F4X(2, 5, 1, 4, 64, 1, 1, 8, 16, 8, 0),  // 2.1  32 -> 192 -> 32
     // CF_F4_VARIANT=1: every block shape on this kernel (A/B runs, parity tests)
     F4E(1, 3, 2, 2, 32, 1, 0, 8, 16, 4),     // 1.0  16 ->  96 -> 24
     F4E(1, 3, 1, 3, 48, 1, 1, 8, 16, 4),     // 1.1  24 -> 144 -> 24
@@ -309,26 +316,61 @@ static const F4Entry kF4Table[] = {
     F4E(1, 3, 1, 8, 32, 2, 1, 8, 16, 4),     // 3.1  64 -> 384 -> 64
     F4E(1, 5, 1, 8, 32, 3, 0, 8, 16, 4),     // 4.0  64 -> 384 -> 96
     F4E(1, 5, 1, 12, 32, 3, 1, 8, 16, 4),    // 4.1  96 -> 576 -> 96
+#ifdef CF_EXPERIMENTS   // A/B sweep of the split mode (CF_F4_VARIANT=3..6): small stride-2 tiles, X fragments resident for wide Cin
+    F4X(3, 3, 2, 2, 32, 1, 0, 4, 16, 2, 0),    // 1.0 4x16, KG 2
+    F4X(4, 3, 2, 2, 32, 1, 0, 4, 16, 4, 0),    // 1.0 4x16, KG 4
+    F4X(5, 3, 2, 2, 96, 1, 0, 4, 16, 4, 0),    // 1.0 4x16, HC 96
+    F4X(6, 3, 2, 2, 48, 1, 0, 4, 16, 2, 0),    // 1.0 4x16, HC 48 (KG 2: 3 pairs each)
+    F4X(3, 5, 2, 3, 48, 1, 0, 4, 16, 2, 0),    // 2.0 4x16 HC 48 KG 2
+    F4X(4, 5, 2, 3, 48, 1, 0, 4, 16, 3, 0),    // 2.0 4x16 HC 48 KG 3
+    F4X(5, 5, 2, 3, 16, 1, 0, 4, 16, 2, 0),    // 2.0 4x16 HC 16 KG 2
+    F4X(6, 5, 2, 3, 16, 1, 0, 8, 16, 4, 0),    // 2.0 8x16 HC 16 KG 2
+    F4X(3, 3, 2, 4, 32, 2, 0, 4, 16, 2, 0),    // 3.0 4x16 KG 2
+    F4X(4, 3, 2, 4, 32, 2, 0, 4, 16, 4, 0),    // 3.0 4x16 KG 4
+    F4X(5, 3, 2, 4, 64, 2, 0, 4, 16, 4, 0),    // 3.0 4x16 HC 64
+    F4X(6, 3, 2, 4, 32, 2, 0, 8, 16, 8, 0),    // 3.0 8x16 KG 4
+    F4X(3, 3, 1, 8, 32, 2, 1, 8, 16, 4, 0),    // 3.1 X resident, 4 waves
+    F4X(4, 3, 1, 8, 32, 2, 1, 8, 16, 8, 0),    // 3.1 X resident, 8 waves (KG 4)
+    F4X(5, 3, 1, 8, 64, 2, 1, 8, 16, 8, 0),    // 3.1 HC 64, 8 waves
+    F4X(6, 3, 1, 8, 64, 2, 1, 8, 16, 4, 0),    // 3.1 HC 64, 4 waves
+    F4X(3, 5, 1, 8, 32, 3, 0, 8, 16, 4, 0),    // 4.0 X resident, 4 waves
+    F4X(4, 5, 1, 8, 32, 3, 0, 8, 16, 8, 0),    // 4.0 X resident, 8 waves
+    F4X(5, 5, 1, 8, 64, 3, 0, 8, 16, 8, 0),    // 4.0 HC 64
+    F4X(6, 5, 1, 8, 32, 3, 0, 8, 16, 8, 1),    // 4.0 X reload, 8 waves
+    F4X(3, 5, 1, 12, 32, 3, 1, 8, 16, 4, 0),   // 4.1 X resident, 4 waves
+    F4X(4, 5, 1, 12, 32, 3, 1, 8, 16, 8, 0),   // 4.1 X resident, 8 waves
+    F4X(5, 5, 1, 12, 64, 3, 1, 8, 16, 8, 0),   // 4.1 HC 64
+    F4X(6, 5, 1, 12, 32, 3, 1, 8, 16, 8, 1),   // 4.1 X reload, 8 waves
+    F4X(3, 3, 1, 3, 48, 1, 1, 8, 16, 2, 0),    // 1.1 2 waves
+    F4X(4, 3, 1, 3, 48, 1, 1, 8, 16, 6, 0),    // 1.1 KG 3
+    F4X(5, 3, 1, 3, 144, 1, 1, 8, 16, 4, 0),   // 1.1 HC 144 (one round)
+    F4X(6, 3, 1, 3, 48, 1, 1, 16, 16, 4, 0),   // 1.1 16x16
+    F4X(3, 5, 1, 4, 32, 1, 1, 8, 16, 8, 0),    // 2.1 KG 4
+    F4X(4, 5, 1, 4, 64, 1, 1, 8, 16, 4, 0),    // 2.1 HC 64
+    F4X(5, 5, 1, 4, 64, 1, 1, 8, 16, 8, 0),    // 2.1 HC 64 KG 4
+    F4X(6, 5, 1, 4, 32, 1, 1, 16, 16, 4, 0),   // 2.1 16x16
+#endif
 };
 #undef F4E
+#undef F4X
 
-static const F4Entry* f4_find(int k, int s, int jx, int nbo, int res) {
+static const F4Entry* f4_find(int dtype, int k, int s, int jx, int nbo, int res) {
     static const int want = cf_env_int("CF_F4_VARIANT", 0);      // product switch: 1 = every fp32 block on this file's kernel
     const F4Entry* base = nullptr;
     for (const F4Entry& e : kF4Table)
         if (e.k == k && e.s == s && e.jx == jx && e.nbo == nbo && e.res == res) {
-            if (e.var == want) return &e;
-            if (e.var == 0) base = &e;
+            if (want && e.var == want) return &e;
+            if (e.var == 0 || (e.var == 2 && dtype == 2)) base = &e;
         }
     return base;                           // nullptr: the block stays on cf_mbconv.hip
 }
 
 bool mb4_geometry(int dtype, MbGeom& g, int Cin, int hid, int Cout, int k, int s) {
-    (void)dtype;                       // fp32 and split mode share the table (same storage, same tile geometry)
+    // fp32 and split mode share the table (same storage, same tile geometry); some rows are the default in split mode only
     static const int on = cf_ab_int("CF_F4", 1);      // A/B: 0 = cf_mbconv.hip's fp32 instance
     if (!on || (Cin % 8) || (Cout % 8) || Cout > 96 || Cin > 96 || hid == Cin) return false;
     const int jx = (Cin * 4 / 16 + 1) / 2, nbo = (Cout + 31) / 32;
-    const F4Entry* e = f4_find(k, s, jx, nbo, (Cin == Cout && s == 1) ? 1 : 0);
+    const F4Entry* e = f4_find(dtype, k, s, jx, nbo, (Cin == Cout && s == 1) ? 1 : 0);
     if (!e || hid % e->hc) return false;
     g = MbGeom{};
     g.ok = true; g.kind = 7; g.S = s;
@@ -365,7 +407,7 @@ void mb4_repack(int dtype, const MbGeom& g, int hid, int Cout, int k, const floa
 }
 
 hipError_t mb4_launch(hipStream_t s, int dtype, const MbParams& p) {
-    const F4Entry* e = f4_find(p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
+    const F4Entry* e = f4_find(dtype, p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
     if (!e || e->hc != p.HC) return hipErrorInvalidValue;
     return dtype == 2 ? e->fn_sp(s, p) : e->fn(s, p);
 }
