@@ -133,10 +133,17 @@ __device__ __forceinline__ void mma_split_parts(f32x16& acc, const u32x4& w, con
     acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(cf_s16x4, wh), __builtin_bit_cast(cf_s16x4, xl), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(cf_s16x4, wh), __builtin_bit_cast(cf_s16x4, xh), acc, 0, 0, 0);
 }
+// run2: two consecutive operand chunks (k-steps j, j + 1 of the lane) at once.  bf16 / exact fp32: two run() calls.  Split mode:
+// the eight fp32 values of the pair are ONE k = 16 step of v_mfma_f32_32x32x16_bf16 (twice the rate of the k = 8 form): the
+// host stores the pair's weights as [8 x hi] in fragment slot j and [8 x lo] in slot j + 1 (split_pairs_inplace); an unpaired
+// last chunk keeps the [4 x hi | 4 x lo] form of run().
 template <typename T> struct CfMma;
 template <> struct CfMma<bf16_t> {
     static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, w), __builtin_bit_cast(cf_bf16x8, x), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void run2(f32x16& acc, const u32x4& w0, const u32x4& w1, const u32x4& x0, const u32x4& x1) {
+        run(acc, w0, x0); run(acc, w1, x1);
     }
 };
 template <> struct CfMma<float> {
@@ -146,13 +153,40 @@ template <> struct CfMma<float> {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
     }
+    static __device__ __forceinline__ void run2(f32x16& acc, const u32x4& w0, const u32x4& w1, const u32x4& x0, const u32x4& x1) {
+        run(acc, w0, x0); run(acc, w1, x1);
+    }
 };
+// the split halves of a chunk pair, computed once and reused against several weight blocks
+struct SplitPair { u32x4 hi, lo; };
+__device__ __forceinline__ SplitPair split8(const u32x4& x0, const u32x4& x1) {
+    u32x2 h0, l0, h1, l1;
+    split4(x0, h0, l0); split4(x1, h1, l1);
+    SplitPair s;
+    s.hi.x = h0.x; s.hi.y = h0.y; s.hi.z = h1.x; s.hi.w = h1.y;
+    s.lo.x = l0.x; s.lo.y = l0.y; s.lo.z = l1.x; s.lo.w = l1.y;
+    return s;
+}
 template <> struct CfMma<sp32_t> {
     static __device__ __forceinline__ void run(f32x16& acc, const u32x4& w, const u32x4& x) {
         u32x2 xh, xl; split4(x, xh, xl);
         mma_split_parts(acc, w, xh, xl);
     }
+    static __device__ __forceinline__ void run2(f32x16& acc, const u32x4& whi, const u32x4& wlo, const u32x4& x0, const u32x4& x1) {
+        const SplitPair s = split8(x0, x1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, wlo), __builtin_bit_cast(cf_bf16x8, s.hi), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, whi), __builtin_bit_cast(cf_bf16x8, s.lo), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, whi), __builtin_bit_cast(cf_bf16x8, s.hi), acc, 0, 0, 0);
+    }
 };
+// acc += sum over the J operand chunks of a lane: pairs through run2, an odd last chunk through run (straight-line: J, w(j), x(j)
+// are compile-time indexable)
+template <typename T, int J, typename WF, typename XF>
+__device__ __forceinline__ void mma_chain(f32x16& acc, WF w, XF x) {
+#pragma unroll
+    for (int j = 0; j + 1 < J; j += 2) CfMma<T>::run2(acc, w(j), w(j + 1), x(j), x(j + 1));
+    if constexpr (J & 1) CfMma<T>::run(acc, w(J - 1), x(J - 1));
+}
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
@@ -290,9 +324,33 @@ static inline void pack_split4(const float* src, void* dst16) {
         d[4 + e] = host_f32_to_bf16(src[e] - host_bf16_to_f32(hi));
     }
 }
-// host: P elements of storage/operand type `dtype` (0 fp32, 1 bf16, 2 split) into a 16-byte fragment chunk
+// host: fragments packed as fp32 ([group][J slots][64 lanes] x 16 B = four fp32 each) -> the split mode's operand format, in
+// place: slots (2i, 2i + 1) of a group become [8 x hi] and [8 x lo] of the pair's eight weights (CfMma<sp32_t>::run2), an odd
+// last slot becomes [4 x hi | 4 x lo] (run).  The kernel walks the same J slots in the same pairs (mma_chain).
+static inline void split_pairs_inplace(void* frags, size_t ngroups, int J) {
+    char* base = (char*)frags;
+    for (size_t g = 0; g < ngroups; ++g) {
+        char* grp = base + g * (size_t)J * 1024;
+        for (int j = 0; j + 1 < J; j += 2)
+            for (int lane = 0; lane < 64; ++lane) {
+                char* c0 = grp + ((size_t)j * 64 + lane) * 16, * c1 = c0 + 1024;
+                float v[8];
+                __builtin_memcpy(v, c0, 16); __builtin_memcpy(v + 4, c1, 16);
+                uint16_t hi[8], lo[8];
+                for (int e = 0; e < 8; ++e) { hi[e] = host_f32_to_bf16(v[e]); lo[e] = host_f32_to_bf16(v[e] - host_bf16_to_f32(hi[e])); }
+                __builtin_memcpy(c0, hi, 16); __builtin_memcpy(c1, lo, 16);
+            }
+        if (J & 1)
+            for (int lane = 0; lane < 64; ++lane) {
+                char* c = grp + ((size_t)(J - 1) * 64 + lane) * 16;
+                float v[4]; __builtin_memcpy(v, c, 16);
+                pack_split4(v, c);
+            }
+    }
+}
+// host: P elements of storage/operand type `dtype` into a 16-byte fragment chunk: 0 fp32 and 2 split (raw fp32 here -- every
+// packer of the split mode finishes with split_pairs_inplace over its fragment groups), 1 bf16
 static inline void pack_chunk(int dtype, const float* src, void* dst16) {
-    if (dtype == 0) __builtin_memcpy(dst16, src, 16);
-    else if (dtype == 2) pack_split4(src, dst16);
+    if (dtype != 1) __builtin_memcpy(dst16, src, 16);
     else for (int e = 0; e < 8; ++e) ((uint16_t*)dst16)[e] = host_f32_to_bf16(src[e]);
 }

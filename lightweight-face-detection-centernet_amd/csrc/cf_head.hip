@@ -84,6 +84,7 @@ void head_pack_weights(int dtype, int collapsed, const float* w0, const float* b
                     }
                     pack_chunk(dtype, vv, dst);
                 }
+    if (dtype == 2) split_pairs_inplace(w0p_host, (size_t)NB * 3, SPD);        // the SPD chunk steps of a kernel row in pairs
     for (int q = 0; q < (collapsed ? 16 : 96); ++q) b0_host[q] = q < NQ ? (float)bq[q] : 0.0f;
     if (collapsed == 2) b0_host[15] = (float)bq[0];
     for (int i = 0; i < 96 * 16; ++i) w1d_host[i] = 0.0f;
@@ -159,13 +160,8 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
         }
         if (dy + 1 < 3) load_row(dy + 1, xn);
 #pragma unroll
-        for (int j = 0; j < SPD; ++j) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                u32x4 wc = ld16(wbase + (((size_t)i * 3 + dy) * SPD + j) * 1024);
-                HMma<T>::run(acc[i], wc, xc[j]);
-            }
-        }
+        for (int i = 0; i < NB; ++i)
+            mma_chain<T, SPD>(acc[i], [&](int j) { return ld16(wbase + (((size_t)i * 3 + dy) * SPD + j) * 1024); }, [&](int j) { return xc[j]; });
     }
 
     // ---- second stage.  Lane (pixel, h) holds first-stage channels nb*32 + h*16 + r.

@@ -71,6 +71,8 @@ struct MbGeom {
     int NBE, JX, HALF, NBO, rowb;
     size_t lds_bytes, wexp_bytes, wdw_floats, wproj_bytes;
     int kind, S;          // kind 0: cf_mbconv.hip, 1: cf_mbconv2.hip (fp16 pixel-pair tile, bf16 storage only)
+    int KG;               // k-groups of the project loop (fp32 / split kernels: the wave groups that split a hidden chunk's k-steps);
+                          // the split mode packs the project fragments in pairs per k-group (split_pairs_inplace)
 };
 MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s);
 void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int k,

@@ -49,7 +49,7 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
     if (g.kind == 6) { mx_fused2_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 7) {                       // cf_mbconv4.hip: this file's expand fragments, its own tap table and project fragments
         MbGeom g0 = g; g0.kind = 0;
-        mb_pack_weights(dtype, g0, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host);
+        mb_pack_weights(dtype, g0, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host);      // (its project fragments are overwritten)
         mb4_repack(dtype, g, hid, Cout, k, wd, wp, wdw_host, wproj_host);
         return;
     }
@@ -89,6 +89,12 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
                     char* dst = (char*)wproj_host + ((((size_t)nbo * g.nq + q) * g.HALF + j) * 64 + lane) * 16;
                     put(dst, wp + (size_t)co * hid + hc, P);
                 }
+    }
+    if (dtype == 2) {                                               // split mode: chunk pairs per MFMA chain (cf_common.h)
+        split_pairs_inplace(wexp_host, (size_t)g.nq * g.NBE, g.JX);                             // expand: the JX chunks of a lane half
+        // project: one chunk per MFMA set.  Pairing the k-steps here (two depthwise chunks + two weight fragments per n-block live
+        // at once) cost layer4.1 its second wave per SIMD (0.331 -> 0.463 ms) and gained nothing on 3.x: measured, not kept
+        split_pairs_inplace(wproj_host, (size_t)g.NBO * g.nq * g.HALF, 1);
     }
 }
 
@@ -190,8 +196,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = 0.0f;
             const char* wb = wx + (nbl * JX * 64 + lane) * 16;
-#pragma unroll
-            for (int j = 0; j < JX; ++j) MbMma<T>::run(a, ld16(wb + j * 1024), xfr[j]);
+            mma_chain<T, JX>(a, [&](int j) { return ld16(wb + j * 1024); }, [&](int j) { return xfr[j]; });
             constexpr bool PARTIAL = (HC % 32 == 16);
             if (PARTIAL && nbl == NBE - 1) {
                 // half-filled last block: channels nbl*32 + h*8 + [0,8) live in registers 0..7
@@ -463,6 +468,7 @@ MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
     g.HALF = g.HC * sz / 16 / 2;
     g.rowb = g.HC * (e->ef ? 4 : sz) + 16;
     g.lds_bytes = (size_t)e->lds_bytes;
+    g.KG = e->nw / (e->toh * e->tow / 32);
     g.wexp_bytes = (size_t)g.nq * g.NBE * g.JX * 64 * 16;
     g.wdw_floats = (size_t)g.nq * k * k * g.HC;
     g.wproj_bytes = (size_t)g.NBO * g.nq * g.HALF * 64 * 16;

@@ -117,8 +117,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = 0.0f;
             const char* wb = wx + (nbl * JX * 64 + lane) * 16;
-#pragma unroll
-            for (int j = 0; j < JX; ++j) MMA::run(a, ld16(wb + j * 1024), xfr[j]);
+            mma_chain<typename std::conditional<SP, sp32_t, float>::type, JX>(a, [&](int j) { return ld16(wb + j * 1024); }, [&](int j) { return xfr[j]; });
             const bool half_block = PART && nbl == NBE - 1;       // 8 channels on each lane half (mb_pack_weights)
             const int ch0 = half_block ? nbl * 32 + h * 8 : nbl * 32 + h * 16;
 #pragma unroll
@@ -154,13 +153,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
         if (q + 1 < nq) stage_weights(q + 1);
 
         // ---- phase 2 + 3: depthwise + Swish on channel groups A, B; swap halves; project MFMAs of both pixel blocks
-#pragma unroll
-        for (int js = 0; js < JS; ++js) {
-            const int jp = kg * JS + js;                                        // pair of groups 2 jp, 2 jp + 1 (wave-uniform)
-            u32x4 wpc[NBO];
-#pragma unroll
-            for (int i = 0; i < NBO; ++i)
-                wpc[i] = ld16((const char*)p.wproj + ((((size_t)i * nq + q) * G::NPAIR + jp) * 64 + lane) * 16);
+        // one step = the pair of channel groups 2 jp, 2 jp + 1 -> the operand chunks x0 (pixel block 0) and x1 (pixel block 1)
+        auto dw_step = [&](int jp, u32x4& x0, u32x4& x1) {
             float d[2][4];
 #pragma unroll
             for (int ab = 0; ab < 2; ++ab) {
@@ -186,15 +180,48 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
                     d[ab][c] = y2.x; d[ab][c + 1] = y2.y;
                 }
             }
-            u32x4 x0, x1;
-            {
-                auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0][0]), __float_as_uint(d[1][0]), false, false); x0.x = s0[0]; x1.x = s0[1];
-                auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0][1]), __float_as_uint(d[1][1]), false, false); x0.y = s1[0]; x1.y = s1[1];
-                auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0][2]), __float_as_uint(d[1][2]), false, false); x0.z = s2[0]; x1.z = s2[1];
-                auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0][3]), __float_as_uint(d[1][3]), false, false); x0.w = s3[0]; x1.w = s3[1];
+            auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0][0]), __float_as_uint(d[1][0]), false, false); x0.x = s0[0]; x1.x = s0[1];
+            auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0][1]), __float_as_uint(d[1][1]), false, false); x0.y = s1[0]; x1.y = s1[1];
+            auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0][2]), __float_as_uint(d[1][2]), false, false); x0.z = s2[0]; x1.z = s2[1];
+            auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[0][3]), __float_as_uint(d[1][3]), false, false); x0.w = s3[0]; x1.w = s3[1];
+        };
+        auto wproj_at = [&](int i, int jp) { return ld16((const char*)p.wproj + ((((size_t)i * nq + q) * G::NPAIR + jp) * 64 + lane) * 16); };
+        if constexpr (SP) {
+            // split mode: the JS steps of this k-group in pairs (one k = 16 MFMA set per pair and pixel block), an odd last step alone
+#pragma unroll
+            for (int js = 0; js + 1 < JS; js += 2) {
+                const int jp = kg * JS + js;
+                u32x4 w0[NBO], w1[NBO];
+#pragma unroll
+                for (int i = 0; i < NBO; ++i) { w0[i] = wproj_at(i, jp); w1[i] = wproj_at(i, jp + 1); }
+                u32x4 xa0, xa1, xb0, xb1;
+                dw_step(jp, xa0, xa1);
+                dw_step(jp + 1, xb0, xb1);
+#pragma unroll
+                for (int i = 0; i < NBO; ++i) { MMA::run2(acc[0][i], w0[i], w1[i], xa0, xb0); MMA::run2(acc[1][i], w0[i], w1[i], xa1, xb1); }
             }
+            if constexpr (JS & 1) {
+                const int jp = kg * JS + JS - 1;
+                u32x4 w0[NBO];
+#pragma unroll
+                for (int i = 0; i < NBO; ++i) w0[i] = wproj_at(i, jp);
+                u32x4 x0, x1;
+                dw_step(jp, x0, x1);
+#pragma unroll
+                for (int i = 0; i < NBO; ++i) { MMA::run(acc[0][i], w0[i], x0); MMA::run(acc[1][i], w0[i], x1); }
+            }
+        } else {
+#pragma unroll
+        for (int js = 0; js < JS; ++js) {
+            const int jp = kg * JS + js;                                        // pair of groups 2 jp, 2 jp + 1 (wave-uniform)
+            u32x4 wpc[NBO];
+#pragma unroll
+            for (int i = 0; i < NBO; ++i) wpc[i] = wproj_at(i, jp);
+            u32x4 x0, x1;
+            dw_step(jp, x0, x1);
 #pragma unroll
             for (int i = 0; i < NBO; ++i) { MMA::run(acc[0][i], wpc[i], x0); MMA::run(acc[1][i], wpc[i], x1); }
+        }
         }
     }
 
@@ -265,7 +292,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
 
 // ---------------------------------------------------------------- host side
 struct F4Entry {
-    int k, s, jx, hc, nbo, res, var, lds_bytes;      // var 0: default (both modes), 1: CF_F4_VARIANT=1, 2: default in split mode only
+    int k, s, jx, hc, nbo, res, var, lds_bytes, kg;  // var 0: default (both modes), 1: CF_F4_VARIANT=1, 2: default in split mode only
     hipError_t (*fn)(hipStream_t, const MbParams&);
     hipError_t (*fn_sp)(hipStream_t, const MbParams&);      // split-bf16 products (dtype 2)
 };
@@ -288,7 +315,7 @@ static hipError_t f4_launch_t(hipStream_t s, const MbParams& p) {
     return hipGetLastError();
 }
 #define F4X(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW, XR) \
-    {KS, S, JX, HC, NBO, RES, V, F4<KS, S, HC, TOH, TOW, JX, NW>::LDS, &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, false, (XR != 0)>, \
+    {KS, S, JX, HC, NBO, RES, V, F4<KS, S, HC, TOH, TOW, JX, NW>::LDS, F4<KS, S, HC, TOH, TOW, JX, NW>::KG, &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, false, (XR != 0)>, \
      &f4_launch_t<KS, S, NBO, (RES != 0), NW, JX, HC, TOH, TOW, true, (XR != 0)>}
 #define F4E(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW) F4X(V, KS, S, JX, HC, NBO, RES, TOH, TOW, NW, (JX >= 8))
 static const F4Entry kF4Table[] = {
@@ -375,7 +402,7 @@ bool mb4_geometry(int dtype, MbGeom& g, int Cin, int hid, int Cout, int k, int s
     g = MbGeom{};
     g.ok = true; g.kind = 7; g.S = s;
     g.JX = jx; g.NBO = nbo; g.HC = e->hc; g.nq = hid / e->hc;
-    g.NBE = (g.HC + 31) / 32; g.HALF = g.HC / 8; g.rowb = g.HC * 4 + 16;
+    g.NBE = (g.HC + 31) / 32; g.HALF = g.HC / 8; g.rowb = g.HC * 4 + 16; g.KG = e->kg;
     g.lds_bytes = (size_t)e->lds_bytes;
     g.wexp_bytes = (size_t)g.nq * g.NBE * g.JX * 64 * 16;
     g.wdw_floats = (size_t)g.nq * k * k * g.HC;
@@ -404,6 +431,7 @@ void mb4_repack(int dtype, const MbGeom& g, int hid, int Cout, int k, const floa
                     char* dst = (char*)wproj_host + ((((size_t)nbo * g.nq + q) * g.HALF + jp) * 64 + lane) * 16;
                     pack_chunk(dtype, wp + (size_t)co * hid + q * g.HC + 8 * jp + 4 * h, dst);
                 }
+    if (dtype == 2) split_pairs_inplace(wproj_host, (size_t)g.NBO * g.nq * g.KG, g.HALF / g.KG);      // the JS steps of a k-group in pairs
 }
 
 hipError_t mb4_launch(hipStream_t s, int dtype, const MbParams& p) {

@@ -20,6 +20,7 @@
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace cf {
 
@@ -59,6 +60,7 @@ void pw_pack_weights(int dtype, const float* w, int K, int N, void* out_host) {
                 const float* src = w + (size_t)ch * K + (size_t)c * P;
                 pack_chunk(dtype, src, dst);
             }
+    if (dtype == 2) split_pairs_inplace(out_host, (size_t)((NB + 7) / 8 * 8), NCh);      // per n-block: the K chain of a lane half in pairs
 }
 
 template <typename T> using Mma = CfMma<T>;      // bf16 / exact fp32 / split-bf16 MFMA over one 16-byte chunk (cf_common.h)
@@ -106,6 +108,20 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
             for (int i = 0; i < NBW; ++i)
                 wc[u][i] = ld16(wbase + ((size_t)(i < nbv ? i : 0) * NCh + j) * 1024);
         }
+        if constexpr (std::is_same<T, sp32_t>::value) {       // split mode: chunk pairs = one k = 16 step, an odd last chunk alone
+#pragma unroll
+            for (int u = 0; u < 4; u += 2) {
+                if (j0 + u + 1 < NCh) {                       // uniform
+#pragma unroll
+                    for (int i = 0; i < NBW; ++i)
+                        if (i < nbv) Mma<T>::run2(acc[i], wc[u][i], wc[u + 1][i], xc[u], xc[u + 1]);
+                } else if (j0 + u < NCh) {
+#pragma unroll
+                    for (int i = 0; i < NBW; ++i)
+                        if (i < nbv) Mma<T>::run(acc[i], wc[u][i], xc[u]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (j0 + u < NCh) {                               // uniform
@@ -113,6 +129,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
                 for (int i = 0; i < NBW; ++i)
                     if (i < nbv) Mma<T>::run(acc[i], wc[u][i], xc[u]);
             }
+        }
         }
     }
 
@@ -239,7 +256,21 @@ __global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
             if (t + NST - 1 < NT) prefetch(t + NST - 1, smem + ((u + NST - 1) % NST) * STAGE, xr[(u + NST - 1) % NST]);
             const int kt = NCh - t * KT < KT ? NCh - t * KT : KT;
             const char* st = smem + u * STAGE;
-            if (nbv == NBW) {                              // wave-uniform: all n-blocks of this workgroup exist
+            if constexpr (std::is_same<T, sp32_t>::value) {      // split mode: chunk pairs (KT is even: pairs never straddle a tile)
+#pragma unroll
+                for (int jj = 0; jj < KT; jj += 2) {
+                    if (jj + 1 < kt) {
+#pragma unroll
+                        for (int i = 0; i < NBW; ++i)
+                            if (i < nbv) Mma<T>::run2(acc[i], ld16(st + (i * KT + jj) * 1024 + lane * 16), ld16(st + (i * KT + jj + 1) * 1024 + lane * 16),
+                                                      xr[u][jj], xr[u][jj + 1]);
+                    } else if (jj < kt) {
+#pragma unroll
+                        for (int i = 0; i < NBW; ++i)
+                            if (i < nbv) Mma<T>::run(acc[i], ld16(st + (i * KT + jj) * 1024 + lane * 16), xr[u][jj]);
+                    }
+                }
+            } else if (nbv == NBW) {                              // wave-uniform: all n-blocks of this workgroup exist
 #pragma unroll
                 for (int jj = 0; jj < KT; ++jj) {
                     if (jj < kt) {

@@ -48,6 +48,7 @@ void stem_pack_weights(int dtype, const float* w, void* out_host) {
             }
             pack_chunk(dtype, vv, dst);
         }
+    if (dtype == 2) split_pairs_inplace(out_host, 1, NCH);
 }
 
 template <typename T, int FMT>
@@ -101,8 +102,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const char* wbase = (const char*)p.w + (size_t)lane * 16;
     if constexpr (F32) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) CfMma<T>::run(acc, ld16(wbase + (size_t)c * 1024), pack16<float>(&v[4 * c]));
+        mma_chain<T, 4>(acc, [&](int c) { return ld16(wbase + (size_t)c * 1024); }, [&](int c) { return pack16<float>(&v[4 * c]); });
     } else {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {

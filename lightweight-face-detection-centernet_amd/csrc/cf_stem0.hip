@@ -64,6 +64,7 @@ void stem0_pack_proj(int dtype, const float* wp, void* out_host) {
             char* dst = (char*)out_host + ((size_t)j * 64 + lane) * 16;
             pack_chunk(dtype, wp + co * 32 + (h * HALF + j) * P, dst);
         }
+    if (dtype == 2) split_pairs_inplace(out_host, 1, HALF);
 }
 
 template <typename T> using S0Mma = CfMma<T>;
@@ -164,12 +165,7 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
                 const int ky = t / 9, rr = t - 9 * ky;
                 v[s] = t < 27 ? xp[ky * S0_PROW + rr] : 0.0f;
             }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                u32x4 xc; xc.x = __float_as_uint(v[4 * c]); xc.y = __float_as_uint(v[4 * c + 1]);
-                xc.z = __float_as_uint(v[4 * c + 2]); xc.w = __float_as_uint(v[4 * c + 3]);
-                S0Mma<T>::run(a, ws[c], xc);
-            }
+            mma_chain<T, 4>(a, [&](int c) { return ws[c]; }, [&](int c) { return pack16<float>(&v[4 * c]); });
         } else {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -207,8 +203,7 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < HALF; ++j) {
+    auto dw_chunk = [&](int j) -> u32x4 {
         const int c = h * HALF + j;
         f32x2 d2[P / 2];
 #pragma unroll
@@ -229,8 +224,9 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
         float d[P];
 #pragma unroll
         for (int e = 0; e < P / 2; ++e) { const f32x2 y2 = swish2(d2[e]); d[2 * e] = y2.x; d[2 * e + 1] = y2.y; }
-        S0Mma<T>::run(acc, ld16((const char*)p.wproj + ((size_t)j * 64 + lane) * 16), pack16<T>(d));
-    }
+        return pack16<T>(d);
+    };
+    mma_chain<T, HALF>(acc, [&](int j) { return ld16((const char*)p.wproj + ((size_t)j * 64 + lane) * 16); }, dw_chunk);
     const int gy = oy0 + oy, gx = ox0 + ox;
     if (h != 0 || gy >= Ho || gx >= Wo) return;                  // channels 0..15 live in the h == 0 lanes
     T* out = (T*)p.y + (((size_t)b * Ho + gy) * Wo + gx) * 16;
