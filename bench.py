@@ -60,7 +60,7 @@ def parse(argv=None):
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--depth", type=int, default=2,
                     help="contexts per GPU used round-robin (batches in flight); 1 = a single context, every step on one stream chain")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32_split"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_with_h2d / tolerance_mode / exact_fp32_mode / parity (profiling runs)")
     ap.add_argument("--gather", default="auto", choices=["auto", "cf", "torch"],

@@ -18,8 +18,7 @@ namespace cf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
-constexpr int UH_TH = 8, UH_TW = 32, UH_IH = UH_TH + 2, UH_IW = UH_TW + 2, UH_IPX = UH_IH * UH_IW;   // 10 x 34 = 340
-constexpr int UH_NIB = (UH_IPX + 31) / 32;                                                            // 11
+constexpr int UH_TW = 32, UH_IW = UH_TW + 2;      // tile width; the tile height TH and the wave count NW are template parameters
 constexpr int UH_PIT = 48;                        // bytes per pixel: 24 bf16 channels = 3 x 16-byte chunks
 constexpr int UH_WHB = 3 * 5 * 1024;              // collapsed bf16 head fragments: 3 kernel rows x 5 k-steps
 
@@ -27,9 +26,12 @@ __device__ __forceinline__ f32x16 uh_mma(f32x16 acc, const u32x4& w, const u32x4
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w), __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
 }
 
-template <bool COALESCE>
-__global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
-    __shared__ __attribute__((aligned(16))) char Rs[COALESCE ? 4 * 2048 : 16];   // one row of 32 records per wave, staged for full-line stores
+// TH x 32 output tile (TH + 2 halo rows: 10 x 34 = 340 pixels at TH = 8, 18 x 34 = 612 at TH = 16), NW waves; NT: the head
+// records (105 MB per batch of 64, read back only at the K decoded cells) are stored non-temporally
+template <bool COALESCE, int UH_TH = 8, int NW = 4, bool NT = false>
+__global__ __launch_bounds__(NW * 64) void uphead_kernel(UpHeadParams p) {
+    constexpr int UH_IH = UH_TH + 2, UH_IPX = UH_IH * UH_IW, UH_NIB = (UH_IPX + 31) / 32;
+    __shared__ __attribute__((aligned(16))) char Rs[COALESCE ? NW * 2048 : 16];   // one row of 32 records per wave, staged for full-line stores
     __shared__ __attribute__((aligned(16))) char T3[UH_NIB * 32 * UH_PIT];      // neck tile incl. halo, bf16
     __shared__ __attribute__((aligned(16))) char Wh[UH_WHB];                   // head weight fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
     const int ox0 = tbx * UH_TW, oy0 = tby * UH_TH, b = tbz;
 
     // head weights -> LDS by DMA; lands under phase A, fenced by the barrier
-    for (int c = wave; c < UH_WHB / 1024; c += 4)
+    for (int c = wave; c < UH_WHB / 1024; c += NW)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)p.w0p + c * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void*)(Wh + c * 1024), 16, 0, 0);
 
@@ -49,12 +51,12 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
     const u32x4 wc1 = ld16((const char*)p.wcv + (size_t)(1 * 64 + lane) * 16);
     // All global loads of this wave's (up to three) halo blocks are issued before the first result is
     // consumed; padding selects are applied afterwards, on the registers.
-    constexpr int MAXB = (UH_NIB + 3) / 4;
+    constexpr int MAXB = (UH_NIB + NW - 1) / NW;
     u32x4 x0[MAXB], x1[MAXB], lw[MAXB][2];
     bool valid[MAXB]; int tapv[MAXB];
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
-        const int ib = wave + 4 * t;
+        const int ib = wave + NW * t;
         const int ip = ib * 32 + pl;
         const int ipc = ip < UH_IPX ? ip : UH_IPX - 1;
         const int ty = ipc / UH_IW, tx = ipc - ty * UH_IW;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
     }
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
-        const int ib = wave + 4 * t;
+        const int ib = wave + NW * t;
         if (ib >= UH_NIB) break;
         const int ip = ib * 32 + pl;
         f32x16 acc;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
 
     // ---- phase B: collapsed 3x3 head conv from the LDS tile (cf_head.hip: kernel row dy = 72 contiguous
     // elements = 9 chunks; lane half 0 owns chunks 0-4, half 1 chunks 5-8)
-    for (int ob = wave; ob < UH_TH * UH_TW / 32; ob += 4) {
+    for (int ob = wave; ob < UH_TH * UH_TW / 32; ob += NW) {
         const int o = ob * 32 + pl;
         const int oy = o / UH_TW, ox = o - oy * UH_TW;
         f32x16 acc;
@@ -147,7 +149,10 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
                 for (int k = 0; k < 2; ++k) {
                     const int q = lane + 64 * k;                                // 16-byte piece q of the row: record q / 4
                     const u32x4 v = ld16(rs + q * 16);
-                    if (ox0 + (q >> 2) < p.w) st16(row0 + q * 16, v);
+                    if (ox0 + (q >> 2) < p.w) {
+                        if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(row0 + q * 16));
+                        else st16(row0 + q * 16, v);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -160,17 +165,35 @@ __global__ __launch_bounds__(256) void uphead_kernel(UpHeadParams p) {
     }
 }
 
+template <bool CO, int TH, int NW, bool NT>
+static hipError_t uphead_launch_t(hipStream_t s, const UpHeadParams& q) {
+    dim3 grid((q.w + UH_TW - 1) / UH_TW, (q.h + TH - 1) / TH, q.B), blk(NW * 64);
+    set_kernel_tag("void cf::uphead_kernel<%s, %d, %d, %s>(cf::UpHeadParams)", CO ? "true" : "false", TH, NW, NT ? "true" : "false");
+    hipLaunchKernelGGL((uphead_kernel<CO, TH, NW, NT>), grid, blk, 0, s, q);
+    return hipGetLastError();
+}
+
 hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p) {
     if (p.B <= 0) return hipSuccess;
-    dim3 grid((p.w + UH_TW - 1) / UH_TW, (p.h + UH_TH - 1) / UH_TH, p.B), blk(256);
-
     static const bool xcd_on = cf_ab_int("CF_UH_XCD", 0) >= 1;      // A/B only: 0.090 -> 0.094 ms with it
     UpHeadParams q = p; q.xcd = xcd_on ? 1 : 0;
-    static const bool coalesce = cf_ab_int("CF_UH_COALESCE", 1) != 0;      // A/B
-    set_kernel_tag(coalesce ? "void cf::uphead_kernel<true>(cf::UpHeadParams)" : "void cf::uphead_kernel<false>(cf::UpHeadParams)");
-    if (coalesce) hipLaunchKernelGGL(uphead_kernel<true>, grid, blk, 0, s, q);
-    else hipLaunchKernelGGL(uphead_kernel<false>, grid, blk, 0, s, q);
-    return hipGetLastError();
+#ifdef CF_EXPERIMENTS
+    static const int var = cf_ab_int("CF_UH_VARIANT", 0);           // A/B sweep of tile height / waves / non-temporal record stores
+    if (cf_ab_int("CF_UH_COALESCE", 1) == 0) return uphead_launch_t<false, 8, 4, false>(s, q);
+    switch (var) {
+        case 1: return uphead_launch_t<true, 8, 4, true>(s, q);
+        case 2: return uphead_launch_t<true, 16, 8, false>(s, q);
+        case 3: return uphead_launch_t<true, 8, 4, false>(s, q);       // the round-3 geometry
+        case 4: return uphead_launch_t<true, 16, 4, true>(s, q);
+        case 5: return uphead_launch_t<true, 32, 8, true>(s, q);
+        case 6: return uphead_launch_t<true, 8, 8, true>(s, q);
+        default: break;
+    }
+#endif
+    // 16 x 32 tiles on eight waves, non-temporal record stores: halo rows 2 / 8 -> 2 / 16 of the skip / low fetch (B = 64, 640x640, HIP
+    // events, same box: 8x32 / 4 waves 79.0 us, + non-temporal 78.1, 16x32 / 8 waves 73.2, + non-temporal 72.3; 16x32 / 4 waves 84.9,
+    // 32x32 / 8 waves 86.4, 8x32 / 8 waves 91.4); every variant is bit-identical to the two-kernel path (test_fused_up3_heads_...)
+    return uphead_launch_t<true, 16, 8, true>(s, q);
 }
 
 }  // namespace cf
