@@ -203,8 +203,8 @@ hipError_t launch_encode_targets(hipStream_t s, const EncodeParams& p);
 
 // ------------------------------------------------------------------ IDAUp stage 3 + heads fused (bf16, collapsed heads)
 struct UpHeadParams {
-    const void* skip;     // [B][h][w][24] bf16: the IDAUp skip input (layer1 output)
-    const void* low;      // [B][h/2][w/2][24] bf16: previous IDAUp stage
+    const void* skip;     // [B][h][w][24] T: the IDAUp skip input (layer1 output)
+    const void* low;      // [B][h/2][w/2][24] T: previous IDAUp stage
     const void* wcv;      // pw_pack_weights(24 -> 24, BN folded)
     const float* bias;    // [24] BN shift of the 1x1 conv
     const float* upw;     // [4][24] deconv tap * BN scale
@@ -216,7 +216,7 @@ struct UpHeadParams {
     int B, h, w;
     int xcd;              // 1 = XCD-aware tile order (set by the launcher)
 };
-hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p);
+hipError_t launch_uphead(hipStream_t s, int dtype, const UpHeadParams& p);
 
 // conv_last + up1 + up2 as one kernel (cf_neck.hip, bf16): the 1/32 and 1/16 neck maps exist only in LDS
 struct NeckParams {

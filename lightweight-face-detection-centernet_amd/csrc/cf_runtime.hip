@@ -292,7 +292,8 @@ void build_plan(cf_ctx* c) {
     hd.macs = (c->flags & CF_FLAG_COLLAPSE_HEADS) ? (double)curH * curW * 216 * 15
                                                   : (double)curH * curW * (4 * 216 * 24 + 15 * 24);
     push(hd);
-    if (fuse && !(c->flags & CF_FLAG_NO_UPHEAD) && c->dtype == CF_BF16 && (c->flags & CF_FLAG_COLLAPSE_HEADS)) {
+    // (bf16 and the split-mode tolerance path; the exact-fp32 test mode keeps the two launches)
+    if (fuse && !(c->flags & CF_FLAG_NO_UPHEAD) && c->dtype != CF_F32 && (c->flags & CF_FLAG_COLLAPSE_HEADS)) {
         const int ih = (int)c->ops.size() - 1, iu = ih - 1;               // heads, up3
         c->ops[iu].fused_away = true;
         c->ops[ih].partner = iu;
@@ -725,7 +726,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
         const Op& u = c->ops[op.partner];
         UpHeadParams p{}; p.skip = bp(u.in); p.low = bp(u.low); p.wcv = u.wp; p.bias = u.bias; p.upw = u.upw; p.upb = u.upb;
         p.w0p = op.wp; p.b0 = op.bias; p.heads = (float*)bp(op.out); p.hm_plane = c->hm_plane; p.B = B; p.h = op.Hout; p.w = op.Wout;
-        return launch_uphead(c->stream, p);
+        return launch_uphead(c->stream, c->dtype, p);
     }
     if (op.neck_cl >= 0) {
         const Op& cl = c->ops[op.neck_cl]; const Op& u1 = c->ops[op.neck_u1];

@@ -19,21 +19,31 @@ namespace cf {
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
 constexpr int UH_TW = 32, UH_IW = UH_TW + 2;      // tile width; the tile height TH and the wave count NW are template parameters
-constexpr int UH_PIT = 48;                        // bytes per pixel: 24 bf16 channels = 3 x 16-byte chunks
-constexpr int UH_WHB = 3 * 5 * 1024;              // collapsed bf16 head fragments: 3 kernel rows x 5 k-steps
 
-__device__ __forceinline__ f32x16 uh_mma(f32x16 acc, const u32x4& w, const u32x4& x) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w), __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
-}
-
+// T = bf16_t (benchmarked mode), sp32_t (tolerance mode: fp32 tile, split-bf16 products) or float (exact fp32 MFMA).
 // TH x 32 output tile (TH + 2 halo rows: 10 x 34 = 340 pixels at TH = 8, 18 x 34 = 612 at TH = 16), NW waves; NT: the head
-// records (105 MB per batch of 64, read back only at the K decoded cells) are stored non-temporally
-template <bool COALESCE, int UH_TH = 8, int NW = 4, bool NT = false>
+// records (105 MB per batch of 64, read back only at the K decoded cells) are stored non-temporally.
+template <typename T, int UH_TH, int NW>
+struct Uh {
+    static constexpr int P = Elem<T>::PER16;
+    static constexpr int PIT = 24 * (int)sizeof(T);                 // bytes per tile pixel: 24 channels
+    static constexpr int NC = PIT / 16, NCH = (NC + 1) / 2;        // 1x1 conv: chunks per pixel row / per lane half (k-steps)
+    static constexpr int CPD = 3 * NC, SPD = (CPD + 1) / 2;        // head conv: chunks per kernel row (3 pixels) / steps per lane half
+    static constexpr int G = 16 / P;                                // channel groups of P per lane (16 output channels)
+    static constexpr int IH = UH_TH + 2, IPX = IH * UH_IW, NIB = (IPX + 31) / 32, MAXB = (NIB + NW - 1) / NW;
+    static constexpr int T3B = NIB * 32 * PIT, WHB = 3 * SPD * 1024, RSB = NW * 2048;
+    static constexpr int LDS = T3B + WHB + RSB;
+};
+
+template <typename T, bool COALESCE, int UH_TH = 8, int NW = 4, bool NT = false>
 __global__ __launch_bounds__(NW * 64) void uphead_kernel(UpHeadParams p) {
-    constexpr int UH_IH = UH_TH + 2, UH_IPX = UH_IH * UH_IW, UH_NIB = (UH_IPX + 31) / 32;
-    __shared__ __attribute__((aligned(16))) char Rs[COALESCE ? NW * 2048 : 16];   // one row of 32 records per wave, staged for full-line stores
-    __shared__ __attribute__((aligned(16))) char T3[UH_NIB * 32 * UH_PIT];      // neck tile incl. halo, bf16
-    __shared__ __attribute__((aligned(16))) char Wh[UH_WHB];                   // head weight fragments
+    typedef Uh<T, UH_TH, NW> U;
+    constexpr int P = U::P, PIT = U::PIT, NC = U::NC, NCH = U::NCH, CPD = U::CPD, SPD = U::SPD, G = U::G;
+    constexpr int UH_IPX = U::IPX, UH_NIB = U::NIB, MAXB = U::MAXB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* T3 = smem;                       // neck tile incl. halo, storage type T
+    char* Wh = smem + U::T3B;              // head weight fragments
+    char* Rs = Wh + U::WHB;                // one row of 32 records per wave, staged for full-line stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
     unsigned tbx = blockIdx.x, tby = blockIdx.y, tbz = blockIdx.z;
@@ -41,18 +51,18 @@ __global__ __launch_bounds__(NW * 64) void uphead_kernel(UpHeadParams p) {
     const int ox0 = tbx * UH_TW, oy0 = tby * UH_TH, b = tbz;
 
     // head weights -> LDS by DMA; lands under phase A, fenced by the barrier
-    for (int c = wave; c < UH_WHB / 1024; c += NW)
+    for (int c = wave; c < U::WHB / 1024; c += NW)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)p.w0p + c * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void*)(Wh + c * 1024), 16, 0, 0);
 
-    // ---- phase A: up3 on the halo tile.  1x1 conv 24 -> 24 as in cf_pw.hip (K = 3 chunks: lane half 0 owns
-    // chunks 0,1, half 1 chunk 2), epilogue bias + ReLU, + ReLU(low * tap weight + shift), bf16 -> LDS
-    const u32x4 wc0 = ld16((const char*)p.wcv + (size_t)(0 * 64 + lane) * 16);
-    const u32x4 wc1 = ld16((const char*)p.wcv + (size_t)(1 * 64 + lane) * 16);
-    // All global loads of this wave's (up to three) halo blocks are issued before the first result is
-    // consumed; padding selects are applied afterwards, on the registers.
-    constexpr int MAXB = (UH_NIB + NW - 1) / NW;
-    u32x4 x0[MAXB], x1[MAXB], lw[MAXB][2];
+    // ---- phase A: up3 on the halo tile.  1x1 conv 24 -> 24 as in cf_pw.hip (lane half h owns chunks h NCH .. of the pixel row; a
+    // chunk past the row meets a zeroed operand), epilogue bias + ReLU, + ReLU(low * tap weight + shift), storage type -> LDS
+    u32x4 wc[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) wc[j] = ld16((const char*)p.wcv + (size_t)(j * 64 + lane) * 16);
+    // All global loads of this wave's halo blocks are issued before the first result is consumed; padding selects are applied
+    // afterwards, on the registers.
+    u32x4 xs[MAXB][NCH], lw[MAXB][G];
     bool valid[MAXB]; int tapv[MAXB];
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
@@ -63,13 +73,13 @@ __global__ __launch_bounds__(NW * 64) void uphead_kernel(UpHeadParams p) {
         const int gy = oy0 - 1 + ty, gx = ox0 - 1 + tx;
         valid[t] = ib < UH_NIB && ip < UH_IPX && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
         const int cy = min(max(gy, 0), p.h - 1), cx = min(max(gx, 0), p.w - 1);
-        const char* xrow = (const char*)p.skip + (((size_t)b * p.h + cy) * p.w + cx) * UH_PIT + h * 32;
-        x0[t] = ld16(xrow);
-        x1[t] = ld16(xrow + (h == 0 ? 16 : 0));                    // half 1 has no second chunk (zeroed below)
+        const char* xrow = (const char*)p.skip + (((size_t)b * p.h + cy) * p.w + cx) * PIT;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) xs[t][j] = ld16(xrow + min(h * NCH + j, NC - 1) * 16);      // a chunk past the row: zeroed below
         const size_t low_row = ((size_t)b * (p.h >> 1) + (cy >> 1)) * (p.w >> 1) + (cx >> 1);
         tapv[t] = ((cy & 1) << 1) | (cx & 1);
-        lw[t][0] = ld16((const char*)p.low + (low_row * 24 + h * 16) * 2);
-        lw[t][1] = ld16((const char*)p.low + (low_row * 24 + (h == 0 ? 8 : 16)) * 2);   // half 1 owns channels 16..23 only
+#pragma unroll
+        for (int g = 0; g < G; ++g) lw[t][g] = ld16((const char*)p.low + (low_row * 24 + min(h * 16 + g * P, 24 - P)) * sizeof(T));
     }
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
@@ -79,28 +89,27 @@ __global__ __launch_bounds__(NW * 64) void uphead_kernel(UpHeadParams p) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        acc = uh_mma(acc, wc0, x0[t]);
-        acc = uh_mma(acc, wc1, h == 0 ? x1[t] : zero16());
+        mma_chain<T, NCH>(acc, [&](int j) { return wc[j]; }, [&](int j) { return (h * NCH + j) < NC ? xs[t][j] : zero16(); });
         const int tap = tapv[t];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int ch = h * 16 + g * 8;
+        for (int g = 0; g < G; ++g) {
+            const int ch = h * 16 + g * P;
             if (ch >= 24) break;
-            float v[8], r[8];
+            float v[P], r[P];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = relu_f(acc[g * 8 + e] + p.bias[ch + e]);
-            unpack16<bf16_t>(lw[t][g], r);
+            for (int e = 0; e < P; ++e) v[e] = relu_f(acc[g * P + e] + p.bias[ch + e]);
+            unpack16<T>(lw[t][g], r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += relu_f(r[e] * p.upw[tap * 24 + ch + e] + p.upb[ch + e]);
-            u32x4 o = pack16<bf16_t>(v);
+            for (int e = 0; e < P; ++e) v[e] += relu_f(r[e] * p.upw[tap * 24 + ch + e] + p.upb[ch + e]);
+            u32x4 o = pack16<T>(v);
             if (!valid[t]) o = zero16();
-            st16(T3 + ip * UH_PIT + ch * 2, o);
+            st16(T3 + ip * PIT + ch * (int)sizeof(T), o);
         }
     }
     cf_sync_lds_dma();            // the tile is complete and the head weights (LDS-DMA) have landed for every wave
 
-    // ---- phase B: collapsed 3x3 head conv from the LDS tile (cf_head.hip: kernel row dy = 72 contiguous
-    // elements = 9 chunks; lane half 0 owns chunks 0-4, half 1 chunks 5-8)
+    // ---- phase B: collapsed 3x3 head conv from the LDS tile (cf_head.hip: kernel row dy = 72 contiguous elements = CPD chunks;
+    // lane half h owns chunks h SPD ..)
     for (int ob = wave; ob < UH_TH * UH_TW / 32; ob += NW) {
         const int o = ob * 32 + pl;
         const int oy = o / UH_TW, ox = o - oy * UH_TW;
@@ -109,14 +118,10 @@ __global__ __launch_bounds__(NW * 64) void uphead_kernel(UpHeadParams p) {
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const char* row = T3 + ((oy + dy) * UH_IW + ox) * UH_PIT;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int c = h * 5 + j;
-                u32x4 xc = ld16(row + (c < 9 ? c : 8) * 16);
-                if (c >= 9) xc = zero16();
-                acc = uh_mma(acc, ld16(Wh + ((dy * 5 + j) * 64 + lane) * 16), xc);
-            }
+            const char* row = T3 + ((oy + dy) * UH_IW + ox) * PIT;
+            mma_chain<T, SPD>(acc, [&](int j) { return ld16(Wh + ((dy * SPD + j) * 64 + lane) * 16); },
+                              [&](int j) { const int c = h * SPD + j; u32x4 xc = ld16(row + (c < CPD ? c : CPD - 1) * 16);
+                                           if (c >= CPD) xc = zero16(); return xc; });
         }
         const int gy = oy0 + oy, gx = ox0 + ox;
         if constexpr (!COALESCE) { if (gy >= p.h || gx >= p.w) continue; }
@@ -165,35 +170,59 @@ __global__ __launch_bounds__(NW * 64) void uphead_kernel(UpHeadParams p) {
     }
 }
 
-template <bool CO, int TH, int NW, bool NT>
+template <typename T, bool CO, int TH, int NW, bool NT>
 static hipError_t uphead_launch_t(hipStream_t s, const UpHeadParams& q) {
+    typedef Uh<T, TH, NW> U;
+    auto kfn = uphead_kernel<T, CO, TH, NW, NT>;
+    static thread_local bool configured_dev[32] = {};               // function attributes are per device
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool& configured = configured_dev[dev & 31];
+    if (U::LDS > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, U::LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
     dim3 grid((q.w + UH_TW - 1) / UH_TW, (q.h + TH - 1) / TH, q.B), blk(NW * 64);
-    set_kernel_tag("void cf::uphead_kernel<%s, %d, %d, %s>(cf::UpHeadParams)", CO ? "true" : "false", TH, NW, NT ? "true" : "false");
-    hipLaunchKernelGGL((uphead_kernel<CO, TH, NW, NT>), grid, blk, 0, s, q);
+    set_kernel_tag("void cf::uphead_kernel<%s, %s, %d, %d, %s>(cf::UpHeadParams)", type_tag<T>(), CO ? "true" : "false", TH, NW, NT ? "true" : "false");
+    hipLaunchKernelGGL(kfn, grid, blk, U::LDS, s, q);
     return hipGetLastError();
 }
 
-hipError_t launch_uphead(hipStream_t s, const UpHeadParams& p) {
+hipError_t launch_uphead(hipStream_t s, int dtype, const UpHeadParams& p) {
     if (p.B <= 0) return hipSuccess;
     static const bool xcd_on = cf_ab_int("CF_UH_XCD", 0) >= 1;      // A/B only: 0.090 -> 0.094 ms with it
     UpHeadParams q = p; q.xcd = xcd_on ? 1 : 0;
 #ifdef CF_EXPERIMENTS
     static const int var = cf_ab_int("CF_UH_VARIANT", 0);           // A/B sweep of tile height / waves / non-temporal record stores
-    if (cf_ab_int("CF_UH_COALESCE", 1) == 0) return uphead_launch_t<false, 8, 4, false>(s, q);
-    switch (var) {
-        case 1: return uphead_launch_t<true, 8, 4, true>(s, q);
-        case 2: return uphead_launch_t<true, 16, 8, false>(s, q);
-        case 3: return uphead_launch_t<true, 8, 4, false>(s, q);       // the round-3 geometry
-        case 4: return uphead_launch_t<true, 16, 4, true>(s, q);
-        case 5: return uphead_launch_t<true, 32, 8, true>(s, q);
-        case 6: return uphead_launch_t<true, 8, 8, true>(s, q);
-        default: break;
+    if (dtype == 1) {
+        if (cf_ab_int("CF_UH_COALESCE", 1) == 0) return uphead_launch_t<bf16_t, false, 8, 4, false>(s, q);
+        switch (var) {
+            case 1: return uphead_launch_t<bf16_t, true, 8, 4, true>(s, q);
+            case 2: return uphead_launch_t<bf16_t, true, 16, 8, false>(s, q);
+            case 3: return uphead_launch_t<bf16_t, true, 8, 4, false>(s, q);       // the round-3 geometry
+            case 4: return uphead_launch_t<bf16_t, true, 16, 4, true>(s, q);
+            case 5: return uphead_launch_t<bf16_t, true, 32, 8, true>(s, q);
+            case 6: return uphead_launch_t<bf16_t, true, 8, 8, true>(s, q);
+            default: break;
+        }
+    } else if (dtype == 2) {
+        switch (var) {
+            case 1: return uphead_launch_t<sp32_t, true, 8, 4, true>(s, q);
+            case 2: return uphead_launch_t<sp32_t, true, 16, 8, true>(s, q);
+            case 3: return uphead_launch_t<sp32_t, true, 4, 4, true>(s, q);
+            case 4: return uphead_launch_t<sp32_t, true, 16, 16, true>(s, q);
+            default: break;
+        }
     }
 #endif
-    // 16 x 32 tiles on eight waves, non-temporal record stores: halo rows 2 / 8 -> 2 / 16 of the skip / low fetch (B = 64, 640x640, HIP
-    // events, same box: 8x32 / 4 waves 79.0 us, + non-temporal 78.1, 16x32 / 8 waves 73.2, + non-temporal 72.3; 16x32 / 4 waves 84.9,
+    // bf16: 16 x 32 tiles on eight waves, non-temporal record stores: halo rows 2 / 8 -> 2 / 16 of the skip / low fetch (B = 64, 640x640,
+    // HIP events, same box: 8x32 / 4 waves 79.0 us, + non-temporal 78.1, 16x32 / 8 waves 73.2, + non-temporal 72.3; 16x32 / 4 waves 84.9,
     // 32x32 / 8 waves 86.4, 8x32 / 8 waves 91.4); every variant is bit-identical to the two-kernel path (test_fused_up3_heads_...)
-    return uphead_launch_t<true, 16, 8, true>(s, q);
+    if (dtype == 1) return uphead_launch_t<bf16_t, true, 16, 8, true>(s, q);
+    // fp32 tile (twice the LDS per pixel): 8 x 32 tiles on eight waves, 77.8 KB = two workgroups per CU.  B = 64, 640x640: 0.132 ms
+    // (four waves 0.154, 16x32 / 8 waves 0.159, 4x32 / 4 waves 0.187) against 0.103 + 0.149 for the two launches
+    if (dtype == 2) return uphead_launch_t<sp32_t, true, 8, 8, true>(s, q);
+    return uphead_launch_t<float, true, 8, 4, true>(s, q);
 }
 
 }  // namespace cf

@@ -893,16 +893,18 @@ def test_fused_neck_bit_equal_to_three_kernels(size, B):
     ef.close(); e3.close()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32_split"])
 @pytest.mark.parametrize("size", [(96, 128), (160, 224), (352, 640)])
-def test_fused_up3_heads_bit_equal_to_two_kernels(size):
+def test_fused_up3_heads_bit_equal_to_two_kernels(size, dtype):
     """cf_uphead.hip (last IDAUp stage + collapsed heads, neck output only in LDS) performs the same arithmetic
     in the same order as cf_pw.hip's IDAUp epilogue followed by cf_head.hip: bit-identical head maps, on map
     sizes with partial tiles in both directions."""
     H, W = size
     rng = np.random.default_rng(H + W)
     x = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
-    ef = cfa.Engine(H, W, max_batch=3, dtype="bf16", uphead=True)
-    e2 = cfa.Engine(H, W, max_batch=3, dtype="bf16", uphead=False)
+    ef = cfa.Engine(H, W, max_batch=3, dtype=dtype, uphead=True)
+    e2 = cfa.Engine(H, W, max_batch=3, dtype=dtype, uphead=False)
+    assert any(op["name"] == "up3+heads" for op in ef.plan()) and not any(op["name"] == "up3+heads" for op in e2.plan())
     ef.forward_enqueue(x); e2.forward_enqueue(x)
     hf, h2 = ef.heads(sigmoid_hm=True), e2.heads(sigmoid_hm=True)
     for k in ("hm", "wh", "lm", "reg", "hm_sigmoid"):
