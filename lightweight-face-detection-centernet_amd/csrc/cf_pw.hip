@@ -475,7 +475,7 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
             // 6.0 project, K = 960); slower than pw_wlds_kernel at B = 64, 640x640 (20x20 maps: 23 -> 29, 30 -> 49 us; layer4.1's K = 576
             // on its 40x40 map: 32 -> 35 us, N = 96), hence K >= 512 AND N >= 128: layer5.0 / 5.1 / 6.0 of 1280-class inputs (13.7 -> 8.8 us for 5.0)
             static const int ks_env = cf_ab_int("CF_PW_KSPLIT", -1);   // A/B: 0 off, 1 force
-            if (ks_env != 0 && p.K >= 256 && (ks_env > 0 || (p.K >= 512 && p.N >= 128 && (long long)p.Ho * p.Wo >= 1024 && (long long)p.Ho * p.Wo < 4096)))
+            if (ks_env != 0 && p.K >= 256 && (p.act == 0 || !p.res) /* the k-split epilogues: Swish, none, none + residual */ && (ks_env > 0 || (p.K >= 512 && p.N >= 128 && (long long)p.Ho * p.Wo >= 1024 && (long long)p.Ho * p.Wo < 4096)))
                 return (NB % 3 == 0 || NB == 5) ? dispatch_ksplit<3>(s, p) : dispatch_ksplit<2>(s, p);
         }
         static const int nst_env = cf_ab_int("CF_PW_NST", 0);       // A/B: ring depth 2..4

@@ -16,6 +16,7 @@ fi
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 600 "$OUT/bench.json"
 timeout 300 python tools/profile_ops.py --json "$OUT/ops.json" > "$OUT/ops.txt" 2>&1
 timeout 300 python tools/profile_ops.py --dtype fp32 --batch 64 > "$OUT/ops_fp32_b64.txt" 2>&1
+timeout 300 python tools/profile_ops.py --dtype fp32_split --batch 64 --json "$OUT/ops_split.json" > "$OUT/ops_split_b64.txt" 2>&1
 # BASELINE configs[4] per-GPU shards (1280x1280, top-1000) and the configs[3] VGA bucket mix
 timeout 300 python tools/profile_ops.py --size 1280 --topk 1000 --batch 4 --json "$OUT/ops_1280_b4.json" > "$OUT/ops_1280_b4.txt" 2>&1
 timeout 300 python tools/profile_ops.py --size 1280 --topk 1000 --batch 32 --json "$OUT/ops_1280_b32.json" > "$OUT/ops_1280_b32.txt" 2>&1
@@ -43,6 +44,19 @@ timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_IN
 timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS \
     --kernel-trace --output-format csv -d "$OUT/prof_lds" -o l -- \
     python "$ROOT/tools/profile_ops.py" --reps 3 > "$OUT/prof_lds.log" 2>&1
+# tolerance mode (fp32_split): kernel durations, HBM traffic and the SQ view that shows what binds its kernels (LDS vs VALU vs MFMA)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_ksplit" -o k -- \
+    python "$ROOT/bench.py" --dtype fp32_split --depth 1 --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-extras > "$OUT/prof_ksplit.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM \
+    --kernel-trace --output-format csv -d "$OUT/prof_sq_split" -o s -- \
+    python "$ROOT/tools/profile_ops.py" --dtype fp32_split --reps 3 > "$OUT/prof_sq_split.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA \
+    --kernel-trace --output-format csv -d "$OUT/prof_lds_split" -o l -- \
+    python "$ROOT/tools/profile_ops.py" --dtype fp32_split --reps 3 > "$OUT/prof_lds_split.log" 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/prof_fetch_split" -o f -- \
+    python "$ROOT/tools/profile_ops.py" --dtype fp32_split --reps 3 > "$OUT/prof_fetch_split.log" 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/prof_write_split" -o w -- \
+    python "$ROOT/tools/profile_ops.py" --dtype fp32_split --reps 3 > "$OUT/prof_write_split.log" 2>&1
 find "$OUT" -name '*.csv' | head -20
 # keep the merge-back under 64 MiB: drop per-dispatch traces, keep stats + counters
 find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
