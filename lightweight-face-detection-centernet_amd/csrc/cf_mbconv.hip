@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
 
     // this lane's output pixel (phase 2/3 and epilogue) and its share of the k-steps
     const int pbk = wave % NPB, jg = wave / NPB;
-    const int o = pbk * 32 + pl;
+    const int o = pbk * 32 + (sizeof(T) == 4 ? lds_group_pixel(pl) : pl);       // fp32 tile: conflict-free ds_read_b128 groups (cf_common.h)
     const int oy = o / TOW, ox = o % TOW;
     const unsigned e_pix = (unsigned)((oy * S) * IW + ox * S) * (unsigned)ROWB;
     constexpr int JSPLIT = KG == 2 ? (HALF + 1) / 2 : HALF;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
 
     // phase 2: this wave's 64 output pixels and its share of the chunk's channel pairs
     const int pw = wave % NPW, kg = wave / NPW;
-    const int o = pw * 64 + lane, oy = o / TOW, ox = o % TOW;
+    const int o = pw * 64 + (lane & 32) + lds_group_pixel(lane & 31), oy = o / TOW, ox = o % TOW;      // conflict-free ds_read_b128 groups (cf_common.h)
     const unsigned e_pix = (unsigned)((oy * S) * IW + ox) * (unsigned)ROWB;       // stride 2: column 2 ox = position ox of the even half
 
     f32x16 acc[2][NBO];
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
     // ---- epilogue: lane (pl, h) holds 16 contiguous output channels of pixel pl of each of the wave's two pixel blocks
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-        const int o2 = pw * 64 + blk * 32 + pl, oy2 = o2 / TOW, ox2 = o2 % TOW;
+        const int o2 = pw * 64 + blk * 32 + lds_group_pixel(pl), oy2 = o2 / TOW, ox2 = o2 % TOW;       // the pixel lane pl of block blk computed
         const int gy = oy0 + oy2, gx = ox0 + ox2;
         if (gy >= p.Hout || gx >= p.Wout) continue;
         const size_t opix = ((size_t)b * p.Hout + gy) * p.Wout + gx;

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
     __syncthreads();
 
     // ---- phase 2 + 3: depthwise 3x3 + Swish -> project 32->16
-    const int o = wave * 32 + pl;
+    const int o = wave * 32 + (F32 ? lds_group_pixel(pl) : pl);                 // fp32 tile: conflict-free ds_read_b128 groups (cf_common.h)
     const int oy = o / S0_TOW, ox = o % S0_TOW;
     const char* eb0 = E + (oy * S0_IW + ox) * ROWB;
     f32x16 acc;
