@@ -333,7 +333,10 @@ static const F4Entry kF4Table[] = {
     // split-mode sweep (tools/split_sweep.sh, profiles/r04_split_sweep.txt): 4x16 stride-2 tiles with four k-groups for 1.0
     // (0.438 on cf_mbconv.hip -> 0.414), eight waves / HC 64 for 2.1 (0.2175 -> 0.2056)
     F4X(2, 3, 2, 2, 32, 1, 0, 4, 16, 4, 0),  // 1.0  16 ->  96 -> 24
-    F4X(2, 5, 1, 4, 64, 1, 1, 8, 16, 8, 0),  // 2.1  32 -> 192 -> 32
+    // second sweep, after the conflict-free lane map (profiles/r04_split_sweep2.txt): 2.0 here on an 8x16 tile with HC 16 (the [even |
+    // odd] column layout has no stride-2 bank conflicts: 0.297 on cf_mbconv.hip -> 0.261), 2.1 with HC 32 on eight waves (0.191 -> 0.179)
+    F4X(2, 5, 2, 3, 16, 1, 0, 8, 16, 4, 0),  // 2.0  24 -> 144 -> 32
+    F4X(2, 5, 1, 4, 32, 1, 1, 8, 16, 8, 0),  // 2.1  32 -> 192 -> 32
     // CF_F4_VARIANT=1: every block shape on this kernel (A/B runs, parity tests)
     F4E(1, 3, 2, 2, 32, 1, 0, 8, 16, 4),     // 1.0  16 ->  96 -> 24
     F4E(1, 3, 1, 3, 48, 1, 1, 8, 16, 4),     // 1.1  24 -> 144 -> 24
