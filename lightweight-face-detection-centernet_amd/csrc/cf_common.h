@@ -45,6 +45,21 @@ __device__ __forceinline__ f32x2 swish2(f32x2 x) {
     f32x2 r; r.x = __builtin_amdgcn_rcpf(den.x); r.y = __builtin_amdgcn_rcpf(den.y);
     return x * r;                                                 // v_pk_mul_f32
 }
+// Swish with the -log2(e) factor already in the operand (folded into the producing conv's weights): u = -log2(e) x ->
+// u / (1 + 2^u) = -log2(e) swish(x): one packed multiply fewer per pair; the consumer's weights carry the leftover -ln 2.
+// The bf16 kernels have always done this (cf_mx.h: swish2_pre); the split-mode fp32-tile kernels do since round 4 (PRE = true),
+// the exact-fp32 mode keeps swish2 (its arithmetic is what the goldens pin to the last bit).
+static constexpr float kCfNegLog2e = -1.44269504088896341f, kCfNegLn2 = -0.69314718055994531f;
+template <bool PRE> __device__ __forceinline__ f32x2 swish2_sel(f32x2 x) {
+    if constexpr (PRE) {
+        f32x2 e; e.x = __builtin_amdgcn_exp2f(x.x); e.y = __builtin_amdgcn_exp2f(x.y);
+        const f32x2 den = e + 1.0f;
+        f32x2 r; r.x = __builtin_amdgcn_rcpf(den.x); r.y = __builtin_amdgcn_rcpf(den.y);
+        return x * r;
+    } else {
+        return swish2(x);
+    }
+}
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // activation over a small register array, two lanes' worth per packed instruction (N even)
 template <int ACT, int N> __device__ __forceinline__ void act_arr(float* v) {

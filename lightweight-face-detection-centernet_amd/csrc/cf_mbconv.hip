@@ -24,6 +24,7 @@
 #include "cf_kernels.h"
 #include <type_traits>
 #include <cstdlib>
+#include <vector>
 
 namespace cf {
 
@@ -50,8 +51,19 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
     if (g.kind == 7) {                       // cf_mbconv4.hip: this file's expand fragments, its own tap table and project fragments
         MbGeom g0 = g; g0.kind = 0;
         mb_pack_weights(dtype, g0, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host);      // (its project fragments are overwritten)
+        std::vector<float> wp7;
+        if (dtype == 2) { wp7.assign(wp, wp + (size_t)Cout * hid); for (float& v : wp7) v *= kCfNegLn2; wp = wp7.data(); }   // as the recursive call did for its own copy
         mb4_repack(dtype, g, hid, Cout, k, wd, wp, wdw_host, wproj_host);
         return;
+    }
+    // split mode: -log2(e) folded into the expand weights, the leftover -ln 2 into the project weights (swish2_sel<true>, cf_common.h);
+    // the depthwise taps stay as they are (their input and their output both carry the -log2(e) factor)
+    std::vector<float> we_s, wp_s;
+    if (dtype == 2) {
+        we_s.assign(we, we + (size_t)hid * Cin);
+        for (float& v : we_s) v *= kCfNegLog2e;
+        we = we_s.data();
+        if (wp) { wp_s.assign(wp, wp + (size_t)Cout * hid); for (float& v : wp_s) v *= kCfNegLn2; wp = wp_s.data(); }
     }
     const int P = per16(dtype);
     const int NCx = Cin * (int)elem_size(dtype) / 16;
@@ -110,6 +122,7 @@ template <typename T, int KS, int S, int NBO, bool RESID, int NW, int JX, int HC
 __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
     typedef typename std::conditional<EF, float, T>::type ET;     // element type of E in LDS
     constexpr int P = Elem<T>::PER16;                             // channels per project k-chunk
+    constexpr bool PRE = std::is_same<T, sp32_t>::value;          // split mode: Swish factors folded into the expand / project weights (mb_pack_weights)
     constexpr int EP = 16 / (int)sizeof(ET);                      // E elements per 16 bytes
     constexpr int IH = (TOH - 1) * S + KS, IW = (TOW - 1) * S + KS, IPX = IH * IW;
     constexpr int NIB = (IPX + 31) / 32;
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
 #pragma unroll
                     for (int e = 0; e < EP; e += 2) {
                         f32x2 x2; x2.x = a[g * EP + e]; x2.y = a[g * EP + e + 1];
-                        const f32x2 y2 = swish2(x2);
+                        const f32x2 y2 = swish2_sel<PRE>(x2);
                         v[e] = y2.x; v[e + 1] = y2.y;
                     }
                     if (ipok) st16(erow + (ch0 + g * EP) * (int)sizeof(ET), pack16<ET>(v));
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
 #pragma unroll
                     for (int e = 0; e < EP; e += 2) {
                         f32x2 x2; x2.x = a[g * EP + e]; x2.y = a[g * EP + e + 1];
-                        const f32x2 y2 = swish2(x2);
+                        const f32x2 y2 = swish2_sel<PRE>(x2);
                         v[e] = y2.x; v[e + 1] = y2.y;
                     }
                     if (ipok) st16(erow + (ch0 + g * EP) * (int)sizeof(ET), pack16<ET>(v));
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
                 }
             float d[P];
 #pragma unroll
-            for (int e = 0; e < P / 2; ++e) { const f32x2 y2 = swish2(d2[e]); d[2 * e] = y2.x; d[2 * e + 1] = y2.y; }
+            for (int e = 0; e < P / 2; ++e) { const f32x2 y2 = swish2_sel<PRE>(d2[e]); d[2 * e] = y2.x; d[2 * e + 1] = y2.y; }
             const u32x4 xc = pack16<T>(d);
 #pragma unroll
             for (int i = 0; i < NBO; ++i) MbMma<T>::run(acc[i], wpc[i], xc);

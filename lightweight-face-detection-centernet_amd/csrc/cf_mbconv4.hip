@@ -13,7 +13,8 @@
 //     B) for pixel block 0 and pixel block 1 of the wave;
 //   * stride 2: a tile row keeps its even input columns first, then the odd ones, so the 16 lanes of a ds_read_b128 group walk
 //     consecutive rows of the tile (one 16-byte bank slot apart) instead of every second one (two-way conflict).
-// No weight folding and the same swish2() as the other fp32 kernels: the parity mode's arithmetic stays what the goldens pin.
+// Exact mode: no weight folding and the same swish2() as the other fp32 kernels (its arithmetic is what the goldens pin);
+// split mode (SP): Swish factors folded into the expand / project weights like cf_mbconv.hip (swish2_sel<true>).
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <cstdlib>
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
                     f32x2 x2; x2.x = a[g * 4 + e]; x2.y = a[g * 4 + e + 1];
-                    const f32x2 y2 = swish2(x2);
+                    const f32x2 y2 = swish2_sel<SP>(x2);
                     v[e] = y2.x; v[e + 1] = y2.y;
                 }
                 if (ipok) st16(erow + (ch0 + g * 4) * 4, pack16<float>(v));
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
 #pragma unroll
                 for (int c = 0; c < 4; c += 2) {
                     f32x2 x2; x2.x = a4[c]; x2.y = a4[c + 1];
-                    const f32x2 y2 = swish2(x2);
+                    const f32x2 y2 = swish2_sel<SP>(x2);
                     d[ab][c] = y2.x; d[ab][c + 1] = y2.y;
                 }
             }

@@ -633,6 +633,14 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
                 stem0mx_pack(ws.f(op.wkey), ws.f(op.wkey_dw), ws.f(op.wkey_proj), w.data(), reinterpret_cast<uint32_t*>(wd.data()), wp.data());
             } else if (px) {
                 stem0px_pack(ws.f(op.wkey), ws.f(op.wkey_dw), ws.f(op.wkey_proj), w.data(), reinterpret_cast<uint32_t*>(wd.data()), wp.data());
+            } else if (dt == CF_F32_SPLIT) {
+                // Swish factors folded into the weights (stem0_kernel<sp32_t>: swish2_sel<true>): -log2(e) into the stem conv, -ln 2 into the project conv
+                std::vector<float> w_s(ws.f(op.wkey), ws.f(op.wkey) + 32 * 27), p_s(ws.f(op.wkey_proj), ws.f(op.wkey_proj) + 16 * 32);
+                for (float& v : w_s) v *= kCfNegLog2e;
+                for (float& v : p_s) v *= kCfNegLn2;
+                stem_pack_weights(dt, w_s.data(), w.data());
+                dw_pack_weights(ws.f(op.wkey_dw), 32, 3, wd.data());
+                stem0_pack_proj(dt, p_s.data(), wp.data());
             } else {
                 stem_pack_weights(dt, ws.f(op.wkey), w.data());
                 dw_pack_weights(ws.f(op.wkey_dw), 32, 3, wd.data());

@@ -73,6 +73,7 @@ template <typename T, int FMT>
 __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
     constexpr int P = Elem<T>::PER16;
     constexpr bool F32 = sizeof(T) == 4;
+    constexpr bool PRE = std::is_same<T, sp32_t>::value;          // split mode: -log2(e) in the stem weights, -ln 2 in the project weights (cf_runtime.hip)
     constexpr int ROWB = 32 * sizeof(T) + 16;
     constexpr int HALF = 32 * sizeof(T) / 16 / 2;                 // k-steps of the project GEMM per lane half
     constexpr int NIB = (S0_IPX + 31) / 32;                       // 11
@@ -189,7 +190,10 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
                 float v[P];
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = inmap ? a[g * P + e] : 0.0f;     // swish(0) = 0
-                act_arr<1, P>(v);
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int e = 0; e < P; e += 2) { f32x2 x2; x2.x = v[e]; x2.y = v[e + 1]; const f32x2 y2 = swish2_sel<true>(x2); v[e] = y2.x; v[e + 1] = y2.y; }
+                } else act_arr<1, P>(v);
                 st16(erow + g * 16, pack16<T>(v));
             }
         }
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
             }
         float d[P];
 #pragma unroll
-        for (int e = 0; e < P / 2; ++e) { const f32x2 y2 = swish2(d2[e]); d[2 * e] = y2.x; d[2 * e + 1] = y2.y; }
+        for (int e = 0; e < P / 2; ++e) { const f32x2 y2 = swish2_sel<PRE>(d2[e]); d[2 * e] = y2.x; d[2 * e + 1] = y2.y; }
         return pack16<T>(d);
     };
     mma_chain<T, HALF>(acc, [&](int j) { return ld16((const char*)p.wproj + ((size_t)j * 64 + lane) * 16); }, dw_chunk);
