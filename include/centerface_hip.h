@@ -158,6 +158,11 @@ int cf_decode_threshold_ex(cf_ctx* ctx, int mode, float score_thresh, float nms_
  * whatever the input size (eval_widerface.py:88); cf_decode_threshold[_ex] clamp to the context's (H, W). */
 int cf_decode_threshold_sized(cf_ctx* ctx, int mode, float score_thresh, float nms_thresh, int img_h, int img_w,
                               int max_out, float* dets, float* lms, int32_t* counts);
+/* Optional asynchronous first half: enqueue the decode kernels right behind the last forward, no host wait.  A later
+ * cf_decode_threshold_sized (or _ex / plain, which call it) with the SAME parameters then only waits and copies the results out;
+ * with other parameters, or after another forward, it launches its own decode as usual.  For hosts that keep several contexts
+ * in flight and collect them later (CenterFaceBuckets): the decode runs when the forward finishes, not when the host gets there. */
+int cf_decode_threshold_enqueue(cf_ctx* ctx, int mode, float score_thresh, float nms_thresh, int img_h, int img_w, int max_out);
 
 /* ---- fused convenience: forward + D3 decode in one enqueue (eval_widerface.py:76-90 shape) -- */
 int cf_detect_topk(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int B, int K,

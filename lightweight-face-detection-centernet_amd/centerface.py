@@ -197,6 +197,12 @@ class Engine(object):
                                          C.c_void_p(int(lms_ptr)) if lms_ptr else None,
                                          C.c_void_p(int(inds_ptr)) if inds_ptr else None, 1))
 
+    def decode_threshold_enqueue(self, score_thresh=0.3, nms_thresh=0.3, max_out=1024, mode="d1", size=None):
+        """Enqueue the threshold decode + NMS kernels of the last forward right behind it (no host wait); a following
+        ``decode_threshold`` with the same arguments only waits and copies the results out (``cf_decode_threshold_enqueue``)."""
+        ih, iw = (self.H, self.W) if size is None else (int(size[0]), int(size[1]))
+        self._chk(self._L.cf_decode_threshold_enqueue(self._h, {"d1": 0, "d2": 1}[mode], float(score_thresh), float(nms_thresh), ih, iw, int(max_out)))
+
     def decode_threshold(self, score_thresh=0.3, nms_thresh=0.3, max_out=1024, mode="d1", size=None):
         """CenterFace.decode + nms on the last forward: list of (boxes [n,5], lms [n,10]) per image.
         mode "d2" = eval_widerface.decode (eval_widerface.py:92-110): threshold honoured, offsets used.
@@ -700,45 +706,64 @@ class CenterFaceBuckets(object):
             eng = self._engine(H, W)
             work.append([eng, [((h, w), idx[j:j + eng.max_batch]) for (h, w), idx in raws.items()
                                for j in range(0, len(idx), eng.max_batch)]])
-        # Software pipeline over the chunks, taken round-robin over the buckets: chunk i is copied into its context's page-locked
-        # buffer by the staging threads WHILE this thread collects (synchronise, D2H, rescale) the oldest chunk in flight, then
-        # chunk i is enqueued (asynchronous DMA + forward on that context's own streams).  A context has one staging buffer and
-        # one decode state, so its previous chunk is always collected before its next one is staged.
+        # Software pipeline over the chunks, taken round-robin over the buckets, on TWO host threads: this thread copies chunk i into
+        # its context's page-locked buffer (with the staging threads) and enqueues it (asynchronous DMA + resize + forward on that
+        # context's own streams); a collector thread waits for the oldest chunk in flight (decode_threshold: the wait happens inside
+        # the C call, without the GIL), copies its results out and rescales them.  Round 3 did both on one thread and was host-bound
+        # (6.3 ms per 128 images of which the device needs 4.2: profiles/r04_depth_sweep.txt).  A context has one staging buffer and
+        # one decode state, so its previous chunk is collected before its next one is staged (the future of that chunk).
         order = []
         while any(chunks for _, chunks in work):
             for eng, chunks in work:
                 if chunks:
                     order.append((eng,) + chunks.pop(0))
-        pending = []
 
         def collect(item):
             eng, (h, w), idx = item
-            post.scale_h, post.scale_w = eng.H / h, eng.W / w
-            res = post._postprocess_many(eng.decode_threshold(0.3, self.nms_thresh, self.max_dets))
+            pp = CenterFace.__new__(CenterFace)                    # per chunk: the scales differ between raw sizes
+            pp.landmarks = post.landmarks
+            pp.scale_h, pp.scale_w = eng.H / h, eng.W / w
+            res = pp._postprocess_many(eng.decode_threshold(0.3, self.nms_thresh, self.max_dets))
             for i, r in zip(idx, res):
                 out[i] = r
 
-        for item in order:
-            eng, (h, w), idx = item
-            for p in [p for p in pending if p[0] is eng]:
-                pending.remove(p)
-                collect(p)
-            stage = self._staging(eng, len(idx), h, w)
-            wait = _stage_copy_begin(stage, [imgs[i] for i in idx], background=len(pending) >= 2)
-            if len(pending) >= 2:                                  # two chunks keep the GPU busy while this one is staged
-                collect(pending.pop(0))
-            wait()
-            if (h, w) == (eng.H, eng.W):
-                eng.forward_enqueue(stage)
-            else:
-                eng.forward_resized_enqueue(stage)
-            pending.append(item)
-        for p in pending:
-            collect(p)
+        collector = self.__dict__.get("_collector")
+        if collector is None:
+            from concurrent.futures import ThreadPoolExecutor
+            collector = self.__dict__["_collector"] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cf-collect")
+        last, futs = {}, []
+        try:
+            for item in order:
+                eng, (h, w), idx = item
+                prev = last.get(id(eng))
+                if prev is not None:
+                    prev.result()                                  # this context's earlier chunk has been collected
+                stage = self._staging(eng, len(idx), h, w)
+                _stage_copy_begin(stage, [imgs[i] for i in idx])()
+                if (h, w) == (eng.H, eng.W):
+                    eng.forward_enqueue(stage)
+                else:
+                    eng.forward_resized_enqueue(stage)
+                eng.decode_threshold_enqueue(0.3, self.nms_thresh, self.max_dets)       # decode + NMS run as soon as the forward is done
+                f = collector.submit(collect, item)                # FIFO on one worker: collected in enqueue order
+                last[id(eng)] = f
+                futs.append(f)
+        finally:
+            err = None
+            for f in futs:                                         # drain even when staging / enqueue raised: no chunk stays in flight
+                try:
+                    f.result()
+                except Exception as exc:                           # noqa: BLE001
+                    err = err or exc
+            if err is not None:
+                raise err
 
     __call__ = detect
 
     def close(self):
+        col = self.__dict__.pop("_collector", None)
+        if col is not None:
+            col.shutdown(wait=True)
         for eng in self._buckets.values():
             eng.close()
         self._buckets = {}

@@ -106,6 +106,8 @@ struct cf_ctx {
     float* t_cand = nullptr; int* t_count = nullptr; int* t_order = nullptr; unsigned long long* t_mask = nullptr; int t_B = 0;
     float* t_dets = nullptr; float* t_lms = nullptr; int* t_counts = nullptr; int* t_overflow = nullptr;
     int t_cap = 0, t_maxout = 0;
+    // cf_decode_threshold_enqueue: the decode kernels of the last forward are already in the stream with these parameters
+    bool thr_pending = false; int thr_mode = 0, thr_h = 0, thr_w = 0, thr_maxout = 0, thr_B = 0; float thr_score = 0.f, thr_nms = 0.f;
     // hipGraph replay of the backbone + neck launches, one executable graph per (input pointer,
     // input format, batch): the second forward with a key captures it, later ones replay it
     struct FwdGraph { const void* in; int fmt, B; hipGraphExec_t exec; bool broken; unsigned long long used; };
@@ -956,6 +958,7 @@ hipGraphExec_t forward_graph(cf_ctx* c, const void* net_in, int in_format, int B
 }
 
 int launch_all_ops(cf_ctx* c, const void* net_in, int in_format, int B) {
+    c->thr_pending = false;                               // an enqueued threshold decode belongs to the forward before this one
     hipGraphExec_t exec = (c->flags & CF_FLAG_NO_GRAPH) ? nullptr : forward_graph(c, net_in, in_format, B);
     if (exec) HIPCHK(c, hipGraphLaunch(exec, c->stream));
     for (auto& op : c->ops) {
@@ -1258,6 +1261,36 @@ int cf_decode_threshold_ex(cf_ctx* c, int mode, float score_thresh, float nms_th
     return cf_decode_threshold_sized(c, mode, score_thresh, nms_thresh, c->H, c->W, max_out, dets, lms, counts);
 }
 
+// the decode kernels of the last forward (threshold compaction, rank, suppression matrix, sweep) on the context's stream; no host wait
+static int thresh_launch(cf_ctx* c, int mode, float score_thresh, float nms_thresh, int img_h, int img_w, int max_out, int cap) {
+    const int B = c->last_B;
+    int r = ensure_thresh_ws(c, max_out, cap, B); if (r) return r;
+    ThreshParams p{};
+    p.heads = (const float*)c->bufs[c->buf_heads].p; p.hm_plane = c->hm_plane; p.B = B; p.h = c->H / 4; p.w = c->W / 4;
+    p.img_h = img_h; p.img_w = img_w; p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = c->t_cap; p.mode = mode;
+    p.cand = c->t_cand; p.cand_count = c->t_count; p.order = c->t_order; p.mask = c->t_mask;
+    p.max_out = max_out; p.dets = c->t_dets; p.lms = c->t_lms; p.counts = c->t_counts; p.overflow = c->t_overflow;
+    HIPCHK(c, hipMemsetAsync(c->t_overflow, 0, sizeof(int), c->stream));
+    HIPCHK(c, launch_decode_threshold(c->stream, p));
+    return CF_OK;
+}
+
+// Asynchronous first half of cf_decode_threshold_sized: the decode kernels are enqueued right behind the forward (so they run as
+// soon as it finishes, not when the host gets around to collecting this context); a later cf_decode_threshold_sized with the same
+// parameters only waits, checks the overflow flag and copies the results out.  Any other forward / decode on the context in between
+// simply makes that call launch its own decode.
+int cf_decode_threshold_enqueue(cf_ctx* c, int mode, float score_thresh, float nms_thresh, int img_h, int img_w, int max_out) {
+    if (!c || max_out < 1 || (mode != 0 && mode != 1) || img_h < 1 || img_w < 1) return CF_EINVAL;
+    if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_decode_threshold_enqueue before cf_forward");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int HW = (c->H / 4) * (c->W / 4);
+    const int cap = c->t_cap > 0 ? c->t_cap : (HW < 4096 ? (HW + 63) / 64 * 64 : 4096);
+    int r = thresh_launch(c, mode, score_thresh, nms_thresh, img_h, img_w, max_out, cap); if (r) return r;
+    c->thr_pending = true; c->thr_mode = mode; c->thr_h = img_h; c->thr_w = img_w; c->thr_maxout = max_out; c->thr_B = c->last_B;
+    c->thr_score = score_thresh; c->thr_nms = nms_thresh;
+    return CF_OK;
+}
+
 int cf_decode_threshold_sized(cf_ctx* c, int mode, float score_thresh, float nms_thresh, int img_h, int img_w, int max_out,
                               float* dets, float* lms, int32_t* counts) {
     if (!c || !dets || !counts || max_out < 1 || (mode != 0 && mode != 1) || img_h < 1 || img_w < 1) return CF_EINVAL;
@@ -1268,26 +1301,30 @@ int cf_decode_threshold_sized(cf_ctx* c, int mode, float score_thresh, float nms
     // any number of cells above the threshold, centerface.py:78-79): on overflow the collect kernel reports the
     // count, the workspace is reallocated and the decode reruns
     int cap = c->t_cap > 0 ? c->t_cap : (HW < 4096 ? (HW + 63) / 64 * 64 : 4096);
+    bool launched = c->thr_pending && c->thr_mode == mode && c->thr_h == img_h && c->thr_w == img_w && c->thr_maxout == max_out && c->thr_B == B &&
+                    c->thr_score == score_thresh && c->thr_nms == nms_thresh;      // cf_decode_threshold_enqueue did the launch
+    c->thr_pending = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        int r = ensure_thresh_ws(c, max_out, cap, B); if (r) return r;
-        ThreshParams p{};
-        p.heads = (const float*)c->bufs[c->buf_heads].p; p.hm_plane = c->hm_plane; p.B = B; p.h = c->H / 4; p.w = c->W / 4;
-        p.img_h = img_h; p.img_w = img_w; p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = c->t_cap; p.mode = mode;
-        p.cand = c->t_cand; p.cand_count = c->t_count; p.order = c->t_order; p.mask = c->t_mask;
-        p.max_out = max_out; p.dets = c->t_dets; p.lms = c->t_lms; p.counts = c->t_counts; p.overflow = c->t_overflow;
-        HIPCHK(c, hipMemsetAsync(c->t_overflow, 0, sizeof(int), c->stream));
-        HIPCHK(c, launch_decode_threshold(c->stream, p));
+        if (!launched) { int r = thresh_launch(c, mode, score_thresh, nms_thresh, img_h, img_w, max_out, cap); if (r) return r; }
+        launched = false;
         int overflow = 0;
         HIPCHK(c, hipMemcpyAsync(&overflow, c->t_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(counts, c->t_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (overflow > c->t_cap && attempt == 0) { cap = (std::min(overflow, HW) + 63) / 64 * 64; continue; }
         if (overflow > c->t_cap) return c->fail(CF_EOVERFLOW, "more than %d cells above the score threshold in one image", c->t_cap);
         break;
     }
-    HIPCHK(c, hipMemcpyAsync(dets, c->t_dets, (size_t)B * max_out * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (lms) HIPCHK(c, hipMemcpyAsync(lms, c->t_lms, (size_t)B * max_out * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(counts, c->t_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // only the rows that exist: [B][rows][5 | 10] out of [B][max_out][.] (the rows past an image's count are never read by the caller)
+    int rows = 0;
+    for (int b = 0; b < B; ++b) rows = std::max(rows, std::min((int)counts[b], max_out));
+    if (rows > 0) {
+        HIPCHK(c, hipMemcpy2DAsync(dets, (size_t)max_out * 5 * sizeof(float), c->t_dets, (size_t)max_out * 5 * sizeof(float),
+                                   (size_t)rows * 5 * sizeof(float), B, hipMemcpyDeviceToHost, c->stream));
+        if (lms) HIPCHK(c, hipMemcpy2DAsync(lms, (size_t)max_out * 10 * sizeof(float), c->t_lms, (size_t)max_out * 10 * sizeof(float),
+                                            (size_t)rows * 10 * sizeof(float), B, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (thresh_mask_bytes(c->t_B, c->t_cap) > kThreshKeepBytes) free_thresh_ws(c);      // an oversized decode does not keep its workspace
     return CF_OK;
 }
@@ -1310,6 +1347,7 @@ int cf_profile_forward(cf_ctx* c, const void* in, int in_format, int in_on_devic
     const void* net_in = nullptr;
     int r = stage_input(c, in, in_format, in_on_device, B, &net_in);
     if (r) return r;
+    c->thr_pending = false;
     int nlaunch = 0;
     for (auto& op : c->ops) nlaunch += op.fused_away ? 0 : 1;
     const int nops = nlaunch + (K > 0 ? 1 : 0);
@@ -1406,6 +1444,7 @@ int cf_forward_trace(cf_ctx* c, const void* in, int in_format, int in_on_device,
     (void)hipFree(tmp);
     if (e != hipSuccess) return c->fail(CF_EHIP, "cf_forward_trace: %s", hipGetErrorString(e));
     c->last_B = op_index + 1 == (int)c->ops.size() ? B : 0;      // heads are only valid after the whole plan ran
+    c->thr_pending = false;
     return CF_OK;
 }
 

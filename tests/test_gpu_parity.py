@@ -1124,6 +1124,34 @@ def test_threshold_decode_takes_any_candidate_count_and_reports_truncation():
     assert np.array_equal(dets[0], np.asarray(O.decode_d2(hm[0], wh[0], reg[0], (640, 640), threshold=0.1), np.float32)[:100])
 
 
+def test_threshold_decode_enqueue_then_collect():
+    """cf_decode_threshold_enqueue: the decode kernels go into the stream right behind the forward; the collecting call with the
+    same parameters returns exactly what a plain decode returns, other parameters or a newer forward make it launch its own."""
+    S, B = 160, 5
+    rng = np.random.default_rng(3)
+    x1 = rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    x2 = rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    eng = cfa.Engine(S, S, max_batch=B, dtype="bf16")
+
+    def same(a, b):
+        return len(a) == len(b) and all(np.array_equal(p[0], q[0]) and np.array_equal(p[1], q[1]) for p, q in zip(a, b))
+    eng.forward_enqueue(x1); want1 = eng.decode_threshold(0.3, 0.3, 256)
+    want1_d2 = eng.decode_threshold(0.25, 0.3, 256, mode="d2", size=(640, 640))
+    eng.forward_enqueue(x2); want2 = eng.decode_threshold(0.3, 0.3, 256)
+    assert sum(len(d) for d, _ in want1) > 0 and not same(want1, want2)
+    eng.forward_enqueue(x1); eng.decode_threshold_enqueue(0.3, 0.3, 256)
+    assert same(eng.decode_threshold(0.3, 0.3, 256), want1)                      # collected
+    assert same(eng.decode_threshold(0.3, 0.3, 256), want1)                      # and again: a fresh launch, same result
+    eng.forward_enqueue(x1); eng.decode_threshold_enqueue(0.3, 0.3, 256)
+    assert same(eng.decode_threshold(0.25, 0.3, 256, mode="d2", size=(640, 640)), want1_d2)      # other parameters: its own decode
+    eng.forward_enqueue(x1); eng.decode_threshold_enqueue(0.3, 0.3, 256)
+    eng.forward_enqueue(x2)                                                      # a newer forward invalidates the enqueued decode
+    assert same(eng.decode_threshold(0.3, 0.3, 256), want2)
+    eng.forward_enqueue(x1); eng.decode_threshold_enqueue(0.3, 0.3, 4)           # more survivors than rows: the grow-and-rerun path
+    assert same(eng.decode_threshold(0.3, 0.3, 4), want1)
+    eng.close()
+
+
 def test_stream_and_buffer_hazards_between_entry_points():
     """(1) forward_resized followed by a host-input forward WITHOUT a sync in between: the resize writes a dedicated
     buffer, so the second call's H2D copy cannot overwrite what the first forward's stem still reads.  (2) A
