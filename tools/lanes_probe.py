@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B of the two-lane schedule (cf_forward_lanes) against the free-running pair of contexts (EngineRing), B = 64, 640x640,
 forward + top-100 decode, inputs resident in HBM; also checks that both schedules return identical boxes.
-`python tools/lanes_probe.py [--steps 40] [--windows 9]`; cut points via CF_LANE_CUT1 / CF_LANE_CUT2 (op-name prefixes)."""
+`python tools/lanes_probe.py [--steps 40] [--windows 9]`; cut points via CF_LANE_CUT1 / CF_LANE_CUT2 (op-name prefixes).
+Needs the EXPERIMENTS build of the library (cf_forward_lanes is not in the product ABI since round 4):
+`make -C lightweight-face-detection-centernet_amd/csrc EXP=1` and `CF_LIB=.../libcenterface_hip_exp.so python tools/lanes_probe.py`."""
 import argparse, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
