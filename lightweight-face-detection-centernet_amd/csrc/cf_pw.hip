@@ -482,7 +482,10 @@ static hipError_t dispatch_nbw(hipStream_t s, const PwParams& p) {
         static const int nbw_env = cf_ab_int("CF_PW_NBW", 0);
         // N = 320: five n-blocks per wave (activations read twice); N = 160: 3 + 2 (two workgroup rows: 200 -> 400 workgroups on
         // the 20x20 maps at B = 64, 16.7 -> 16.0 and 25.2 -> 23.1 us); N = 96: three
-        const int nbw = nbw_env ? nbw_env : (NB == 3 || NB == 5 ? 3 : (NB % 5 == 0 ? 5 : 4));
+        // fp32-width outputs (split / exact mode) of the expand GEMMs: three n-blocks per wave (N = 576: six balanced workgroup rows instead of 4 + 4 + 4 + 4 + 2;
+        // B = 64 split mode: layer5.0 / 5.1 / 6.0 expand 0.132 / 0.071 / 0.070 -> 0.118 / 0.064 / 0.064 ms; the project GEMMs keep 3 / 5: 6.0 project 0.088 -> 0.108 with three)
+        const bool wide_f32_expand = sizeof(T) == 4 && p.act == 1 && NB % 3 == 0 && NB >= 12;
+        const int nbw = nbw_env ? nbw_env : wide_f32_expand ? 3 : (NB == 3 || NB == 5 ? 3 : (NB % 5 == 0 ? 5 : 4));
         dim3 grid((unsigned)gx, (unsigned)((NB + nbw - 1) / nbw));
         // ring depth: 3-4 stages (<= 64 KB of LDS) when the grid is at most half a workgroup per CU (small batches: the
         // K chain's latency is the kernel time), 2 stages (more workgroups per CU) otherwise -- measured
