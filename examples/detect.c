@@ -70,8 +70,12 @@ int main(int argc, char** argv) {
         float* rec = (float*)malloc((size_t)world * B * K * 16 * sizeof(float));
         CHECK(NULL, cf_comm_unique_id(id, (int)sizeof id));
         CHECK(ctx, cf_comm_create(ctx, rank, world, id, &comm));
+        /* declare the shard (B images x K records) once: the only extra collective of the gather path, enqueued and polled --
+         * a host with a deadline gives up with cf_comm_abort instead of blocking in the first gather */
+        CHECK(ctx, cf_comm_set_shard(comm, B, K));
+        { int q; while ((q = cf_comm_query(comm)) == 1) { } if (q != 0) { fprintf(stderr, "shard agreement: %s\n", cf_comm_last_error(comm)); return 1; } }
         CHECK(ctx, cf_forward(ctx, img, CF_IN_U8_HWC_BGR, 0, B));
-        CHECK(ctx, cf_gather_topk(ctx, comm, K, 1, rec, 0));
+        CHECK(ctx, cf_gather_topk(ctx, comm, K, 1, rec, 0));        /* one ncclAllGather: [header | records] per rank */
         for (int b = 0; b < world * B; ++b)
             if (rec[(size_t)b * K * 16 + 4] != dets[(size_t)b * K * 6 + 4]) { fprintf(stderr, "gathered record differs\n"); return 1; }
         printf("gathered %d x %d records over RCCL (world %d)\n", world * B, K, world);

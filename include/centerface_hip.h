@@ -187,27 +187,37 @@ int cf_comm_create(cf_ctx* ctx, int rank, int world, const void* id, cf_comm** o
 int cf_comm_create_all(cf_ctx** ctxs, int n, cf_comm** out);
 int cf_comm_destroy(cf_comm* comm);
 /* Give up on a communicator whose collective does not complete (ncclCommAbort: in-flight RCCL kernels exit), then release
- * it.  cf_comm_query: 0 = every enqueued gather has completed, 1 = still running, CF_EINVAL = a gather found unequal
- * (B, K) on the ranks (latched by the agreement step in front of it; reported whether or not the record gather behind it
- * ever completes; text from cf_comm_last_error).  Never blocks -- a host polls it against its own deadline and aborts
- * instead of hanging.  cf_comm_synchronize waits by polling cf_comm_query, so the latch ends the wait too. */
+ * it.  cf_comm_query: 0 = everything enqueued on the gather stream (shard agreement, gathers) has completed, 1 = still
+ * running, CF_EINVAL = the agreement or a slot header found unequal (B, K) or unequal step numbers on the ranks (latched;
+ * text from cf_comm_last_error).  Never blocks -- a host polls it against its own deadline and aborts instead of hanging.
+ * cf_comm_synchronize waits by polling cf_comm_query, so the latch ends the wait too. */
 int cf_comm_abort(cf_comm* comm);
 int cf_comm_query(cf_comm* comm);
 int cf_comm_synchronize(cf_comm* comm);
 const char* cf_comm_last_error(cf_comm* comm);
+/* Declare the shard every rank gathers: B images x K records (= the fixed slot size of every later gather).  Collective by
+ * contract: every rank calls it with the same values at the same point of its call sequence (the first cf_gather_topk of a
+ * communicator calls it implicitly; call it again on every rank to change the geometry).  It enqueues the ONLY extra
+ * collective of the gather path -- a 2-int all-gather of each rank's (B, K) plus a device-side compare that latches a
+ * mismatch -- and returns without waiting; poll cf_comm_query (0 = agreed, CF_EINVAL = unequal shards) against a deadline.
+ * The first gather of the geometry reads that verdict (waiting for it if the host has not) BEFORE it enqueues a record
+ * gather, so an all-gather with per-rank-unequal counts is never launched. */
+int cf_comm_set_shard(cf_comm* comm, int B, int K);
 /* Test hooks.  what = 0: park the gather stream behind a spin kernel of `value` ms (a collective that does not complete in
- * time); what = 1: the next gather publishes B + value in its agreement step (the mismatch path on a single rank). */
+ * time); what = 1: the header of the next gather's slot carries B + value (the mismatch path on a single rank). */
 int cf_comm_debug(cf_comm* comm, int what, int value);
 void* cf_comm_stream(cf_comm* comm);                    /* the gather stream (hipStream_t) */
 /* D3 decode of the last forward (as cf_decode_topk) followed by the all-gather: records [world * B, K, 16] =
  * x1,y1,x2,y2,score,cls,lm0..lm9 per detection, rank-major = exactly the batch order of the unsharded run.  Every rank
- * must pass the same B and K.  EVERY gather is preceded on the gather stream by a 2-int all-gather of each rank's (B, K)
- * and a device-side compare (rank-invariant: the collective sequence never depends on per-rank state; no host wait).  A
- * mismatch is latched: the blocking form returns CF_EINVAL before the record gather is enqueued; the asynchronous form
- * reports it from cf_comm_query / cf_comm_synchronize / the next cf_gather_topk.  The decode runs on the context's decode
- * stream, the all-gather on the communicator's stream behind it, both underneath the next forward.  out_on_device = 1:
- * `records` is a device buffer, the call never waits on the host (cf_comm_query / cf_comm_synchronize before reading it);
- * 0: host buffer, blocking. */
+ * must pass the same B and K (cf_comm_set_shard).  ONE collective per call: each rank sends a fixed-size slot = a 64-byte
+ * header {magic, B, K, step number} + its B x K x 16 records; behind the all-gather a device kernel checks every rank's
+ * header against the agreed shard and this rank's step count and strips the headers into `records`.  A rank whose shard
+ * differs from the agreed one still sends a full-size slot (carrying its real B, K) and returns CF_EINVAL: the counts and
+ * the collective sequence stay identical on all ranks, every rank latches the mismatch, nobody hangs.  A latched mismatch
+ * is reported by the blocking form itself, and by cf_comm_query / cf_comm_synchronize / the next cf_gather_topk for the
+ * asynchronous form.  The decode runs on the context's decode stream, the all-gather on the communicator's stream behind
+ * it, both underneath the next forward.  out_on_device = 1: `records` is a device buffer, the call never waits on the host
+ * once the shard is agreed (cf_comm_query / cf_comm_synchronize before reading it); 0: host buffer, blocking. */
 int cf_gather_topk(cf_ctx* ctx, cf_comm* comm, int K, int use_reg, float* records, int out_on_device);
 
 /* ---- stream / timing plumbing -------------------------------------------------------------- */

@@ -732,6 +732,7 @@ class CenterFaceBuckets(object):
             from concurrent.futures import ThreadPoolExecutor
             collector = self.__dict__["_collector"] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cf-collect")
         last, futs = {}, []
+        main_exc = None
         try:
             for item in order:
                 eng, (h, w), idx = item
@@ -748,15 +749,23 @@ class CenterFaceBuckets(object):
                 f = collector.submit(collect, item)                # FIFO on one worker: collected in enqueue order
                 last[id(eng)] = f
                 futs.append(f)
-        finally:
-            err = None
-            for f in futs:                                         # drain even when staging / enqueue raised: no chunk stays in flight
-                try:
-                    f.result()
-                except Exception as exc:                           # noqa: BLE001
-                    err = err or exc
-            if err is not None:
-                raise err
+        except BaseException as exc:                               # noqa: BLE001  (re-raised below, after the drain)
+            main_exc = exc
+        # drain even when staging / enqueue raised: no chunk stays in flight.  The exception of this thread wins; a collector
+        # failure is raised only when nothing else is propagating (and is not re-raised a second time when it already surfaced
+        # through prev.result() above).
+        err = None
+        for f in futs:
+            try:
+                f.result()
+            except Exception as exc:                               # noqa: BLE001
+                err = err or exc
+        if main_exc is not None:
+            if err is not None and err is not main_exc:
+                raise main_exc from err
+            raise main_exc
+        if err is not None:
+            raise err
 
     __call__ = detect
 
@@ -764,6 +773,19 @@ class CenterFaceBuckets(object):
         col = self.__dict__.pop("_collector", None)
         if col is not None:
             col.shutdown(wait=True)
-        for eng in self._buckets.values():
+        for eng in self.__dict__.get("_buckets", {}).values():
             eng.close()
         self._buckets = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()                                           # the collector thread does not outlive the object
+        except Exception:                                          # noqa: BLE001
+            pass

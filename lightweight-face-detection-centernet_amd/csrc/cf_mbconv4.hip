@@ -386,14 +386,24 @@ static const F4Entry kF4Table[] = {
 #undef F4X
 
 static const F4Entry* f4_find(int dtype, int k, int s, int jx, int nbo, int res) {
-    static const int want = cf_env_int("CF_F4_VARIANT", 0);      // product switch: 1 = every fp32 block on this file's kernel
-    const F4Entry* base = nullptr;
+    // product switch: 1 = every fp32 block on this file's kernel.  Other values select sweep rows and exist in the experiments
+    // build only (var 2 = the split mode's own defaults: never selectable for the exact mode, whose goldens pin the arithmetic)
+    static const int want = [] {
+        const int v = cf_env_int("CF_F4_VARIANT", 0);
+#ifdef CF_EXPERIMENTS
+        return v == 2 ? 0 : v;
+#else
+        return v == 1 ? 1 : 0;
+#endif
+    }();
+    const F4Entry *def0 = nullptr, *def2 = nullptr;
     for (const F4Entry& e : kF4Table)
         if (e.k == k && e.s == s && e.jx == jx && e.nbo == nbo && e.res == res) {
             if (want && e.var == want) return &e;
-            if (e.var == 0 || (e.var == 2 && dtype == 2)) base = &e;
+            if (e.var == 0 && !def0) def0 = &e;
+            if (e.var == 2 && !def2) def2 = &e;
         }
-    return base;                           // nullptr: the block stays on cf_mbconv.hip
+    return (dtype == 2 && def2) ? def2 : def0;      // split mode prefers its own row explicitly; nullptr: the block stays on cf_mbconv.hip
 }
 
 bool mb4_geometry(int dtype, MbGeom& g, int Cin, int hid, int Cout, int k, int s) {

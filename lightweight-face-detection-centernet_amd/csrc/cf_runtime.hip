@@ -95,7 +95,8 @@ struct cf_ctx {
     std::string err;
     hipEvent_t events[64] = {};
     // decode workspaces (lazy)
-    unsigned long long* keys = nullptr; int* key_count = nullptr; unsigned long long* big = nullptr; size_t big_stride = 0; float* d_rec = nullptr;
+    unsigned long long* keys = nullptr; int* key_count = nullptr; unsigned long long* big = nullptr; size_t big_stride = 0;
+    float* d_rec = nullptr; float* d_slot = nullptr;                    // d_rec = d_slot + 16: the gather slot of a rank is [header | records]
     hipEvent_t ev_main_dec = nullptr; bool main_dec_pending = false;
     // two-lane schedule (cf_forward_lanes): segment events and the back half still to be launched
     hipEvent_t ev_seg1 = nullptr, ev_seg2 = nullptr; bool seg2_recorded = false;
@@ -390,9 +391,9 @@ __global__ void cf_spin_kernel(long long ticks) {
     while (wall_clock64() - t0 < ticks) { }
 }
 
-// shard agreement of cf_gather_topk: publish this rank's (B, K) ...
+// Shard agreement of the gather (cf_comm_set_shard): publish this rank's (B, K), all-gather the pairs ONCE per geometry, ...
 __global__ void cf_comm_publish_kernel(int* mine, int B, int K) { mine[0] = B; mine[1] = K; }
-// ... and, behind the all-gather of those pairs, compare every rank's against ours; a mismatch is latched in host-visible memory
+// ... and compare every rank's against ours; a mismatch is latched in host-visible memory
 __global__ void cf_comm_compare_kernel(const int* all, int world, int B, int K, int* flag) {
     if (threadIdx.x != 0 || flag[0]) return;
     for (int r = 0; r < world; ++r)
@@ -403,6 +404,36 @@ __global__ void cf_comm_compare_kernel(const int* all, int world, int B, int K, 
             __threadfence_system();
             return;
         }
+}
+// Every gather step sends ONE fixed-size slot per rank: a 16-float header {magic, B, K, step} in front of the B x K x 16 records.
+constexpr unsigned kSlotMagic = 0x43464731u;      // "CFG1"
+constexpr int kSlotHeader = 16;                   // floats (64 bytes: the records stay line-aligned)
+__global__ void cf_comm_header_kernel(float* slot, int B, int K, unsigned step) {
+    unsigned* h = reinterpret_cast<unsigned*>(slot);
+    h[0] = kSlotMagic; h[1] = (unsigned)B; h[2] = (unsigned)K; h[3] = step;
+}
+// Behind the all-gather of the slots: validate every rank's header against the agreed shard (B, K) and this step's number --
+// a mismatch is latched in host-visible memory, as above -- and copy the records of all ranks, rank-major, into `dst`
+// (nullptr: validate only; the host-destination path strips the headers with a strided copy instead).
+__global__ void cf_comm_unpack_kernel(const float* slots, int world, size_t slot_floats, int B, int K, unsigned step, float* dst, int* flag) {
+    const size_t n = (size_t)B * K * 16;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !flag[0])
+        for (int r = 0; r < world; ++r) {
+            const unsigned* h = reinterpret_cast<const unsigned*>(slots + (size_t)r * slot_floats);
+            if (h[0] != kSlotMagic || h[1] != (unsigned)B || h[2] != (unsigned)K || h[3] != step) {
+                flag[1] = r; flag[2] = (int)h[1]; flag[3] = (int)h[2]; flag[4] = B; flag[5] = K; flag[6] = (int)h[3]; flag[7] = (int)step;
+                __threadfence_system();
+                flag[0] = h[0] != kSlotMagic ? 3 : (h[3] != step && h[1] == (unsigned)B && h[2] == (unsigned)K) ? 2 : 1;
+                __threadfence_system();
+                break;
+            }
+        }
+    if (!dst) return;
+    const size_t n4 = n / 4, total = n4 * world;                       // 16 floats per record: n is a multiple of 4
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / n4, j = i - r * n4;
+        reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(slots + r * slot_floats + kSlotHeader)[j];
+    }
 }
 
 // One host-to-device copy stream per DEVICE, shared by every context on it.  Two contexts with a copy stream each
@@ -528,7 +559,7 @@ int cf_destroy(cf_ctx* c) {
     if (c->ev_seg2) hipEventDestroy(c->ev_seg2);
     for (auto& b : c->bufs) if (b.p) hipFree(b.p);
     for (void* p : c->owned) hipFree(p);
-    for (void* p : {(void*)c->src_stage, (void*)c->d_trans, (void*)c->hm_plane, (void*)c->keys, (void*)c->key_count, (void*)c->big, (void*)c->d_rec, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
+    for (void* p : {(void*)c->src_stage, (void*)c->d_trans, (void*)c->hm_plane, (void*)c->keys, (void*)c->key_count, (void*)c->big, (void*)c->d_slot, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
                     (void*)c->t_order, (void*)c->t_mask, (void*)c->t_dets, (void*)c->t_lms, (void*)c->t_counts, (void*)c->t_overflow})
         if (p) hipFree(p);
     for (auto& ev : c->events) if (ev) hipEventDestroy(ev);
@@ -883,12 +914,14 @@ int ensure_topk_ws(cf_ctx* c, int K) {
         HIPCHK(c, hipStreamSynchronize(c->stream));           // a decode in flight may still write the old buffers
         HIPCHK(c, hipStreamSynchronize(c->stream2));
         if (c->gather_pending) { HIPCHK(c, hipEventSynchronize(c->ev_gather)); c->gather_pending = false; }   // ... and a gather may still read d_rec
-        for (void* p : {(void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->d_rec, (void*)c->big}) if (p) hipFree(p);
-        c->d_dets = nullptr; c->d_lms = nullptr; c->d_inds = nullptr; c->d_rec = nullptr; c->big = nullptr; c->big_stride = 0;
+        for (void* p : {(void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->d_slot, (void*)c->big}) if (p) hipFree(p);
+        c->d_dets = nullptr; c->d_lms = nullptr; c->d_inds = nullptr; c->d_slot = nullptr; c->d_rec = nullptr; c->big = nullptr; c->big_stride = 0;
         HIPCHK(c, hipMalloc((void**)&c->d_dets, (size_t)c->max_batch * K * 6 * sizeof(float)));
         HIPCHK(c, hipMalloc((void**)&c->d_lms, (size_t)c->max_batch * K * 10 * sizeof(float)));
         HIPCHK(c, hipMalloc((void**)&c->d_inds, (size_t)c->max_batch * K * sizeof(long long)));
-        HIPCHK(c, hipMalloc((void**)&c->d_rec, (size_t)c->max_batch * K * 16 * sizeof(float)));
+        // the gather records live behind a 16-float header: [header | B x K x 16] is the slot one rank sends per gather step
+        HIPCHK(c, hipMalloc((void**)&c->d_slot, ((size_t)c->max_batch * K * 16 + kSlotHeader) * sizeof(float)));
+        c->d_rec = c->d_slot + kSlotHeader;
         if (K > 1024) {
             c->big_stride = topk_big_stride(K);
             HIPCHK(c, hipMalloc((void**)&c->big, (size_t)c->max_batch * c->big_stride * sizeof(unsigned long long)));
@@ -1304,13 +1337,17 @@ int cf_decode_threshold_sized(cf_ctx* c, int mode, float score_thresh, float nms
     bool launched = c->thr_pending && c->thr_mode == mode && c->thr_h == img_h && c->thr_w == img_w && c->thr_maxout == max_out && c->thr_B == B &&
                     c->thr_score == score_thresh && c->thr_nms == nms_thresh;      // cf_decode_threshold_enqueue did the launch
     c->thr_pending = false;
+    // the pre-enqueued launch is only valid while the workspace it wrote still exists with the geometry it was launched on
+    if (launched && (!c->t_overflow || !c->t_counts || c->t_B < B || c->t_cap < 1 || c->t_maxout < max_out)) launched = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (!launched) { int r = thresh_launch(c, mode, score_thresh, nms_thresh, img_h, img_w, max_out, cap); if (r) return r; }
         launched = false;
         int overflow = 0;
-        HIPCHK(c, hipMemcpyAsync(&overflow, c->t_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(counts, c->t_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // `overflow` lives on this stack frame: never return while a copy into it may still be in flight
+        const hipError_t e1 = hipMemcpyAsync(&overflow, c->t_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(counts, c->t_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream) : e1;
+        const hipError_t e3 = hipStreamSynchronize(c->stream);
+        HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
         if (overflow > c->t_cap && attempt == 0) { cap = (std::min(overflow, HW) + 63) / 64 * 64; continue; }
         if (overflow > c->t_cap) return c->fail(CF_EOVERFLOW, "more than %d cells above the score threshold in one image", c->t_cap);
         break;
@@ -1604,13 +1641,20 @@ struct cf_comm {
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;                       // THE gather stream of this rank: every all-gather of every context goes here, in call order
     hipEvent_t ev_done = nullptr;                       // recorded after the last enqueued all-gather (cf_comm_query / _synchronize)
-    float* recv = nullptr; size_t recv_elems = 0;       // staging for host destinations
-    // shard agreement (B, K of every rank), checked on EVERY gather by a device-side compare behind a 2-int all-gather: the
-    // decision to issue that collective never depends on per-rank state, and the host never waits for it
+    // ONE collective per gather step: every rank sends a fixed-size slot [16-float header {magic, B, K, step} | B x K x 16
+    // records].  The slot geometry (B, K) is agreed ONCE (cf_comm_set_shard, or the first gather): a 2-int all-gather + a
+    // device-side compare whose verdict the host reads before the first record gather of that geometry is enqueued -- so an
+    // all-gather with per-rank-unequal counts is never launched.  After that, the header of every slot is validated on the
+    // device behind the all-gather (a rank whose shard changed still sends a full-size slot carrying its real (B, K): every
+    // rank latches the mismatch, nobody hangs).
+    int slot_B = 0, slot_K = 0; bool slot_verified = false; size_t slot_floats = 0;
+    unsigned step = 0;                                  // gathers enqueued so far: carried in the header, equal on all ranks by construction
+    float* recv = nullptr; size_t recv_elems = 0;       // [world][slot] landing area of the all-gather
+    float* d_spare = nullptr; size_t spare_elems = 0;   // a slot-size send buffer for the rank-local mismatch path
     int* d_chk = nullptr;                               // [world][2] gathered (B, K) + [2] this rank's pair
-    int* h_flag = nullptr; int* d_flag = nullptr;       // pinned + mapped: {mismatch seen, peer rank, peer B, peer K, my B, my K} (sticky)
-    hipEvent_t ev_chk = nullptr;                        // behind the compare kernel (blocking gathers wait for it)
-    int debug_skew = 0;                                 // cf_comm_debug(1, v): the next gather publishes B + v (tests of the mismatch path)
+    int* h_flag = nullptr; int* d_flag = nullptr;       // pinned + mapped: {verdict, peer rank, peer B, peer K, my B, my K, peer step, my step} (sticky)
+    hipEvent_t ev_chk = nullptr;                        // behind the compare kernel of the agreement
+    int debug_skew = 0;                                 // cf_comm_debug(1, v): the next gather's header carries B + v (tests of the mismatch path)
     std::string err;
 };
 
@@ -1735,6 +1779,7 @@ int cf_comm_destroy(cf_comm* m) {
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
     if (m->recv) hipFree(m->recv);
+    if (m->d_spare) hipFree(m->d_spare);
     if (m->d_chk) hipFree(m->d_chk);
     if (m->h_flag) hipHostFree(m->h_flag);
     if (m->comm) rccl()->CommDestroy(m->comm);
@@ -1754,20 +1799,25 @@ int cf_comm_abort(cf_comm* m) {
     return cf_comm_destroy(m);
 }
 
-// the latched verdict of the device-side shard comparison (cf_gather_topk): CF_EINVAL + text once any gather saw unequal shards
+// the latched verdict of the device-side checks (agreement compare, slot headers): CF_EINVAL + text once any of them failed
 static int comm_mismatch(cf_comm* m) {
     volatile int* f = m->h_flag;
     if (!f || !f[0]) return CF_OK;
-    char buf[256];
-    snprintf(buf, sizeof buf, "cf_gather_topk: rank %d has (B=%d, K=%d), rank %d has (B=%d, K=%d) -- the gather needs equal shards (pad the last one)",
-             m->rank, f[4], f[5], f[1], f[2], f[3]);
+    char buf[320];
+    if (f[0] == 2)
+        snprintf(buf, sizeof buf, "cf_gather_topk: rank %d is at gather step %d, rank %d sent step %d -- every rank must call cf_gather_topk the same number of times in the same order",
+                 m->rank, f[7], f[1], f[6]);
+    else if (f[0] == 3)
+        snprintf(buf, sizeof buf, "cf_gather_topk: the slot received from rank %d carries no gather header (another payload size or library version on that rank?)", f[1]);
+    else
+        snprintf(buf, sizeof buf, "cf_gather_topk: rank %d has (B=%d, K=%d), rank %d has (B=%d, K=%d) -- the gather needs equal shards (pad the last one)",
+                 m->rank, f[4], f[5], f[1], f[2], f[3]);
     m->err = buf;
     return CF_EINVAL;
 }
 
-// 0: every enqueued gather has completed, 1: still running, < 0: error (CF_EINVAL: a gather saw unequal shards on the ranks --
-// reported as soon as the 2-int agreement collective in front of it has run, whether or not the record gather behind it
-// ever completes).  Never blocks.
+// 0: everything enqueued on the gather stream (agreement, gathers) has completed, 1: still running, < 0: error (CF_EINVAL: the
+// agreement or a slot header found unequal shards / steps on the ranks).  Never blocks.
 int cf_comm_query(cf_comm* m) {
     if (!m) return CF_EINVAL;
     hipSetDevice(m->device);
@@ -1779,8 +1829,7 @@ int cf_comm_query(cf_comm* m) {
     return CF_EHIP;
 }
 
-// Waits for the gather stream by POLLING, so that a latched shard mismatch ends the wait even when the record gather behind
-// it hangs (unequal counts): CF_EINVAL then, and cf_comm_abort is the way out.
+// Waits for the gather stream by POLLING (a latched mismatch ends the wait: CF_EINVAL, and cf_comm_abort is the way out).
 int cf_comm_synchronize(cf_comm* m) {
     if (!m) return CF_EINVAL;
     for (unsigned spins = 0;; ++spins) {
@@ -1793,7 +1842,7 @@ int cf_comm_synchronize(cf_comm* m) {
 const char* cf_comm_last_error(cf_comm* m) { return m ? m->err.c_str() : "null communicator"; }
 
 // Test hooks.  what = 0: park the gather stream behind a spin kernel of `value` milliseconds (a collective that does not
-// complete in time, for the deadline tests); what = 1: the next gather publishes B + value (the mismatch path at world 1).
+// complete in time, for the deadline tests); what = 1: the header of the next gather's slot carries B + value (the mismatch path at world 1).
 int cf_comm_debug(cf_comm* m, int what, int value) {
     if (!m) return CF_EINVAL;
     hipSetDevice(m->device);
@@ -1808,6 +1857,43 @@ int cf_comm_debug(cf_comm* m, int what, int value) {
 
 void* cf_comm_stream(cf_comm* m) { return m ? (void*)m->stream : nullptr; }
 
+// Declare the shard every rank will gather: B images x K records.  Collective by contract (every rank calls it with the same
+// values at the same point of its call sequence; the first cf_gather_topk of a communicator calls it implicitly).  Enqueues,
+// on the gather stream, the only extra collective of the gather path -- a 2-int all-gather of each rank's (B, K) and a
+// device-side compare that latches a mismatch -- and returns without waiting: a host with a deadline polls cf_comm_query
+// (0 = agreed, CF_EINVAL = unequal shards) and aborts instead of blocking.  The first gather of the geometry reads the verdict
+// (waiting for it if the host did not) BEFORE it enqueues a record gather: unequal counts never reach ncclAllGather.
+int cf_comm_set_shard(cf_comm* m, int B, int K) {
+    if (!m || B < 1 || K < 1) return CF_EINVAL;
+    if (!m->comm) { m->err = "communicator was aborted"; return CF_ESTATE; }
+    if (hipSetDevice(m->device) != hipSuccess) { m->err = "hipSetDevice failed"; return CF_EHIP; }
+    { int mm = comm_mismatch(m); if (mm) return mm; }
+    const size_t slot = (size_t)B * K * 16 + kSlotHeader;
+    auto hipfail = [&](hipError_t e, const char* what) { m->err = std::string(what) + ": " + hipGetErrorString(e); return CF_EHIP; };
+    if (m->recv_elems < slot * m->world || m->spare_elems < slot) {
+        hipError_t e = hipStreamSynchronize(m->stream);                  // gathers of the previous geometry still use the old buffers
+        if (e != hipSuccess) return hipfail(e, "hipStreamSynchronize");
+        if (m->recv) (void)hipFree(m->recv);
+        if (m->d_spare) (void)hipFree(m->d_spare);
+        m->recv = nullptr; m->recv_elems = 0; m->d_spare = nullptr; m->spare_elems = 0;
+        if ((e = hipMalloc((void**)&m->recv, slot * m->world * sizeof(float))) != hipSuccess) return hipfail(e, "hipMalloc (gather landing area)");
+        m->recv_elems = slot * m->world;
+        if ((e = hipMalloc((void**)&m->d_spare, slot * sizeof(float))) != hipSuccess) return hipfail(e, "hipMalloc (spare slot)");
+        if ((e = hipMemsetAsync(m->d_spare, 0, slot * sizeof(float), m->stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
+        m->spare_elems = slot;
+    }
+    m->slot_B = B; m->slot_K = K; m->slot_floats = slot; m->slot_verified = false;
+    int* mine = m->d_chk + 2 * m->world;
+    hipLaunchKernelGGL(cf_comm_publish_kernel, dim3(1), dim3(1), 0, m->stream, mine, B, K);
+    hipError_t le = hipGetLastError(); if (le != hipSuccess) return hipfail(le, "cf_comm_publish_kernel");
+    ncclResult_t e = rccl()->AllGather(mine, m->d_chk, 2, ncclInt32, m->comm, m->stream);
+    if (e != ncclSuccess) { m->err = std::string("ncclAllGather (shard agreement): ") + rccl()->GetErrorString(e); return CF_EHIP; }
+    hipLaunchKernelGGL(cf_comm_compare_kernel, dim3(1), dim3(64), 0, m->stream, (const int*)m->d_chk, m->world, B, K, m->d_flag);
+    if ((le = hipGetLastError()) != hipSuccess) return hipfail(le, "cf_comm_compare_kernel");
+    if ((le = hipEventRecord(m->ev_chk, m->stream)) != hipSuccess) return hipfail(le, "hipEventRecord");
+    return CF_OK;
+}
+
 int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, int out_on_device) {
     if (!c || !m || !records) return CF_EINVAL;
     if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_gather_topk before cf_forward");
@@ -1819,64 +1905,69 @@ int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, in
     int r = ensure_topk_ws(c, K); if (r) return r;
     if (!c->ev_gather) HIPCHK(c, hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
     { int mm = comm_mismatch(m); if (mm) return c->fail(CF_EINVAL, "%s", m->err.c_str()); }
-    // ncclAllGather takes ONE count for all ranks: ranks with different shards would hang or mis-place records without any
-    // error.  EVERY gather is therefore preceded, on the gather stream, by an all-gather of each rank's (B, K) and a device-side
-    // compare that latches a mismatch in host-visible memory.  Rank-invariant (no rank decides from local state whether to issue
-    // the extra collective, so the collective sequence is identical everywhere) and asynchronous (the host never waits for it:
-    // cf_comm_query / cf_comm_synchronize / the next cf_gather_topk report the latch).
-    {
-        int* mine = m->d_chk + 2 * m->world;
-        hipLaunchKernelGGL(cf_comm_publish_kernel, dim3(1), dim3(1), 0, m->stream, mine, B + m->debug_skew, K);
-        m->debug_skew = 0;
-        HIPCHK(c, hipGetLastError());
-        ncclResult_t e = rccl()->AllGather(mine, m->d_chk, 2, ncclInt32, m->comm, m->stream);
-        if (e != ncclSuccess) return c->fail(CF_EHIP, "ncclAllGather (shard agreement): %s", rccl()->GetErrorString(e));
-        hipLaunchKernelGGL(cf_comm_compare_kernel, dim3(1), dim3(64), 0, m->stream, (const int*)m->d_chk, m->world, B, K, m->d_flag);
-        HIPCHK(c, hipGetLastError());
-        if (!out_on_device) {
-            // the blocking form may wait: the verdict is known before the record gather is enqueued
-            HIPCHK(c, hipEventRecord(m->ev_chk, m->stream));
-            for (unsigned spins = 0;; ++spins) {
-                hipError_t q = hipEventQuery(m->ev_chk);
-                if (q == hipSuccess) break;
-                if (q != hipErrorNotReady) return c->fail(CF_EHIP, "hipEventQuery (shard agreement): %s", hipGetErrorString(q));
-                (void)hipGetLastError();
-                if (spins > 200) usleep(20);
-            }
-            int mm = comm_mismatch(m); if (mm) return c->fail(CF_EINVAL, "%s", m->err.c_str());
+    // ncclAllGather takes ONE count for all ranks.  The count of every gather is the slot agreed by cf_comm_set_shard (implicitly
+    // here on the first gather): its verdict is read -- waited for by polling if the host has not done so through
+    // cf_comm_query -- before the first record gather of the geometry is enqueued.
+    if (!m->slot_B) { r = cf_comm_set_shard(m, B, K); if (r) return c->fail(r, "%s", m->err.c_str()); }
+    if (!m->slot_verified) {
+        for (unsigned spins = 0;; ++spins) {
+            hipError_t q = hipEventQuery(m->ev_chk);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return c->fail(CF_EHIP, "hipEventQuery (shard agreement): %s", hipGetErrorString(q));
+            (void)hipGetLastError();
+            if (spins > 200) usleep(20);
         }
+        int mm = comm_mismatch(m); if (mm) return c->fail(CF_EINVAL, "%s", m->err.c_str());
+        m->slot_verified = true;
     }
-    const size_t n = (size_t)B * K * 16;
-    float* dst = records;
-    if (!out_on_device) {
-        if (m->recv_elems < n * m->world) {
-            HIPCHK(c, hipStreamSynchronize(m->stream));
-            if (m->recv) HIPCHK(c, hipFree(m->recv));
-            m->recv = nullptr; m->recv_elems = 0;
-            HIPCHK(c, hipMalloc((void**)&m->recv, n * m->world * sizeof(float)));
-            m->recv_elems = n * m->world;
-        }
-        dst = m->recv;
+    // A shard that differs from the agreed one is a rank-LOCAL fact: this rank still enqueues its full-size slot (from the spare
+    // buffer, the header carrying its real (B, K)), so the collective sequence and every count stay identical on all ranks, every
+    // rank's header check latches the mismatch, and the call returns CF_EINVAL here.
+    const bool local_ok = (B == m->slot_B && K == m->slot_K);
+    const size_t n = (size_t)m->slot_B * m->slot_K * 16;
+    const unsigned step = m->step++;
+    float* src = c->d_slot;
+    if (local_ok) {
+        // decode stream of the context: [wait forward] [wait the previous gather: it reads d_slot] decode -> records -> event
+        // gather stream of the communicator (one per rank, shared by all its contexts): [wait that event] header, all-gather,
+        // header check + unpack (-> D2H).  With ONE communicator and ONE stream per rank every rank enqueues its collectives in
+        // the same order as long as it calls cf_gather_topk in the same order -- no cross-communicator ordering to get wrong.
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
+        if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_gather, 0));
+        r = enqueue_topk(c, B, K, use_reg, nullptr, nullptr, nullptr, nullptr, c->stream2, c->d_rec);
+        if (r) return r;
+        HIPCHK(c, hipEventRecord(c->ev_dec, c->stream2));
+        c->dec_pending = true;
+        HIPCHK(c, hipStreamWaitEvent(m->stream, c->ev_dec, 0));
+    } else {
+        src = m->d_spare;
     }
-    // decode stream of the context: [wait forward] [wait the previous gather: it reads d_rec] decode -> records -> event
-    // gather stream of the communicator (one per rank, shared by all its contexts): [wait that event] all-gather (-> D2H)
-    // With ONE communicator and ONE stream per rank every rank enqueues its collectives in the same order as long as it
-    // calls cf_gather_topk in the same order -- no cross-communicator ordering to get wrong.
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
-    if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_gather, 0));
-    r = enqueue_topk(c, B, K, use_reg, nullptr, nullptr, nullptr, nullptr, c->stream2, c->d_rec);
-    if (r) return r;
-    HIPCHK(c, hipEventRecord(c->ev_dec, c->stream2));
-    c->dec_pending = true;
-    HIPCHK(c, hipStreamWaitEvent(m->stream, c->ev_dec, 0));
-    ncclResult_t e = rccl()->AllGather(c->d_rec, dst, n, ncclFloat, m->comm, m->stream);
+    hipLaunchKernelGGL(cf_comm_header_kernel, dim3(1), dim3(1), 0, m->stream, src, B + m->debug_skew, K, step);
+    m->debug_skew = 0;
+    HIPCHK(c, hipGetLastError());
+    ncclResult_t e = rccl()->AllGather(src, m->recv, m->slot_floats, ncclFloat, m->comm, m->stream);
     if (e != ncclSuccess) return c->fail(CF_EHIP, "ncclAllGather: %s", rccl()->GetErrorString(e));
-    HIPCHK(c, hipEventRecord(c->ev_gather, m->stream));
-    c->gather_pending = true;
+    float* dev_dst = (local_ok && out_on_device) ? records : nullptr;
+    const int ublocks = dev_dst ? (int)std::min<size_t>(1024, (n / 4 * m->world + 255) / 256) : 1;
+    hipLaunchKernelGGL(cf_comm_unpack_kernel, dim3(ublocks), dim3(256), 0, m->stream, (const float*)m->recv, m->world, m->slot_floats, m->slot_B, m->slot_K, step, dev_dst, m->d_flag);
+    HIPCHK(c, hipGetLastError());
+    if (local_ok) {
+        HIPCHK(c, hipEventRecord(c->ev_gather, m->stream));
+        c->gather_pending = true;
+    }
+    if (!local_ok) {
+        volatile int* f = m->h_flag;                     // the device check will latch the same verdict; make it visible to the host now
+        if (!f[0]) { f[1] = m->rank; f[2] = B; f[3] = K; f[4] = m->slot_B; f[5] = m->slot_K; f[0] = 1; }
+        return c->fail(CF_EINVAL, "cf_gather_topk: this rank's shard is (B=%d, K=%d), the communicator agreed on (B=%d, K=%d) -- the gather needs equal shards (pad the last one, or cf_comm_set_shard on every rank)",
+                       B, K, m->slot_B, m->slot_K);
+    }
     if (!out_on_device) {
-        HIPCHK(c, hipMemcpyAsync(records, dst, n * m->world * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        // host destination: strip the headers with a strided copy (row = one rank's records), then the verdict of this step's check
+        HIPCHK(c, hipMemcpy2DAsync(records, n * sizeof(float), m->recv + kSlotHeader, m->slot_floats * sizeof(float), n * sizeof(float), (size_t)m->world,
+                                   hipMemcpyDeviceToHost, m->stream));
         HIPCHK(c, hipStreamSynchronize(m->stream));
         c->gather_pending = false;
+        int mm = comm_mismatch(m); if (mm) return c->fail(CF_EINVAL, "%s", m->err.c_str());
     }
     return CF_OK;
 }

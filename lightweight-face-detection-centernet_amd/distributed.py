@@ -134,6 +134,15 @@ class Comm(object):
         _lib.check(_lib.lib().cf_comm_create_all(ctxs, n, outs), engines[0]._h)
         return [cls(e, i, n, None, _handle=C.c_void_p(outs[i])) for i, e in enumerate(engines)]
 
+    def set_shard(self, B, K):
+        """``cf_comm_set_shard``: declare the shard (B images x K records) every rank gathers.  Collective by contract (same
+        values, same point of the call sequence on every rank); enqueues the one agreement collective of the gather path and
+        returns without waiting -- ``wait(timeout)`` / ``query()`` give the verdict (RuntimeError on unequal shards).  The
+        first ``gather_topk*`` calls it implicitly and then waits for the verdict itself."""
+        r = _lib.lib().cf_comm_set_shard(self._h, int(B), int(K))
+        if r != 0:
+            raise RuntimeError("cf_comm_set_shard failed (%d): %s" % (r, self.last_error()))
+
     def gather_topk(self, K=100, use_reg=True, engine=None):
         """Decode the engine's last forward and all-gather: float32 [world * B, K, 16] (host, blocking)."""
         eng = engine or self.engine
@@ -158,8 +167,8 @@ class Comm(object):
         return (_lib.lib().cf_comm_last_error(self._h) or b"").decode()
 
     def debug(self, what, value):
-        """Test hooks of ``cf_comm_debug``: (0, ms) parks the gather stream behind a spin kernel, (1, d) skews the B the next
-        gather publishes in its agreement step."""
+        """Test hooks of ``cf_comm_debug``: (0, ms) parks the gather stream behind a spin kernel, (1, d) skews the B in the header of the
+        next gather's slot."""
         if _lib.lib().cf_comm_debug(self._h, int(what), int(value)) != 0:
             raise RuntimeError("cf_comm_debug(%d, %d) failed" % (what, value))
 

@@ -108,8 +108,11 @@ def match_counts(picked_boxes, annot_boxes, threshold=0.5, device=0):
     return counts
 
 
-def _accumulate(picked_boxes, annots, threshold, device, strip_padding=True):
-    """One batch of evaluate (:180-208): the reference's three empty cases, then the two ratios per image."""
+def _accumulate(picked_boxes, annots, threshold, device, strip_padding=True, reference_empties=True):
+    """One batch of evaluate (:180-208): the reference's three empty cases, then the two ratios per image.
+    ``reference_empties=False`` (box_match between two detection sets): an image on which BOTH sets are empty is a perfect
+    match (1, 1), and a set that is empty on one side only scores (0, 0) -- the reference's bookkeeping credits recall or
+    precision there for reasons that have nothing to do with agreement between two detectors."""
     annots = [np.asarray(a, np.float32).reshape(-1, np.asarray(a).shape[-1] if len(a) else 4) for a in annots]
     if strip_padding:
         annots = [a[a[:, 0] != -1] for a in annots]
@@ -118,6 +121,13 @@ def _accumulate(picked_boxes, annots, threshold, device, strip_padding=True):
     for j, boxes in enumerate(picked_boxes):
         na = annots[j].shape[0]
         nb = 0 if boxes is None else len(boxes)
+        if not reference_empties:
+            if nb == 0 and na == 0:
+                recall_iter += 1.0
+                precision_iter += 1.0
+                continue
+            if nb == 0 or na == 0:
+                continue
         if boxes is None and na == 0:
             continue
         if nb < 1 and na != 0:
@@ -151,6 +161,8 @@ def evaluate(val_data, model, threshold=0.5, device=0, detections=None):
 
 def box_match(test_boxes, ref_boxes, threshold=0.5, device=0):
     """The evaluate metric between two detection sets of the same images (``ref_boxes`` in the role of the annotations):
-    {"recall", "precision"} in the reference's sense (previous docstring).  Lists of float32 [n,4+] (or [] for no boxes)."""
-    r, p = _accumulate(list(test_boxes), list(ref_boxes), threshold, device, strip_padding=False)
+    {"recall", "precision"} in the reference's sense (previous docstring) on the images where both sets have boxes; both sets
+    empty = a perfect match, one empty = (0, 0) (evaluate keeps the reference's own empty cases).  Lists of float32 [n,4+]
+    (or [] for no boxes)."""
+    r, p = _accumulate(list(test_boxes), list(ref_boxes), threshold, device, strip_padding=False, reference_empties=False)
     return {"recall": r, "precision": p, "iou_threshold": threshold, "images": len(test_boxes)}

@@ -176,9 +176,11 @@ def test_bench_first_gather_deadline_covers_the_first_collective():
 
 
 def test_gather_is_asynchronous_and_latches_a_shard_mismatch():
-    """cf_gather_topk(out_on_device=1) returns while the gather stream is parked (no host wait on its agreement collective);
-    a (B, K) mismatch between ranks -- forced here by skewing the B this rank publishes -- is latched by the device-side
-    compare and reported by query / synchronize / the next gather, for the blocking form before the record gather is enqueued."""
+    """ONE collective per gather step: the shard (B, K) is agreed once (cf_comm_set_shard: enqueued, polled),
+    every gather sends a fixed-size slot whose header carries (B, K, step) and is validated on the device behind the all-gather.
+    cf_gather_topk(out_on_device=1) returns while the gather stream is parked (no host wait once the shard is agreed); a (B, K)
+    mismatch between ranks -- forced here by skewing the B in this rank's header -- is latched and reported by query /
+    synchronize / the next gather, and by the blocking form itself."""
     import time
     import torch
     S, B, K = 96, 3, 20
@@ -186,10 +188,19 @@ def test_gather_is_asynchronous_and_latches_a_shard_mismatch():
     eng = cfa.Engine(S, S, max_batch=B, dtype="bf16")
     comm = cfa.distributed.Comm(eng, 0, 1, cfa.distributed.unique_id())
     out = torch.zeros((B, K, 16), dtype=torch.float32, device="cuda:0")
+    # explicit agreement with the gather stream parked: set_shard returns at once, the verdict arrives by polling
+    comm.debug(0, 800)
+    t0 = time.perf_counter()
+    comm.set_shard(B, K)
+    assert time.perf_counter() - t0 < 0.5, "cf_comm_set_shard waited on the host"
+    assert comm.query()
+    assert comm.wait(60.0)
     eng.forward_enqueue(imgs)
     comm.gather_topk_device(K, out.data_ptr())          # warm-up (loads RCCL kernels)
     assert comm.wait(60.0)
     want = out.cpu().numpy().copy()
+    eng.forward_enqueue(imgs)
+    assert np.array_equal(want, _records(eng, K))        # the unpack kernel stripped the slot header: records only, in place
     comm.debug(0, 1500)                                  # park the gather stream for 1.5 s
     t0 = time.perf_counter()
     eng.forward_enqueue(imgs)
@@ -209,14 +220,56 @@ def test_gather_is_asynchronous_and_latches_a_shard_mismatch():
         comm.synchronize()
     with pytest.raises((RuntimeError, ValueError), match="equal shards"):
         comm.gather_topk_device(K, out.data_ptr())
+    with pytest.raises(RuntimeError, match="equal shards"):
+        comm.set_shard(B, K)                             # the latch is sticky: abort is the way out
     comm.abort()
-    # blocking form on a fresh communicator: CF_EINVAL from the call itself
+    # blocking form on a fresh communicator (implicit agreement on its first gather): CF_EINVAL from the call itself
     comm = cfa.distributed.Comm(eng, 0, 1, cfa.distributed.unique_id())
     eng.forward_enqueue(imgs)
     assert np.array_equal(comm.gather_topk(K), want)
     comm.debug(1, -1)
     with pytest.raises((RuntimeError, ValueError), match="equal shards"):
         comm.gather_topk(K)
+    comm.abort()
+    eng.close()
+
+
+def test_gather_shard_change_is_rank_local_and_never_sends_unequal_counts():
+    """a rank whose shard differs from the agreed one (a short last batch) must not enqueue an all-gather with
+    another count.  It sends the agreed slot size with its real (B, K) in the header and gets CF_EINVAL at once; the header
+    check latches the mismatch (as it would on every other rank), and a new geometry needs cf_comm_set_shard on a fresh
+    communicator or before any mismatch.  Also: changing the geometry through set_shard, and K != the agreed K."""
+    import torch
+    S, B, K = 96, 4, 20
+    imgs = np.random.default_rng(18).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    eng = cfa.Engine(S, S, max_batch=B, dtype="bf16")
+    comm = cfa.distributed.Comm(eng, 0, 1, cfa.distributed.unique_id())
+    eng.forward_enqueue(imgs)
+    want = _records(eng, K)
+    assert np.array_equal(comm.gather_topk(K), want)
+    # geometry change done right: set_shard (collective by contract), then gathers of the new shape
+    comm.set_shard(B - 1, K + 5)
+    assert comm.wait(30.0)
+    eng.forward_enqueue(imgs[:B - 1])
+    want2 = _records(eng, K + 5)
+    got2 = comm.gather_topk(K + 5)
+    assert got2.shape == (B - 1, K + 5, 16) and np.array_equal(got2, want2)
+    out = torch.zeros((B - 1, K + 5, 16), dtype=torch.float32, device="cuda:0")
+    eng.forward_enqueue(imgs[:B - 1])
+    comm.gather_topk_device(K + 5, out.data_ptr())
+    assert comm.wait(30.0) and np.array_equal(out.cpu().numpy(), want2)
+    # a short shard without set_shard: rank-local CF_EINVAL, full-size slot sent, latched
+    eng.forward_enqueue(imgs[:B - 2])
+    with pytest.raises((RuntimeError, ValueError), match="equal shards"):
+        comm.gather_topk_device(K + 5, out.data_ptr())
+    with pytest.raises(RuntimeError, match="equal shards"):
+        comm.wait(30.0)                                  # the collective itself completed (equal counts); the verdict is the latch
+    comm.abort()
+    comm = cfa.distributed.Comm(eng, 0, 1, cfa.distributed.unique_id())
+    comm.set_shard(B, K)
+    eng.forward_enqueue(imgs)
+    with pytest.raises((RuntimeError, ValueError), match="equal shards"):
+        comm.gather_topk(K + 1)                          # another K than the agreed one
     comm.abort()
     eng.close()
 
