@@ -341,7 +341,8 @@ def parity_block(cfa, eng16, host_imgs, d_in_ptr, B, S, K, dev_index):
     sg = O.sigmoid_clamp(emu["hm"]).numpy()
     ed, _, ei = O.ctdet_decode(sg, emu["wh"].numpy(), emu["reg"].numpy(), K)
     rms = float(np.sqrt((emu["hm"].numpy() ** 2).mean()))
-    return {
+    aux = {"p32": p32, "ref_boxes": ref_boxes, "thr": thr, "sd_m": sd_m}
+    return aux, {
         "box_match": box_match,
         "vs_fp32_parity_engine": {
             "images": B, "topk": K, "index_overlap_mean": round(float(np.mean(overlap)), 2), "index_overlap_min": int(min(overlap)),
@@ -359,14 +360,52 @@ def parity_block(cfa, eng16, host_imgs, d_in_ptr, B, S, K, dev_index):
     }
 
 
-def tolerance_block(cfa, d_in_ptr, B, S, K, dev_index):
-    """The timed batch through the tolerance mode (fp32_split) against the exact-fp32 engine: every head value and the decode."""
+def kernel_profile(eng, cfa, d_in_ptr, B, K, reps):
+    """HIP events on the ctx stream around every launch of the forward (cf_profile_forward), `reps` times: per kernel symbol the
+    summed ms / algorithmic bytes / flops / launches, and the dominant symbol."""
+    agg = {}
+    for _ in range(reps):
+        for r in eng.profile_forward(d_in_ptr, on_device=True, B=B, in_format=cfa._lib.CF_IN_U8_HWC_BGR, K=K):
+            a = agg.setdefault(r["kernel"], dict(kind=r["kind"], ms=0.0, bytes=0.0, flops=0.0, launches=0, layers=set()))
+            a["ms"] += r["ms"]; a["bytes"] += r["algo_bytes"]; a["flops"] += r["flops"]; a["launches"] += 1
+            a["layers"].add(r["name"])
+    tot_ms = sum(a["ms"] for a in agg.values()) / reps
+    dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    return agg, tot_ms, dom_name, dom
+
+
+def tolerance_block(cfa, host_imgs, d_in_ptr, B, S, K, dev_index, aux, profile_reps):
+    """The timed batch through the tolerance mode (fp32_split): every head value and the decode against the exact-fp32 engine,
+    against the CPU oracle (= the reference's arithmetic) on image 0, BASELINE.json's "box match vs ref" for this mode, and the
+    roofline of its dominant kernel."""
+    import glob
+    import torch
+    from oracle import centerface_oracle as O
+    from centerface_amd import eval_widerface as ew
     fmt = cfa._lib.CF_IN_U8_HWC_BGR
     res = {}
+    roof = None
     for dt in ("fp32", "fp32_split"):
         e = cfa.Engine(S, S, max_batch=B, dtype=dt, device=dev_index)
         e.forward_enqueue(d_in_ptr, on_device=True, B=B, in_format=fmt)
         res[dt] = (e.heads(sigmoid_hm=True), e.decode_topk(K))
+        if dt == "fp32_split":
+            agg, tot_ms, dom_name, dom = kernel_profile(e, cfa, d_in_ptr, B, K, profile_reps)
+            avg_ms, avg_bytes = dom["ms"] / dom["launches"], dom["bytes"] / dom["launches"]
+            traffic = None
+            try:
+                tj = sorted(glob.glob(os.path.join(REPO, "profiles", "*_split_traffic.json")))[-1]
+                traffic = json.load(open(tj)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            except Exception:                               # noqa: BLE001
+                traffic = None
+            ach = avg_bytes / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": avg_bytes, "layers": sorted(dom["layers"]),
+                    "forward_ms_sum_of_kernels": round(tot_ms, 3),
+                    "forward_algo_GBps": round(sum(a["bytes"] for a in agg.values()) / profile_reps / (tot_ms * 1e-3) / 1e9, 1),
+                    "note": "dominant kernel symbol of the fp32_split forward: algorithmic bytes / HIP-event launch time (one context); traffic = PMC "
+                            "FETCH_SIZE x 2 + WRITE_SIZE of the newest committed profiles/*_split_traffic.json; what binds these kernels is LDS + VALU issue "
+                            "(DESIGN.md section 4), the HBM fraction is the contract's figure"}
         e.close()
     (h0, (d0, l0, i0)), (h1, (d1, l1, i1)) = res["fp32"], res["fp32_split"]
     out = {"images": B, "topk": K}
@@ -380,7 +419,39 @@ def tolerance_block(cfa, d_in_ptr, B, S, K, dev_index):
     # ranks that differ: score ties within the head difference (the two modes' rounding decides the order)
     if (~same).any():
         out["score_gap_at_differing_ranks_max"] = float("%.3g" % np.abs(d0[..., 4][~same] - d1[..., 4][~same]).max())
-    return out
+    # ---- against the CPU oracle (the reference's fp32 arithmetic), image 0 of the timed batch: north_star's tolerance itself
+    ref = O.forward(O.to_torch_sd(cfa.weights.synthetic_state_dict(0)), torch.from_numpy(O.preprocess(host_imgs[0])))
+    ref_hm = O.sigmoid_clamp(ref["hm"]).numpy()
+    vs_oracle = {"image": 0}
+    for k in ("hm", "wh", "lm", "reg"):
+        vs_oracle["max_abs_diff_" + k] = float("%.3g" % np.abs(h1[k][:1] - ref[k].numpy()).max())
+    vs_oracle["max_abs_diff_hm_sigmoid"] = float("%.3g" % np.abs(h1["hm_sigmoid"][:1] - ref_hm).max())
+    vs_oracle["allclose_1e-3"] = bool(all(np.allclose(h1[k][:1], ref[k].numpy(), rtol=1e-3, atol=1e-3) for k in ("hm", "wh", "lm", "reg")) and
+                                      np.allclose(h1["hm_sigmoid"][:1], ref_hm, atol=1e-3, rtol=0))
+    rdet, _, rinds = O.ctdet_decode(ref_hm, ref["wh"].numpy(), ref["reg"].numpy(), K, ref["lm"].numpy())
+    same0 = i1[0] == rinds[0]
+    vs_oracle["same_index_same_rank"] = int(same0.sum())
+    vs_oracle["index_overlap"] = len(set(i1[0].tolist()) & set(rinds[0].tolist()))
+    if same0.any():
+        vs_oracle["max_abs_box_diff_map_px"] = float("%.3g" % np.abs(d1[0][same0][:, :4] - rdet[0][same0][:, :4]).max())
+        vs_oracle["max_abs_score_diff"] = float("%.3g" % np.abs(d1[0][same0][:, 4] - rdet[0][same0][:, 4]).max())
+    # ---- "box match vs ref" for this mode: the same measure, threshold and shifted weights as parity.box_match
+    box_match = None
+    if aux is not None:
+        e = cfa.Engine(S, S, max_batch=B, dtype="fp32_split", device=dev_index, weights=aux["sd_m"])
+        e.forward_enqueue(d_in_ptr, on_device=True, B=B, in_format=fmt)
+        psp = [b for b, _ in e.decode_threshold(aux["thr"], 0.3, mode="d2")]
+        e.close()
+        bm = ew.box_match(psp, aux["p32"], 0.5, device=dev_index)
+        bmo = ew.box_match([psp[0]], [aux["ref_boxes"]], 0.5, device=dev_index)
+        rb = aux["ref_boxes"]
+        box_match = {"tolerance_vs_exact_fp32_engine": {"images": B, "recall": round(bm["recall"], 5), "precision": round(bm["precision"], 5),
+                                                        "boxes_tolerance": int(sum(len(b) for b in psp)), "boxes_exact": int(sum(len(b) for b in aux["p32"]))},
+                     "tolerance_vs_cpu_oracle_image0": {"recall": round(bmo["recall"], 5), "precision": round(bmo["precision"], 5), "boxes_oracle": int(len(rb)),
+                                                        "max_abs_box_diff_px": (round(float(np.abs(psp[0][:, :4] - rb[:, :4]).max()), 6)
+                                                                                if psp[0].shape == rb.shape and len(rb) else None)},
+                     "iou_threshold": 0.5, "score_threshold": round(aux["thr"], 6), "nms_threshold": 0.3, "wh_bias_shift": 6.0}
+    return out, vs_oracle, box_match, roof
 
 
 def main():
@@ -528,18 +599,11 @@ def main():
     med = float(np.median(wins))
 
     result = None
+    parity_aux = None
     if rank == 0:
         value = world * B * args.steps / med
         # ---- per-kernel profile (HIP events on the ctx stream around every launch)
-        agg = {}
-        for _ in range(args.profile_reps):
-            for r in eng.profile_forward(d_in.data_ptr(), on_device=True, B=B,
-                                         in_format=cfa._lib.CF_IN_U8_HWC_BGR, K=K):
-                a = agg.setdefault(r["kernel"], dict(kind=r["kind"], ms=0.0, bytes=0.0, flops=0.0, launches=0, layers=set()))
-                a["ms"] += r["ms"]; a["bytes"] += r["algo_bytes"]; a["flops"] += r["flops"]; a["launches"] += 1
-                a["layers"].add(r["name"])
-        tot_ms = sum(a["ms"] for a in agg.values()) / args.profile_reps
-        dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        agg, tot_ms, dom_name, dom = kernel_profile(eng, cfa, d_in.data_ptr(), B, K, args.profile_reps)
         avg_ms = dom["ms"] / dom["launches"]
         avg_bytes = dom["bytes"] / dom["launches"]
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
@@ -564,7 +628,8 @@ def main():
             vj = sorted(glob.glob(os.path.join(REPO, "profiles", "*_valu_counts.json")))[-1]
             vc = json.load(open(vj))
             if (B, S, args.dtype) == (64, 640, "bf16"):
-                per, sb, sm, sr = [], 0.0, 0.0, 0.0
+                per, sb, sm, sr, sh = [], 0.0, 0.0, 0.0, 0.0
+                have_hw = True
                 for name, a in agg.items():
                     kc = vc["kernels"].get(name)
                     if kc is None:
@@ -572,14 +637,27 @@ def main():
                     n = a["launches"] // args.profile_reps
                     ms = a["ms"] / args.profile_reps
                     sb += kc["bound_us"] * n * 1e-3; sm += ms; sr += kc["rocprof_avg_us"] * n * 1e-3
+                    hw = kc.get("bound_hw_us")
+                    have_hw = have_hw and hw is not None
+                    sh += (hw or 0.0) * n * 1e-3
                     per.append({"kernel": name, "launches": n, "bound_ms": round(kc["bound_us"] * n * 1e-3, 4), "measured_ms": round(ms, 4),
-                                "rocprof_ms": round(kc["rocprof_avg_us"] * n * 1e-3, 4), "frac": round(kc["bound_us"] * n * 1e-3 / ms, 3) if ms > 0 else None})
+                                "rocprof_ms": round(kc["rocprof_avg_us"] * n * 1e-3, 4), "frac": round(kc["bound_us"] * n * 1e-3 / ms, 3) if ms > 0 else None,
+                                "bound_hw_ms": round(hw * n * 1e-3, 4) if hw is not None else None,
+                                "frac_hw": round(hw * n * 1e-3 / ms, 3) if (hw is not None and ms > 0) else None})
                 per.sort(key=lambda r: -r["measured_ms"])
                 valu_issue = {"bound_ms": round(sb, 4), "measured_ms": round(sm, 4), "rocprof_ms": round(sr, 4),
                               "frac": round(sb / sm, 4) if sm > 0 else None, "frac_vs_rocprof": round(sb / sr, 4) if sr > 0 else None,
-                              "counts": os.path.basename(vj), "per_kernel": per[:12],
-                              "note": "sum over the forward's kernels of (wave-instruction counts x issue cost) / 1024 SIMDs / 2.4 GHz; measured = HIP events "
-                                      "of this run (one context), rocprof = committed rocprofv3 --kernel-trace averages of the same kernels"}
+                              "bound_hw_ms": round(sh, 4) if have_hw else None, "frac_hw": round(sh / sm, 4) if (have_hw and sm > 0) else None,
+                              "frac_hw_vs_rocprof": round(sh / sr, 4) if (have_hw and sr > 0) else None,
+                              "cost_table": vc.get("cost_cycles_per_wave_instruction"), "cost_table_hw": vc.get("cost_hw_cycles_per_wave_instruction"),
+                              "counts": os.path.basename(vj), "counts_are": "committed dynamic instruction counts of this workload (a constant of the repo, not of this run); the measured_ms they are divided by are this run's",
+                              "per_kernel": per[:12],
+                              "note": "TWO cost tables.  bound_ms: sum over the forward's kernels of (wave-instruction counts x MEASURED issue cost, wall time of a dense "
+                                      "stream of that class expressed in cycles of a nominal 2.4 GHz: transcendental 9.45, packed 5.65, dot2c 4.53, VOP3 4.5, plain 3.1; "
+                                      "LDS / VMEM / MFMA issue slots) / 1024 SIMDs / 2.4 GHz -- what this instruction mix costs in wall time.  bound_hw_ms: VALU "
+                                      "instructions only at ARCHITECTURAL rates (transcendental 8, packed / dot2 4, everything else 2 shader cycles at 2.4 GHz): the "
+                                      "hardware guide's floor, which no sustained stream reaches (tools/ub_clock_probe.hip: dense v_fma_f32 = 2.28 shader cycles at a "
+                                      "power-capped 1.94 GHz).  measured = HIP events of this run (one context), rocprof = committed rocprofv3 --kernel-trace averages"}
         except Exception:                                   # noqa: BLE001
             valu_issue = None
         dom_valu = None
@@ -644,7 +722,7 @@ def main():
                 w1 = time_windows(st1, fence, args.steps, 7)
                 result["value_one_context"] = {"value": round(B * args.steps / float(np.median(w1)), 1), "unit": "images/s",
                                                "note": "the same steps on a single context (one batch in flight); median of 7 windows"}
-            result["parity"] = parity_block(cfa, eng, host_imgs, d_in.data_ptr(), B, S, K, local_rank)
+            parity_aux, result["parity"] = parity_block(cfa, eng, host_imgs, d_in.data_ptr(), B, S, K, local_rank)
     eng_closed = False
     if rank == 0 and world == 1 and not args.no_extras and args.dtype == "bf16":
         close_comms()
@@ -673,12 +751,13 @@ def main():
             return round(B * 6 / float(np.median(w)), 1), round(B * 5 / float(np.median(wb)), 1), len(r2.engines)
         # ---- tolerance mode: the mode that meets north_star's "box/score within 1e-3 of the reference" at speed
         v, v1, nctx = mode_rate("fp32_split")
+        tol_exact, tol_oracle, tol_bm, tol_roof = tolerance_block(cfa, host_imgs, d_in.data_ptr(), B, S, K, local_rank, parity_aux, max(1, args.profile_reps))
         result["tolerance_mode"] = {
             "value": v, "unit": "images/s", "batch": B, "value_one_context": v1, "dtype": "fp32_split",
             "arithmetic": "fp32 storage in HBM and LDS; every GEMM product (stem, expand, project, neck, heads) as a split-bf16 product on the bf16 "
                           "matrix pipe: x = hi + lo (bf16 pairs, 16 mantissa bits), w.x = w_hi.x_hi + w_lo.x_hi + w_hi.x_lo on v_mfma_f32_32x32x8_bf16_1k, fp32 "
                           "accumulate; Swish, depthwise taps, residual adds and epilogues in fp32",
-            "vs_exact_fp32_engine": tolerance_block(cfa, d_in.data_ptr(), B, S, K, local_rank),
+            "vs_exact_fp32_engine": tol_exact, "vs_cpu_oracle_image0": tol_oracle, "box_match": tol_bm, "roofline": tol_roof,
             "note": "%d context(s) round-robin like the headline; median of 7 windows of 6 steps; the reference-golden and oracle tests at "
                     "rtol = atol = 1e-3 run on this mode too (tests/test_gpu_parity.py, EXACT)" % nctx}
         v, v1, nctx = mode_rate("fp32")

@@ -1871,8 +1871,11 @@ int cf_comm_set_shard(cf_comm* m, int B, int K) {
     const size_t slot = (size_t)B * K * 16 + kSlotHeader;
     auto hipfail = [&](hipError_t e, const char* what) { m->err = std::string(what) + ": " + hipGetErrorString(e); return CF_EHIP; };
     if (m->recv_elems < slot * m->world || m->spare_elems < slot) {
-        hipError_t e = hipStreamSynchronize(m->stream);                  // gathers of the previous geometry still use the old buffers
-        if (e != hipSuccess) return hipfail(e, "hipStreamSynchronize");
+        hipError_t e = hipSuccess;
+        if (m->recv || m->d_spare) {                                     // gathers of the previous geometry still use the old buffers
+            e = hipStreamSynchronize(m->stream);                         // (never on the first agreement: nothing to wait for, no host wait)
+            if (e != hipSuccess) return hipfail(e, "hipStreamSynchronize");
+        }
         if (m->recv) (void)hipFree(m->recv);
         if (m->d_spare) (void)hipFree(m->d_spare);
         m->recv = nullptr; m->recv_elems = 0; m->d_spare = nullptr; m->spare_elems = 0;

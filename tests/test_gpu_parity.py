@@ -671,6 +671,53 @@ def test_full_size_640_fp32_vs_oracle_topk(dtype):
     eng.close()
 
 
+def test_batch64_tolerance_mode_vs_cpu_oracle():
+    """The tolerance mode AT THE BATCH IT IS TIMED ON (BASELINE configs[1]: B = 64, 640x640, top-100): the
+    fp32_split engine on the bench's 64 synthetic images against the CPU oracle -- the reference's fp32 arithmetic -- on four
+    images spread over the batch (every image runs the same kernels, the batch index is only blockIdx.z; the oracle of all 64
+    takes minutes).  north_star's tolerance, written here: head maps and sigmoid scores rtol = atol = 1e-3; decoded boxes and
+    scores within 1e-3; top-100 indices identical wherever the oracle's neighbouring scores are separated by more than 4x the
+    measured score error (gap-qualified ranks), and at the other ranks the engine's index is a near-tie of the oracle's."""
+    B, S, K = 64, 640, 100
+    rng = np.random.default_rng(0)
+    imgs = rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    sd = cfa.weights.synthetic_state_dict(0)
+    tsd = O.to_torch_sd(sd)
+    eng = cfa.Engine(S, S, max_batch=B, dtype="fp32_split", weights=sd)
+    eng.forward_enqueue(imgs)
+    got = eng.heads(sigmoid_hm=True)
+    dets, lms, inds = eng.decode_topk(K=K)
+    pick = [0, 21, 42, 63]
+    # decode of OUR heads is bit-exact against the oracle decode of the same heads
+    od, ol, oi = O.ctdet_decode(got["hm_sigmoid"][pick], got["wh"][pick], got["reg"][pick], K, got["lm"][pick])
+    assert np.array_equal(inds[pick], oi) and np.array_equal(dets[pick], od) and np.array_equal(lms[pick], ol)
+    n_gap = n_same = 0
+    for b in pick:
+        ref = O.forward(tsd, torch.from_numpy(O.preprocess(imgs[b])))
+        for k in ("hm", "wh", "lm", "reg"):
+            np.testing.assert_allclose(got[k][b:b + 1], ref[k].numpy(), rtol=1e-3, atol=1e-3, err_msg="image %d head %s" % (b, k))
+        ref_hm = O.sigmoid_clamp(ref["hm"]).numpy()
+        np.testing.assert_allclose(got["hm_sigmoid"][b:b + 1], ref_hm, atol=1e-3, rtol=0)
+        rdet, rlms, rinds = O.ctdet_decode(ref_hm, ref["wh"].numpy(), ref["reg"].numpy(), K, ref["lm"].numpy())
+        err = float(np.abs(got["hm_sigmoid"][b:b + 1] - ref_hm).max())
+        sc = rdet[0, :, 4]
+        gap_ok = np.ones_like(sc, bool)
+        gap_ok[:-1] &= (sc[:-1] - sc[1:]) > 4 * err
+        gap_ok[1:] &= (sc[:-1] - sc[1:]) > 4 * err
+        assert gap_ok.mean() > 0.5, (b, float(gap_ok.mean()), err)
+        assert np.array_equal(inds[b][gap_ok], rinds[0][gap_ok]), b
+        np.testing.assert_allclose(dets[b][gap_ok], rdet[0][gap_ok], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(lms[b][gap_ok], rlms[0][gap_ok], atol=1e-3, rtol=1e-3)
+        same = inds[b] == rinds[0]
+        flat = ref_hm.ravel()
+        for r in np.nonzero(~same)[0]:                       # a swapped rank is a near-tie of the oracle's own scores
+            assert abs(flat[inds[b][r]] - sc[r]) <= 4 * err, (b, int(r), float(flat[inds[b][r]]), float(sc[r]), err)
+        assert len(set(inds[b].tolist()) & set(rinds[0].tolist())) >= 99, b
+        n_gap += int(gap_ok.sum()); n_same += int(same.sum())
+    print("gap-qualified ranks %d / 400, identical ranks %d / 400" % (n_gap, n_same))
+    eng.close()
+
+
 @pytest.mark.parametrize("dtype", EXACT)
 def test_vga_480x640_fp32_vs_oracle(dtype):
     """BASELINE config 4 geometry (VGA, non-square, multiples of 32): heads + D3 decode vs the oracle."""

@@ -25,6 +25,14 @@ LDS_ISSUE, VMEM_ISSUE, MFMA_ISSUE = 4.0, 4.0, 4.0                             # 
 # (tools/ub_mfma_coissue_probe.hip, profiles/r03_mfma_coissue.md): the matrix pipe overlaps only partly with VALU issue
 MFMA_COST = {"4x4x4": 4.5, "16x16": 12.0, "32x32": 22.0}
 SIMDS, CLK = 1024, 2.4e9
+# The second table: ARCHITECTURAL issue rates in shader cycles (MI355X_MICROARCH.md: v_fma_f32 2 cycles = the 157 TFLOP/s vector
+# peak; transcendentals quarter rate = 8; packed fp32 / dot2 move two elements per lane = 4), VALU instructions only, at the full
+# 2.4 GHz.  tools/ub_clock_probe.hip (profiles/r05_valu_clock_probe.md) reconciles the two: a dense v_fma_f32 stream issues at 2.28
+# shader cycles per instruction (loop and dependency overhead over the architectural 2.0) and pulls the shader clock down to
+# 1.94 GHz (power cap), which is 2.8 'cycles' of wall time at a nominal 2.4 GHz -- the COST table above; transcendentals measure
+# 8.1 shader cycles at 2.38 GHz.  The architectural table is a floor no sustained instruction stream reaches on this chip; the
+# measured table is what a stream of that mix costs in wall time.
+COST_HW = {"trans": 8.0, "pk": 4.0, "dot": 4.0, "vop3": 2.0, "plain": 2.0}
 
 TRANS = ("v_exp_", "v_rcp_", "v_log_", "v_sqrt_", "v_rsq_", "v_sin_", "v_cos_")
 
@@ -101,17 +109,22 @@ def main():
              "LDS / VMEM instructions one %.0f-cycle issue slot each; an MFMA 4.5 (4x4x4) / 12 (16x16) / 22 (32x32) cycles of VALU issue) over %d SIMDs at %.1f GHz, against the" % (LDS_ISSUE, SIMDS, CLK / 1e9),
              "measured duration.  `bound/measured` near 1 = the kernel runs at its own instruction-issue bound (rocm-smi shows",
              "sclk 2375-2382 MHz and ~1225 W of the 1400 W cap while bench.py runs: the clock is not the gap).", "",
-             "| kernel | M VALU | of which trans | M MFMA | M LDS | avg cost non-trans | issue-bound us | measured us | bound / measured |",
-             "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+             "Second table (`hw bound`): VALU instructions only at ARCHITECTURAL rates (transcendental 8, packed / dot2 4, everything else 2 shader cycles,",
+             "2.4 GHz): the floor the hardware guide's 157 TFLOP/s vector peak implies.  tools/ub_clock_probe.hip shows why no sustained stream reaches it:",
+             "a dense v_fma_f32 stream issues at 2.28 shader cycles and holds only 1.94 GHz under the power cap (= 2.8 nominal cycles of wall time).", "",
+             "| kernel | M VALU | of which trans | M MFMA | M LDS | avg cost non-trans | issue-bound us | measured us | bound / measured | hw bound us | hw bound / measured |",
+             "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
     jout = {}
     for k, c in sorted(cnt.items(), key=lambda kv: -dur.get(kv[0], 0)):
         if "cf::" not in k or k not in dur:
             continue
         mix = mixes.get(k)
         mfc = MFMA_ISSUE
+        avg_hw = 2.0
         if mix:
             nt = {cl: n for cl, n in mix.items() if cl != "trans" and not cl.startswith("mfma:")}
             avg = sum(COST[cl] * n for cl, n in nt.items()) / max(1, sum(nt.values()))
+            avg_hw = sum(COST_HW[cl] * n for cl, n in nt.items()) / max(1, sum(nt.values()))
             mm = {cl[5:]: n for cl, n in mix.items() if cl.startswith("mfma:")}
             if mm:
                 mfc = sum(MFMA_COST[t] * n for t, n in mm.items()) / sum(mm.values())
@@ -121,16 +134,21 @@ def main():
         mf, lds, vm = c.get("SQ_INSTS_MFMA", 0), c.get("SQ_INSTS_LDS", 0), c.get("SQ_INSTS_VMEM", 0)
         cyc = tr * COST["trans"] + (valu - tr - mf) * avg + lds * LDS_ISSUE + vm * VMEM_ISSUE + mf * mfc
         bound_us = cyc / SIMDS / CLK * 1e6
+        cyc_hw = tr * COST_HW["trans"] + (valu - tr - mf) * avg_hw                    # VALU instructions only, architectural rates
+        cyc_hw2 = tr * 8.0 + (valu - tr) * 2.0                                          # VERDICT r04's own arithmetic: 8 / 2 for everything SQ_INSTS_VALU counts
         jout[k] = {"valu": valu, "trans": tr, "mfma": mf, "lds": lds, "vmem": vm, "avg_cost_nontrans": round(avg, 3), "mfma_cost": round(mfc, 2),
-                   "issue_cycles": cyc, "bound_us": round(bound_us, 2), "rocprof_avg_us": round(dur[k] / 1e3, 2)}
-        lines.append("| `%s` | %.2f | %.2f | %.2f | %.2f | %.2f | %.1f | %.1f | %.2f |" % (
-            k, valu / 1e6, tr / 1e6, mf / 1e6, lds / 1e6, avg, bound_us, dur[k] / 1e3, bound_us / (dur[k] / 1e3)))
+                   "issue_cycles": cyc, "bound_us": round(bound_us, 2), "rocprof_avg_us": round(dur[k] / 1e3, 2),
+                   "avg_cost_nontrans_hw": round(avg_hw, 3), "bound_hw_us": round(cyc_hw / SIMDS / CLK * 1e6, 2), "bound_hw_8_2_us": round(cyc_hw2 / SIMDS / CLK * 1e6, 2)}
+        lines.append("| `%s` | %.2f | %.2f | %.2f | %.2f | %.2f | %.1f | %.1f | %.2f | %.1f | %.2f |" % (
+            k, valu / 1e6, tr / 1e6, mf / 1e6, lds / 1e6, avg, bound_us, dur[k] / 1e3, bound_us / (dur[k] / 1e3),
+            jout[k]["bound_hw_us"], jout[k]["bound_hw_us"] / (dur[k] / 1e3)))
     open(a.out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     if a.json:
         import json
         json.dump({"workload": "B=64 640x640 bf16 forward + top-100 decode, one launch of each kernel (tools/profile_ops.py)",
                    "cost_cycles_per_wave_instruction": dict(COST, lds=LDS_ISSUE, vmem=VMEM_ISSUE, mfma=MFMA_COST),
+                   "cost_hw_cycles_per_wave_instruction": COST_HW,
                    "simds": SIMDS, "clock_hz": CLK, "kernels": jout}, open(a.json, "w"), indent=1)
 
 
