@@ -108,6 +108,12 @@ bool mb4_geometry(int dtype, MbGeom& g, int Cin, int hid, int Cout, int k, int s
 void mb4_repack(int dtype, const MbGeom& g, int hid, int Cout, int k, const float* wd, const float* wp, float* wdw_host, void* wproj_host);
 hipError_t mb4_launch(hipStream_t s, int dtype, const MbParams& p);
 
+// cf_mbconv5.hip: expand + depthwise for the fp32-storage modes (MbGeom::kind = 8, split-bf16 tolerance mode): register-window
+// depthwise on an x-quad-cell tile, packed taps; y = depthwise output in NHWC or pixel-block order; MbGeom::HALF = hidden chunks
+// per workgroup.  Expand fragments as cf_mbconv.hip, taps [chunk][group of 4 channels][tap][4] (mb_pack_weights)
+MbGeom expdw_f32_geometry(int dtype, int Cin, int hid, int k, int s);
+hipError_t expdw_f32_launch(hipStream_t s, int dtype, const MbParams& p);
+
 // cf_mbconv3.hip: depthwise on the matrix cores (v_mfma_f32_4x4x4_16b_f16, Toeplitz operands), stride 1, bf16 storage.
 // MbGeom::kind 4 = expand + depthwise (project stays a GEMM launch)
 MbGeom expdw_mx_geometry(int dtype, int Cin, int hid, int k, int s);
@@ -299,7 +305,7 @@ hipError_t launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int
 // layout converters used by cf_get_heads and the per-op test entry points
 hipError_t launch_nchw_to_nhwc(hipStream_t s, int dtype, const float* src /*f32 NCHW*/, void* dst /*T NHWC*/,
                                int B, int C, int H, int W);
-hipError_t launch_blocked_to_nchw(hipStream_t s, const void* src /*bf16, pixel-block order*/, float* dst /*f32 NCHW*/, int B, int C, int H, int W);
+hipError_t launch_blocked_to_nchw(hipStream_t s, int dtype, const void* src /*pixel-block order*/, float* dst /*f32 NCHW*/, int B, int C, int H, int W);
 hipError_t launch_nhwc_to_nchw(hipStream_t s, int dtype, const void* src /*T NHWC*/, float* dst /*f32 NCHW*/,
                                int B, int C, int H, int W);
 

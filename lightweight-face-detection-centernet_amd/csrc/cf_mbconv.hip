@@ -48,6 +48,17 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
     if (g.kind == 4) { mx_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 5) { mx_fused_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 6) { mx_fused2_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
+    if (g.kind == 8) {                       // cf_mbconv5.hip: this file's expand fragments, taps as [chunk][group of 4 channels][tap][4]
+        MbGeom g0 = g; g0.kind = 0; g0.NBO = 0; g0.HALF = 0; g0.wproj_bytes = 0;
+        std::vector<float> generic(g.wdw_floats);
+        mb_pack_weights(dtype, g0, Cin, hid, Cout, k, we, wd, nullptr, wexp_host, generic.data(), nullptr);
+        for (int q = 0; q < g.nq; ++q)
+            for (int grp = 0; grp < g.HC / 4; ++grp)
+                for (int t = 0; t < k * k; ++t)
+                    for (int c = 0; c < 4; ++c)
+                        wdw_host[(((size_t)q * (g.HC / 4) + grp) * k * k + t) * 4 + c] = wd[(size_t)(q * g.HC + grp * 4 + c) * k * k + t];
+        return;
+    }
     if (g.kind == 7) {                       // cf_mbconv4.hip: this file's expand fragments, its own tap table and project fragments
         MbGeom g0 = g; g0.kind = 0;
         mb_pack_weights(dtype, g0, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host);      // (its project fragments are overwritten)
@@ -68,7 +79,7 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
     const int P = per16(dtype);
     const int NCx = Cin * (int)elem_size(dtype) / 16;
     __builtin_memset(wexp_host, 0, g.wexp_bytes);
-    __builtin_memset(wproj_host, 0, g.wproj_bytes);
+    if (wproj_host && g.wproj_bytes) __builtin_memset(wproj_host, 0, g.wproj_bytes);
     auto put = [&](char* dst, const float* src, int n) { (void)n; pack_chunk(dtype, src, dst); };      // n = P: one 16-byte chunk
     for (int q = 0; q < g.nq; ++q) {
         for (int nbl = 0; nbl < g.NBE; ++nbl)
@@ -106,7 +117,7 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
         split_pairs_inplace(wexp_host, (size_t)g.nq * g.NBE, g.JX);                             // expand: the JX chunks of a lane half
         // project: one chunk per MFMA set.  Pairing the k-steps here (two depthwise chunks + two weight fragments per n-block live
         // at once) cost layer4.1 its second wave per SIMD (0.331 -> 0.463 ms) and gained nothing on 3.x: measured, not kept
-        split_pairs_inplace(wproj_host, (size_t)g.NBO * g.nq * g.HALF, 1);
+        if (wproj_host) split_pairs_inplace(wproj_host, (size_t)g.NBO * g.nq * g.HALF, 1);
     }
 }
 
@@ -346,7 +357,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] = r[e] + v[e];
             }
-            st16((char*)p.y + (opix * p.Cout + ch) * sizeof(T), pack16<T>(v));
+            // yblock: pixel-block order [m / 32][Cout / P][m % 32][P] (the next block's expand+depthwise kernel reads it as operand fragments)
+            st16((char*)p.y + (p.yblock ? blk_off(opix, p.Cout / P, ch / P) : (opix * p.Cout + ch) * sizeof(T)), pack16<T>(v));
         }
     }
 }
@@ -496,6 +508,7 @@ hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p) {
     if (p.kind == 5) return dtype == 1 ? mx_fused_launch(s, p) : hipErrorInvalidValue;
     if (p.kind == 6) return dtype == 1 ? mx_fused2_launch(s, p) : hipErrorInvalidValue;
     if (p.kind == 7) return dtype != 1 ? mb4_launch(s, dtype, p) : hipErrorInvalidValue;
+    if (p.kind == 8) return expdw_f32_launch(s, dtype, p);
     const MbEntry* e = mb_find(dtype, p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
     if (!e || e->hc != p.HC) return hipErrorInvalidValue;
     return e->fn(s, p);

@@ -700,6 +700,7 @@ static const XdEntry* xd_find(int k, int s, int jx) {
 
 // geometry of the expand+depthwise kernel for a block (bf16 storage): MbGeom with kind = 2
 MbGeom expdw_geometry(int dtype, int Cin, int hid, int k, int s) {
+    if (dtype != 1) return expdw_f32_geometry(dtype, Cin, hid, k, s);   // fp32 storage: cf_mbconv5.hip (kind 8)
     MbGeom g = expdw_mx_geometry(dtype, Cin, hid, k, s);          // stride 1: depthwise on the matrix cores (cf_mbconv3.hip)
     if (g.ok) return g;
     static const bool off = cf_ab_int("CF_XD_KIND", 1) == 0;

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
             act_arr<ACT, P>(v);
             if constexpr (RES == 1) {
                 float r[P];
-                unpack16<T>(ld16((const char*)p.res + (p.resblock ? blk_off((size_t)m, p.N / 8, ch / 8) : ((size_t)m * p.N + ch) * sizeof(T))), r);
+                unpack16<T>(ld16((const char*)p.res + (p.resblock ? blk_off((size_t)m, p.N / P, ch / P) : ((size_t)m * p.N + ch) * sizeof(T))), r);
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] += r[e];
             } else if constexpr (RES == 2) {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
                     v[e] += relu_f(r[e] * p.upw[tap * p.N + ch + e] + p.upb[ch + e]);
             }
             const size_t ld = p.ldy ? (size_t)p.ldy : (size_t)p.N;
-            st16((char*)p.y + (p.yblock ? blk_off((size_t)m, p.N / 8, ch / 8) : ((size_t)m * ld + p.yoff + ch) * sizeof(T)), pack16<T>(v));
+            st16((char*)p.y + (p.yblock ? blk_off((size_t)m, p.N / P, ch / P) : ((size_t)m * ld + p.yoff + ch) * sizeof(T)), pack16<T>(v));
         }
     }
 }
@@ -305,11 +305,11 @@ __global__ __launch_bounds__(256) void pw_wlds_kernel(PwParams p) {
             act_arr<ACT, P>(v);
             if constexpr (RES == 1) {
                 float r[P];
-                unpack16<T>(ld16((const char*)p.res + (p.resblock ? blk_off((size_t)m, p.N / 8, ch / 8) : ((size_t)m * p.N + ch) * sizeof(T))), r);
+                unpack16<T>(ld16((const char*)p.res + (p.resblock ? blk_off((size_t)m, p.N / P, ch / P) : ((size_t)m * p.N + ch) * sizeof(T))), r);
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] += r[e];
             }
-            st16((char*)p.y + (p.yblock ? blk_off((size_t)m, p.N / 8, ch / 8) : ((size_t)m * p.N + ch) * sizeof(T)), pack16<T>(v));
+            st16((char*)p.y + (p.yblock ? blk_off((size_t)m, p.N / P, ch / P) : ((size_t)m * p.N + ch) * sizeof(T)), pack16<T>(v));
         }
     }
 }

@@ -142,7 +142,7 @@ void need(cf_ctx* c, int id, size_t elems) { if (c->bufs[id].elems < elems) c->b
 // readers can read it (expand+dw input, GEMM input, GEMM residual), the tensor is kept in block order instead.
 void layout_pass(cf_ctx* c) {
     static const bool off = cf_ab_int("CF_IN_XBLOCK", 1) == 0;      // A/B
-    if (off || c->dtype != CF_BF16) return;
+    if (off || c->dtype == CF_F32) return;                          // bf16, and (round 5) the split mode: cf_mbconv5.hip reads block order too
     auto& ops = c->ops;
     for (size_t i = 0; i < ops.size(); ++i) {
         if (ops[i].kind != OP_EXPDW || !ops[i].out_blk || ops[i].in_blk || (ops[i].Cin % 8)) continue;
@@ -152,7 +152,8 @@ void layout_pass(cf_ctx* c) {
         if (j < 0) continue;
         Op& pr = ops[j];
         const bool can_write = !pr.fused_away && pr.low < 0 &&
-                               ((pr.kind == OP_PW && pr.bnkey.empty()) || (pr.kind == OP_MB && (pr.geo.kind == 1 || pr.geo.kind == 5 || pr.geo.kind == 6)));
+                               ((pr.kind == OP_PW && pr.bnkey.empty()) || (pr.kind == OP_MB && (pr.geo.kind == 1 || pr.geo.kind == 5 || pr.geo.kind == 6)) ||
+                                (pr.kind == OP_MB && c->dtype != CF_BF16 && pr.geo.kind == 0));      // cf_mbconv.hip's fp32-tile kernel (layer3.1 in the split mode)
         if (!can_write) continue;
         bool ok = true;
         size_t end = j + 1;
@@ -222,6 +223,9 @@ void build_plan(cf_ctx* c) {
             // the depthwise output makes a round trip through HBM: 0.111 -> 0.095 ms and 0.166 -> 0.141 ms.  CF_SPLIT_WIDE=0: A/B.
             static const bool fuse_wide = cf_ab_int("CF_SPLIT_WIDE", 1) == 0;
             if (!fuse_wide && c->dtype == CF_BF16 && cout > 64 && geo.kind == 1) geo.ok = false;
+            // fp32-storage modes, round 5: the same split for Cout = 96 (layer4.x) wherever cf_mbconv5.hip has the shape -- the fused
+            // kernel's three accumulator blocks hold it to 8x16 tiles (1.9x halo recompute) and two waves per SIMD
+            if (!fuse_wide && c->dtype != CF_BF16 && cout > 64 && expdw_geometry(c->dtype, cin, hid, k, s).ok) geo.ok = false;
             if (t != 1 && geo.ok && !(c->flags & CF_FLAG_NO_FUSE)) {
                 // fused expand -> dw -> project (cf_mbconv.hip): one launch, expanded tensor stays in LDS
                 Op m; m.kind = OP_MB; m.name = std::string(pre) + ".mbconv"; m.in = cur; m.out = dst;
@@ -532,7 +536,7 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
     for (auto& b : c->bufs) {
         // + slack: kernels may over-read one 16-byte chunk; a tensor in pixel-block order is padded to whole 32-pixel blocks
         // (at most 31 pixels x 960 channels x 2 bytes)
-        size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256 + (b.f32 ? 0 : (size_t)32 * 960 * 2);
+        size_t bytes = b.elems * (size_t)max_batch * (b.f32 ? 4 : elem_size(dtype)) + 256 + (b.f32 ? 0 : (size_t)32 * 960 * elem_size(dtype));
         if ((e = hipMalloc(&b.p, bytes)) != hipSuccess) return bail(e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP, "hipMalloc(activations)", e);
         // zero-initialised incl. the slack: kernels may over-read (never write) one 16-byte chunk
         if ((e = hipMemsetAsync(b.p, 0, bytes, c->stream)) != hipSuccess) return bail(CF_EHIP, "hipMemset(activations)", e);
@@ -1474,7 +1478,7 @@ int cf_forward_trace(cf_ctx* c, const void* in, int in_format, int in_on_device,
     float* tmp = nullptr;
     HIPCHK(c, hipMalloc((void**)&tmp, n * sizeof(float)));
     hipError_t e = op.out_blk
-        ? launch_blocked_to_nchw(c->stream, c->bufs[op.out].p, tmp, B, C, op.Hout, op.Wout)
+        ? launch_blocked_to_nchw(c->stream, c->dtype, c->bufs[op.out].p, tmp, B, C, op.Hout, op.Wout)
         : launch_nhwc_to_nchw(c->stream, head ? CF_F32 : c->dtype, c->bufs[op.out].p, tmp, B, C, op.Hout, op.Wout);
     if (e == hipSuccess) e = hipMemcpyAsync(out_nchw, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

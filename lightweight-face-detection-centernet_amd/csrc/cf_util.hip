@@ -97,15 +97,19 @@ __global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int B, int C, int 
         else dst[i] = bf16_to_f32(v);
     }
 }
-// pixel-block order [m / 32][C / 8][m % 32][8] (bf16), m = (b H + y) W + x  ->  NCHW float32
-__global__ void blocked_to_nchw_kernel(const bf16_t* src, float* dst, int B, int C, int H, int W) {
+// pixel-block order [m / 32][C / P][m % 32][P] (P = channels per 16 bytes: 8 bf16 / 4 fp32), m = (b H + y) W + x  ->  NCHW float32
+template <typename T>
+__global__ void blocked_to_nchw_kernel(const T* src, float* dst, int B, int C, int H, int W) {
+    constexpr int P = 16 / (int)sizeof(T);
     const long long n = (long long)B * C * H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         int x = (int)(i % W); long long t = i / W;
         int y = (int)(t % H); t /= H;
         int c = (int)(t % C); int b = (int)(t / C);
         const size_t m = ((size_t)b * H + y) * W + x;
-        dst[i] = bf16_to_f32(src[(((m >> 5) * (size_t)(C / 8) + (size_t)(c / 8)) * 32 + (m & 31)) * 8 + (c & 7)]);
+        const T v = src[(((m >> 5) * (size_t)(C / P) + (size_t)(c / P)) * 32 + (m & 31)) * P + (c % P)];
+        if constexpr (sizeof(T) == 4) dst[i] = v;
+        else dst[i] = bf16_to_f32(v);
     }
 }
 static unsigned conv_grid(long long n) { long long g = (n + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
@@ -117,10 +121,11 @@ hipError_t launch_nchw_to_nhwc(hipStream_t s, int dtype, const float* src, void*
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(conv_grid(n)), dim3(256), 0, s, src, (bf16_t*)dst, B, C, H, W);
     return hipGetLastError();
 }
-hipError_t launch_blocked_to_nchw(hipStream_t s, const void* src, float* dst, int B, int C, int H, int W) {
+hipError_t launch_blocked_to_nchw(hipStream_t s, int dtype, const void* src, float* dst, int B, int C, int H, int W) {
     long long n = (long long)B * C * H * W;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(blocked_to_nchw_kernel, dim3(conv_grid(n)), dim3(256), 0, s, (const bf16_t*)src, dst, B, C, H, W);
+    if (dtype != 1) hipLaunchKernelGGL(blocked_to_nchw_kernel<float>, dim3(conv_grid(n)), dim3(256), 0, s, (const float*)src, dst, B, C, H, W);
+    else hipLaunchKernelGGL(blocked_to_nchw_kernel<bf16_t>, dim3(conv_grid(n)), dim3(256), 0, s, (const bf16_t*)src, dst, B, C, H, W);
     return hipGetLastError();
 }
 hipError_t launch_nhwc_to_nchw(hipStream_t s, int dtype, const void* src, float* dst, int B, int C, int H, int W) {

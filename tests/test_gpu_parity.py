@@ -855,6 +855,29 @@ def test_expand_dw_kernel_vs_oracle(cfg):
         ops.expand_dw(x, we, wd, k, s, dtype="fp32")           # bf16-only kernel: loud, no fallback
 
 
+@pytest.mark.parametrize("cfg", [(64, 5, 1, 40, 40), (96, 5, 1, 40, 40), (96, 5, 1, 17, 45), (96, 5, 2, 40, 40), (96, 5, 2, 23, 31),
+                                 (160, 5, 1, 20, 20), (160, 5, 1, 13, 27), (160, 3, 1, 20, 20), (160, 3, 1, 9, 41)])
+def test_expand_dw_f32_kernel_vs_oracle(cfg):
+    """The round-5 expand+depthwise kernel of the tolerance mode (cf_mbconv5.hip: fp32 storage, split-bf16 expand products, register-
+    window depthwise on an x-quad-cell tile, packed taps) on every production shape (layer4.0 ... 6.0) and on map sizes that are
+    not a multiple of the tile or of a strip of four (edge tiles, partly filled strip groups, stride-2 even / odd halves), batch
+    > 1: against the oracle's fp32 expand -> Swish -> depthwise -> Swish at the per-op tolerance of the mode (1e-4 of the output
+    scale).  The exact-fp32 mode keeps its round-4 kernels: asking for it here is an error, not a fallback."""
+    cin, k, s, H, W = cfg
+    rng = np.random.default_rng(cin + 10 * k + s + H)
+    hid = cin * 6
+    we = (rng.standard_normal((hid, cin, 1, 1)) * 1.5 / np.sqrt(cin)).astype(np.float32)
+    wd = (rng.standard_normal((hid, 1, k, k)) * 1.5 / k).astype(np.float32)
+    x = rng.standard_normal((3, cin, H, W)).astype(np.float32)
+    ref = O.conv_swish(O.conv_swish(torch.from_numpy(x), torch.from_numpy(we), 1, 1), torch.from_numpy(wd), k, s, groups=hid).numpy()
+    y = ops.expand_dw(x, we, wd, k, s, dtype="fp32_split")
+    assert y.shape == ref.shape
+    scale = float(np.sqrt((ref ** 2).mean()))
+    np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4 * max(1.0, scale), err_msg=str(cfg))
+    with pytest.raises(ValueError):
+        ops.expand_dw(x, we, wd, k, s, dtype="fp32")
+
+
 # (bf16 engine on sizes that are not multiples of any tile / smaller than a tile: tests/test_bf16_parity.py,
 #  layer by layer against the emulating oracle -- it replaced the bf16-vs-fp32-engine noise-floor tests that stood here)
 

@@ -23,6 +23,12 @@
 #define RCP(a) asm volatile("v_rcp_f32 %0, %0" : "+v"(a))
 #define PKFMA(p) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p) : "v"(pm), "v"(pc))
 #define PKMUL(p) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p) : "v"(pm))
+#define PKFMAS(p) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p) : "v"(pc), "s"(sp))       // taps as an SGPR pair
+#define PKFMAS1(p) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p) : "v"(pc), "s"(sp))   // ... one SGPR broadcast to both halves
+#define DOT2CV(a) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a) : "v"(hv), "v"(hw))        // VOP2, both operands VGPR
+#define DOT2CS(a) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a) : "s"(hs), "v"(hw))        // VOP2, taps in an SGPR (the bf16 kernels' form)
+#define DOT2V(a) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a) : "v"(hv), "v"(hw))      // VOP3P
+#define FMACD(a, b) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b), "v"(m))   // neighbour lane's value as src0
 #define X8(OP) OP(a0); OP(a1); OP(a2); OP(a3); OP(a4); OP(a5); OP(a6); OP(a7);
 #define Y8(OP) OP(b0); OP(b1); OP(b2); OP(b3); OP(b4); OP(b5); OP(b6); OP(b7);
 #define Z8(OP) OP(c0); OP(c1); OP(c2); OP(c3); OP(c4); OP(c5); OP(c6); OP(c7);
@@ -45,6 +51,12 @@ __global__ void k(float* out, Stamp* st, int iters, float ms) {
     float m = 0.9999f + threadIdx.x * 1e-9f, c = 1e-4f;
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {b0, b1}, p5 = {b2, b3}, p6 = {b4, b5}, p7 = {b6, b7};
     f2 pm = {m, m}, pc = {c, c};
+    typedef __attribute__((ext_vector_type(2))) float sf2;
+    unsigned long long sp;
+    { float lo = ms, hi = ms * 0.5f; unsigned long long t = ((unsigned long long)__float_as_uint(hi) << 32) | __float_as_uint(lo);
+      sp = __builtin_amdgcn_readfirstlane((unsigned)t) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(t >> 32)) << 32); }
+    unsigned hv = 0x3c003800u + (threadIdx.x & 3), hw = 0x38003c00u + (threadIdx.x & 1);
+    const unsigned hs = __builtin_amdgcn_readfirstlane(0x3c003a00u + (unsigned)(ms * 4.0f));
     unsigned long long t0, t1, r0, r1;
     asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0));
     // the body is repeated eight times by hand: one loop branch (s_add / s_cmp / s_cbranch) per 64+ instructions
@@ -63,6 +75,12 @@ __global__ void k(float* out, Stamp* st, int iters, float ms) {
         else if (MODE == 10) { X8(EXP) Y8(FMA) Z8(FMA) }          // same multiset as 8, blocked instead of interleaved
         else if (MODE == 11) { X8(MUL) }
         else if (MODE == 12) { PKMUL(p0); PKMUL(p1); PKMUL(p2); PKMUL(p3); PKMUL(p4); PKMUL(p5); PKMUL(p6); PKMUL(p7); }
+        else if (MODE == 15) { PKFMAS(p0); PKFMAS(p1); PKFMAS(p2); PKFMAS(p3); PKFMAS(p4); PKFMAS(p5); PKFMAS(p6); PKFMAS(p7); }
+        else if (MODE == 16) { PKFMAS1(p0); PKFMAS1(p1); PKFMAS1(p2); PKFMAS1(p3); PKFMAS1(p4); PKFMAS1(p5); PKFMAS1(p6); PKFMAS1(p7); }
+        else if (MODE == 17) { FMACD(a0, b0); FMACD(a1, b1); FMACD(a2, b2); FMACD(a3, b3); FMACD(a4, b4); FMACD(a5, b5); FMACD(a6, b6); FMACD(a7, b7); }
+        else if (MODE == 18) { X8(DOT2CV) }
+        else if (MODE == 19) { X8(DOT2CS) }
+        else if (MODE == 20) { X8(DOT2V) }
         else if (MODE == 13) { X8(EXP) X8(RCP) Y8(FMA) Z8(FMA) W8(FMA) }     // a Swish-like group, blocked: 16 transcendentals, 24 plain
         else if (MODE == 14) { I1(EXP, FMA) I2(RCP, FMA) }                      // ... the same multiset with every transcendental between plain ops
     ) }
@@ -106,7 +124,8 @@ int main() {
     (void)hipMalloc(&g_out, 2048 * 256 * 4); (void)hipMalloc(&g_st, 2048 * 4 * sizeof(Stamp));
     for (int w : {8, 4, 2, 1}) {
         if (w == 8) { run<0>("v_fma_f32 vop3 vgpr", 8, 8); run<1>("v_fmac_f32 vop2 vgpr", 8, 8); run<2>("v_fma_f32 vop3 sgpr", 8, 8); run<3>("v_fmac_f32 vop2 sgpr", 8, 8);
-                      run<11>("v_mul_f32", 8, 8); run<6>("v_pk_fma_f32", 8, 8); run<12>("v_pk_mul_f32", 8, 8); run<4>("v_exp_f32", 8, 8); run<5>("v_rcp_f32", 8, 8);
+                      run<11>("v_mul_f32", 8, 8); run<6>("v_pk_fma_f32", 8, 8); run<15>("v_pk_fma_f32 sgpr pair", 8, 8); run<16>("v_pk_fma_f32 one sgpr, op_sel", 8, 8); run<17>("v_fmac_f32_dpp row_shl:1", 8, 8);
+                      run<18>("v_dot2c_f32_f16 vop2 vgpr", 8, 8); run<19>("v_dot2c_f32_f16 vop2 sgpr", 8, 8); run<20>("v_dot2_f32_f16 vop3p vgpr", 8, 8); run<12>("v_pk_mul_f32", 8, 8); run<4>("v_exp_f32", 8, 8); run<5>("v_rcp_f32", 8, 8);
                       run<7>("8 exp + 8 fma interleaved", 16, 8); run<8>("8 exp + 16 fma interleaved", 24, 8); run<9>("8 exp + 24 fma interleaved", 32, 8);
                       run<10>("8 exp + 16 fma blocked", 24, 8); run<13>("8 exp 8 rcp 24 fma blocked", 40, 8); run<14>("8 exp 8 rcp 24 fma interleaved", 40, 8); }
         if (w == 4) { run<0>("v_fma_f32 vop3 vgpr", 8, 4); run<4>("v_exp_f32", 8, 4); run<8>("8 exp + 16 fma interleaved", 24, 4); run<10>("8 exp + 16 fma blocked", 24, 4); }
