@@ -114,6 +114,13 @@ hipError_t mb4_launch(hipStream_t s, int dtype, const MbParams& p);
 MbGeom expdw_f32_geometry(int dtype, int Cin, int hid, int k, int s);
 hipError_t expdw_f32_launch(hipStream_t s, int dtype, const MbParams& p);
 
+// cf_mbconv6.hip: the split mode's fused block for Cout <= 32 (MbGeom::kind = 9): cf_mbconv5.hip's register-window depthwise + project
+// MFMAs from an LDS tile of the depthwise output
+bool mb6_geometry(int dtype, MbGeom& g, int Cin, int hid, int Cout, int k, int s);
+void mb6_pack(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+              void* wexp_host, float* wdw_host, void* wproj_host);
+hipError_t mb6_launch(hipStream_t s, const MbParams& p);
+
 // cf_mbconv3.hip: depthwise on the matrix cores (v_mfma_f32_4x4x4_16b_f16, Toeplitz operands), stride 1, bf16 storage.
 // MbGeom::kind 4 = expand + depthwise (project stays a GEMM launch)
 MbGeom expdw_mx_geometry(int dtype, int Cin, int hid, int k, int s);

@@ -54,8 +54,12 @@ struct X5 {
     static_assert(HC % 8 == 0 && NW <= NIB, "hidden chunk / wave geometry");
 };
 
-template <int KS, int S, int HC, int TOH, int TOW, int JX, int NW, bool PIPE, bool SP>
-__global__ __launch_bounds__(NW * 64, 4) void expdw_f32_kernel(MbParams p) {      // four waves per SIMD: two 8-wave workgroups per CU
+// RES: the X fragments of the wave's blocks stay in registers for all chunks, ALREADY SPLIT into bf16 (hi, lo) pairs in the split mode
+// (re-read and re-split per chunk otherwise: 144 of the ~250 VALU instructions of a block at Cin = 96); costs the second workgroup
+// per CU (256-register budget instead of 128)
+// MW: waves per SIMD the register budget is set for (4: 128 registers, two 8-wave workgroups per CU; 2: 256 registers)
+template <int KS, int S, int HC, int TOH, int TOW, int JX, int NW, bool PIPE, bool SP, bool RES = false, int MW = 4>
+__global__ __launch_bounds__(NW * 64, MW) void expdw_f32_kernel(MbParams p) {
     typedef typename std::conditional<SP, sp32_t, float>::type MT;
     typedef X5<KS, S, HC, TOH, TOW, JX, NW> G;
     constexpr int IW = G::IW, IWQ = G::IWQ, HWQ = G::HWQ, IPX = G::IPX, NIB = G::NIB, MAXI = G::MAXI, NG = G::NG, NBE = G::NBE;
@@ -158,8 +162,32 @@ __global__ __launch_bounds__(NW * 64, 4) void expdw_f32_kernel(MbParams p) {    
     // X fragments: ONE buffer of JP chunks, refilled with the next pass's / next block's loads as soon as the MFMA chain has consumed
     // it -- the loads are in flight under the Swish / store half of the block
     u32x4 xf[JP];
-    block_addr(wave);
-    load_pass(0, xf);
+    u32x4 xs[RES ? MAXI : 1][RES ? JX : 1];
+    bool xsv[RES ? MAXI : 1];
+    if constexpr (RES) {
+        static_assert(JX % 2 == 0 && JP % 2 == 0, "resident fragments are kept as chunk pairs");
+#pragma unroll
+        for (int t = 0; t < MAXI; ++t) {
+            const int ib = wave + NW * t;
+            xsv[t] = false;
+            if (ib < NIB) {
+                block_addr(ib);
+                xsv[t] = xvalid;
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    load_pass(pass, xf);
+#pragma unroll
+                    for (int j = 0; j < JP; j += 2) {
+                        if constexpr (SP) { const SplitPair sp2 = split8(xf[j], xf[j + 1]); xs[t][pass * JP + j] = sp2.hi; xs[t][pass * JP + j + 1] = sp2.lo; }
+                        else { xs[t][pass * JP + j] = xf[j]; xs[t][pass * JP + j + 1] = xf[j + 1]; }
+                    }
+                }
+            }
+        }
+    } else {
+        block_addr(wave);
+        load_pass(0, xf);
+    }
 
     const int NC = p.hid / 4;                                                    // 16-byte chunks of a depthwise-output pixel
 #ifdef CF_X5_TIMING      // phase stamps (s_memtime), summed over the chunks of a wave: tools/x5_timing.py
@@ -191,6 +219,25 @@ __global__ __launch_bounds__(NW * 64, 4) void expdw_f32_kernel(MbParams p) {    
             for (int nbl = 0; nbl < NBE; ++nbl)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[nbl][r] = 0.0f;
+            if constexpr (RES) {
+#pragma unroll
+                for (int nbl = 0; nbl < NBE; ++nbl) {
+                    const char* wb = wx + (nbl * JX * 64 + lane) * 16;
+                    if constexpr (SP) {
+#pragma unroll
+                        for (int j = 0; j < JX; j += 2) {
+                            const u32x4 whi = ld16(wb + j * 1024), wlo = ld16(wb + (j + 1) * 1024);
+                            a[nbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, wlo), __builtin_bit_cast(cf_bf16x8, xs[t][j]), a[nbl], 0, 0, 0);
+                            a[nbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, whi), __builtin_bit_cast(cf_bf16x8, xs[t][j + 1]), a[nbl], 0, 0, 0);
+                            a[nbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, whi), __builtin_bit_cast(cf_bf16x8, xs[t][j]), a[nbl], 0, 0, 0);
+                        }
+                    } else {
+                        mma_chain<MT, JX>(a[nbl], [&](int j) { return ld16(wb + j * 1024); }, [&](int j) { return xs[t][j]; });
+                    }
+                }
+                expand_store(ib, a, xsv[t]);
+                continue;
+            }
             const bool vcur = xvalid;
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
@@ -285,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, 4) void expdw_f32_kernel(MbParams p) {    
             }
         }
         X5_STAMP(3)
-        if (q + 1 < q1) { block_addr(wave); load_pass(0, xf); }   // in flight across the barrier at the top of the next chunk
+        if constexpr (!RES) { if (q + 1 < q1) { block_addr(wave); load_pass(0, xf); } }   // in flight across the barrier at the top of the next chunk
     }
 #ifdef CF_X5_TIMING
     if (p.wproj && lane == 0) {
@@ -297,15 +344,15 @@ __global__ __launch_bounds__(NW * 64, 4) void expdw_f32_kernel(MbParams p) {    
 
 // ---------------------------------------------------------------- host side
 struct X5Entry {
-    int k, s, jx, hc, toh, tow, qpw;     // qpw: hidden chunks per workgroup
+    int var, k, s, jx, hc, toh, tow, qpw;     // var: CF_X5_VARIANT (experiments build); qpw: hidden chunks per workgroup
     int lds_bytes;
     hipError_t (*fn)(hipStream_t, const MbParams&);
     hipError_t (*fn_sp)(hipStream_t, const MbParams&);
 };
-template <int KS, int S, int HC, int TOH, int TOW, int JX, int NW, bool PIPE, bool SP>
+template <int KS, int S, int HC, int TOH, int TOW, int JX, int NW, bool PIPE, bool SP, bool RES, int MW>
 static hipError_t x5_launch_t(hipStream_t s, const MbParams& p) {
     typedef X5<KS, S, HC, TOH, TOW, JX, NW> G;
-    auto kfn = expdw_f32_kernel<KS, S, HC, TOH, TOW, JX, NW, PIPE, SP>;
+    auto kfn = expdw_f32_kernel<KS, S, HC, TOH, TOW, JX, NW, PIPE, SP, RES, MW>;
     static thread_local bool configured_dev[32] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     bool& configured = configured_dev[dev & 31];
@@ -316,27 +363,87 @@ static hipError_t x5_launch_t(hipStream_t s, const MbParams& p) {
     }
     const int ntx = (p.Wout + TOW - 1) / TOW, nty = (p.Hout + TOH - 1) / TOH;
     dim3 grid(ntx * nty, (p.nq + p.HALF - 1) / p.HALF, p.B), blk(NW * 64);
-    set_kernel_tag("void cf::expdw_f32_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %s>(cf::MbParams)", KS, S, HC, TOH, TOW, JX, NW, PIPE ? "true" : "false", SP ? "true" : "false");
+    set_kernel_tag("void cf::expdw_f32_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %s, %s, %d>(cf::MbParams)", KS, S, HC, TOH, TOW, JX, NW, PIPE ? "true" : "false", SP ? "true" : "false",
+                   RES ? "true" : "false", MW);
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
     return hipGetLastError();
 }
-#define X5E(KS, S, JX, HC, TOH, TOW, NW, PIPE, QPW) \
-    {KS, S, JX, HC, TOH, TOW, QPW, X5<KS, S, HC, TOH, TOW, JX, NW>::LDS, &x5_launch_t<KS, S, HC, TOH, TOW, JX, NW, (PIPE != 0), false>, &x5_launch_t<KS, S, HC, TOH, TOW, JX, NW, (PIPE != 0), true>}
+#define X5M(V, KS, S, JX, HC, TOH, TOW, NW, PIPE, RES, MW, QPW) \
+    {V, KS, S, JX, HC, TOH, TOW, QPW, X5<KS, S, HC, TOH, TOW, JX, NW>::LDS, &x5_launch_t<KS, S, HC, TOH, TOW, JX, NW, (PIPE != 0), false, (RES != 0), MW>, \
+     &x5_launch_t<KS, S, HC, TOH, TOW, JX, NW, (PIPE != 0), true, (RES != 0), MW>}
+#define X5E(V, KS, S, JX, HC, TOH, TOW, NW, PIPE, RES, QPW) X5M(V, KS, S, JX, HC, TOH, TOW, NW, PIPE, RES, ((RES) ? 2 : 4), QPW)
 static const X5Entry kX5Table[] = {
     // 10x20 tiles (E = 38-44 KB, two 8-wave workgroups per CU); round-5 sweep: profiles/r05_expdw_f32.md
-    //  KS S JX  HC  tile    waves row-pipe chunks/workgroup
-    X5E(5, 1, 8, 32, 10, 20, 8, 0, 4),      // 4.0   64 -> 384, 40x40
-    X5E(5, 1, 12, 32, 10, 20, 8, 0, 6),     // 4.1   96 -> 576, 40x40
-    X5E(5, 2, 12, 16, 5, 20, 8, 0, 12),     // 5.0   96 -> 576, 40x40 -> 20x20
-    X5E(5, 1, 20, 32, 10, 20, 8, 0, 10),    // 5.1  160 -> 960, 20x20
-    X5E(3, 1, 20, 32, 10, 20, 8, 1, 10),    // 6.0  160 -> 960, 20x20
+    // Sweep of the round (gpurun_out/r05j/x5_variants*.txt -> profiles/r05_split_restructure.md; B = 64, 640x640, ms, one box;
+    // rows: the default of every block, CF_X5_VARIANT = 1 ... 6):
+    //            4.0     4.1     5.0     5.1     6.0
+    //   two workgroups per CU, 10x20 tiles, X re-read and re-split per chunk              0.116   0.198   0.205   0.135   0.119
+    //   1: the same tiles, X fragments resident and pre-split, one workgroup per CU       0.134   0.208   0.219   0.141   0.104
+    //   2: 10x40 / 20x20 tiles, resident, every chunk in one workgroup                    0.110   0.176   0.135   0.348   0.252
+    //   3: as 1 with every chunk in one workgroup                                         0.127   0.199   0.204   0.179   0.135
+    //   4: hidden chunks of 64, re-read X                                                 0.125   0.211   0.161   0.195   0.167
+    //   5 / 6: big tiles, re-read X, 18 / 6 chunks per workgroup                          0.126 / 0.122   0.213 / 0.205   0.162 / 0.150   0.306 / 0.143   0.259 / 0.125
+    // Resident, pre-split X fragments win wherever they fit without spills (4.x on 10x40 tiles, 6.0), layer5.0 wants hidden chunks of
+    // 32 on one workgroup per CU (its stride-2 tile is 82 KB), layer5.1 (Cin = 160: 80 fragment registers per block) keeps the re-read.
+    // var KS S JX  HC  tile    waves row-pipe resident-X chunks/workgroup
+    X5E(0, 5, 1, 8, 32, 10, 40, 8, 1, 1, 12),     // 4.0   64 -> 384, 40x40
+    X5E(0, 5, 1, 12, 32, 10, 40, 8, 0, 1, 18),    // 4.1   96 -> 576, 40x40
+    X5E(0, 5, 2, 12, 32, 5, 20, 8, 0, 1, 18),     // 5.0   96 -> 576, 40x40 -> 20x20
+    X5E(0, 5, 1, 20, 32, 10, 20, 8, 0, 0, 10),    // 5.1  160 -> 960, 20x20
+    X5E(0, 3, 1, 20, 32, 10, 20, 8, 1, 1, 10),    // 6.0  160 -> 960, 20x20
+#ifdef CF_EXPERIMENTS
+    X5E(7, 5, 1, 8, 32, 10, 20, 8, 0, 0, 4),      // 7: two workgroups per CU, 10x20 tiles, X re-read (the first table row above)
+    X5E(7, 5, 1, 12, 32, 10, 20, 8, 0, 0, 6),
+    X5E(7, 5, 2, 12, 16, 5, 20, 8, 0, 0, 12),
+    X5E(7, 3, 1, 20, 32, 10, 20, 8, 1, 0, 10),
+    // resident, pre-split X fragments, one workgroup per CU; the same on 10x40 tiles (40x40 maps) and with every chunk in one workgroup
+    X5E(1, 5, 1, 8, 32, 10, 20, 8, 1, 1, 4),
+    X5E(1, 5, 1, 12, 32, 10, 20, 8, 1, 1, 6),
+    X5E(1, 5, 2, 12, 16, 5, 20, 8, 1, 1, 12),
+    X5E(1, 5, 1, 20, 32, 10, 20, 8, 1, 1, 10),
+    X5E(1, 3, 1, 20, 32, 10, 20, 8, 1, 1, 10),
+    X5E(2, 5, 1, 8, 32, 10, 40, 8, 1, 1, 12),
+    X5E(2, 5, 1, 12, 32, 10, 40, 8, 1, 1, 18),
+    X5E(2, 5, 2, 12, 32, 5, 20, 8, 1, 1, 18),
+    X5E(2, 5, 1, 20, 32, 20, 20, 8, 1, 1, 30),
+    X5E(2, 3, 1, 20, 32, 20, 20, 8, 1, 1, 30),
+    X5E(3, 5, 1, 8, 32, 10, 20, 8, 1, 1, 12),
+    X5E(3, 5, 1, 12, 32, 10, 20, 8, 1, 1, 18),
+    X5E(3, 5, 2, 12, 16, 5, 20, 8, 1, 1, 36),
+    X5E(3, 5, 1, 20, 32, 10, 20, 8, 1, 1, 30),
+    X5E(3, 3, 1, 20, 32, 10, 20, 8, 1, 1, 30),
+    // hidden chunks of 64 (the X load / split of a block serves two MFMA blocks), re-read X, 256-register budget, row pipeline
+    X5M(4, 5, 1, 8, 64, 10, 20, 8, 1, 0, 2, 6),
+    X5M(4, 5, 1, 12, 64, 10, 20, 8, 1, 0, 2, 9),
+    X5M(4, 5, 2, 12, 32, 5, 20, 8, 1, 0, 2, 18),
+    X5M(4, 5, 1, 20, 64, 10, 20, 8, 1, 0, 2, 15),
+    X5M(4, 3, 1, 20, 64, 10, 20, 8, 1, 0, 2, 15),
+    // big tiles, chunks of 32, re-read X, 256-register budget, row pipeline
+    X5M(5, 5, 1, 8, 32, 10, 40, 8, 1, 0, 2, 12),
+    X5M(5, 5, 1, 12, 32, 10, 40, 8, 1, 0, 2, 18),
+    X5M(5, 5, 2, 12, 32, 5, 20, 8, 1, 0, 2, 9),
+    X5M(5, 5, 1, 20, 32, 20, 20, 8, 1, 0, 2, 30),
+    X5M(5, 3, 1, 20, 32, 20, 20, 8, 1, 0, 2, 30),
+    // the same with fewer chunks per workgroup (more workgroups)
+    X5M(6, 5, 1, 8, 32, 10, 40, 8, 1, 0, 2, 4),
+    X5M(6, 5, 1, 12, 32, 10, 40, 8, 1, 0, 2, 6),
+    X5M(6, 5, 2, 12, 32, 5, 20, 8, 1, 0, 2, 6),
+    X5M(6, 5, 1, 20, 32, 20, 20, 8, 1, 0, 2, 10),
+    X5M(6, 3, 1, 20, 32, 20, 20, 8, 1, 0, 2, 10),
+#endif
 };
 #undef X5E
+#undef X5M
 
 static const X5Entry* x5_find(int k, int s, int jx) {
+    static const int want = cf_ab_int("CF_X5_VARIANT", 0);
+    const X5Entry* base = nullptr;
     for (const X5Entry& e : kX5Table)
-        if (e.k == k && e.s == s && e.jx == jx) return &e;
-    return nullptr;
+        if (e.k == k && e.s == s && e.jx == jx) {
+            if (e.var == want) return &e;
+            if (e.var == 0) base = &e;
+        }
+    return base;
 }
 
 // geometry of the fp32-storage expand+depthwise kernel for a block: MbGeom with kind = 8 (HALF = hidden chunks per workgroup)
