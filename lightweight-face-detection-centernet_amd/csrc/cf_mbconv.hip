@@ -209,6 +209,13 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
             xf[t][j].x = valid ? v.x : 0u; xf[t][j].y = valid ? v.y : 0u;
             xf[t][j].z = valid ? v.z : 0u; xf[t][j].w = valid ? v.w : 0u;
         }
+        // split mode (round 5): split into bf16 (hi, lo) ONCE, here, not once per hidden chunk inside the MFMA chain (a chunk pair ->
+        // [8 x hi], [8 x lo]; an odd last chunk -> [4 x hi | 4 x lo]): the same products in the same order
+        if constexpr (std::is_same<T, sp32_t>::value) {
+#pragma unroll
+            for (int j = 0; j + 1 < JX; j += 2) { const SplitPair s2 = split8(xf[t][j], xf[t][j + 1]); xf[t][j] = s2.hi; xf[t][j + 1] = s2.lo; }
+            if constexpr (JX & 1) { u32x2 xh, xl; split4(xf[t][JX - 1], xh, xl); xf[t][JX - 1].x = xh.x; xf[t][JX - 1].y = xh.y; xf[t][JX - 1].z = xl.x; xf[t][JX - 1].w = xl.y; }
+        }
     }
 
     auto expand_block = [&](int ib, const u32x4* xfr, const char* wx) {
@@ -221,6 +228,19 @@ __global__ __launch_bounds__(NW * 64) void mbconv_kernel(MbParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = 0.0f;
             const char* wb = wx + (nbl * JX * 64 + lane) * 16;
+            if constexpr (std::is_same<T, sp32_t>::value) {     // fragments already split (above)
+#pragma unroll
+                for (int j = 0; j + 1 < JX; j += 2) {
+                    const u32x4 whi = ld16(wb + j * 1024), wlo = ld16(wb + (j + 1) * 1024);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, wlo), __builtin_bit_cast(cf_bf16x8, xfr[j]), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, whi), __builtin_bit_cast(cf_bf16x8, xfr[j + 1]), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, whi), __builtin_bit_cast(cf_bf16x8, xfr[j]), a, 0, 0, 0);
+                }
+                if constexpr (JX & 1) {
+                    u32x2 xh, xl; xh.x = xfr[JX - 1].x; xh.y = xfr[JX - 1].y; xl.x = xfr[JX - 1].z; xl.y = xfr[JX - 1].w;
+                    mma_split_parts(a, ld16(wb + (JX - 1) * 1024), xh, xl);
+                }
+            } else
             mma_chain<T, JX>(a, [&](int j) { return ld16(wb + j * 1024); }, [&](int j) { return xfr[j]; });
             constexpr bool PARTIAL = (HC % 32 == 16);
             if (PARTIAL && nbl == NBE - 1) {

@@ -51,7 +51,7 @@ struct X5 {
     // cells of a strip's window per kernel row
     static constexpr int NE = S == 1 ? 4 + KS - 1 : 4 + (KS - 1) / 2;      // consecutive (stride 1) / even columns
     static constexpr int NO = S == 1 ? 0 : 4 + (KS - 3) / 2;               // odd columns
-    static_assert(HC % 8 == 0 && NW <= NIB, "hidden chunk / wave geometry");
+    static_assert(HC % 8 == 0, "hidden chunk geometry");
 };
 
 // RES: the X fragments of the wave's blocks stay in registers for all chunks, ALREADY SPLIT into bf16 (hi, lo) pairs in the split mode
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(NW * 64, MW) void expdw_f32_kernel(MbParams p) {
     constexpr int IW = G::IW, IWQ = G::IWQ, HWQ = G::HWQ, IPX = G::IPX, NIB = G::NIB, MAXI = G::MAXI, NG = G::NG, NBE = G::NBE;
     constexpr int QSTRIDE = G::QSTRIDE, WXB = G::WXB, TAPB = G::TAPB, SPR = G::SPR, NSTRIP = G::NSTRIP, NSG = G::NSG, UNITS = G::UNITS;
     constexpr bool PART = G::PART;
+    static_assert(RES || NW <= NIB, "re-read mode: every wave owns a first block");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* E = smem;
     char* Wst = smem + G::EBYTES;
@@ -384,14 +385,19 @@ static const X5Entry kX5Table[] = {
     //   4: hidden chunks of 64, re-read X                                                 0.125   0.211   0.161   0.195   0.167
     //   5 / 6: big tiles, re-read X, 18 / 6 chunks per workgroup                          0.126 / 0.122   0.213 / 0.205   0.162 / 0.150   0.306 / 0.143   0.259 / 0.125
     // Resident, pre-split X fragments win wherever they fit without spills (4.x on 10x40 tiles, 6.0), layer5.0 wants hidden chunks of
-    // 32 on one workgroup per CU (its stride-2 tile is 82 KB), layer5.1 (Cin = 160: 80 fragment registers per block) keeps the re-read.
+    // 32 on one workgroup per CU (its stride-2 tile is 82 KB), layer5.1 (Cin = 160: 80 fragment registers per block) fits them with
+    // twelve waves per workgroup (one halo block per wave).
     // var KS S JX  HC  tile    waves row-pipe resident-X chunks/workgroup
     X5E(0, 5, 1, 8, 32, 10, 40, 8, 1, 1, 12),     // 4.0   64 -> 384, 40x40
     X5E(0, 5, 1, 12, 32, 10, 40, 8, 0, 1, 18),    // 4.1   96 -> 576, 40x40
     X5E(0, 5, 2, 12, 32, 5, 20, 8, 0, 1, 18),     // 5.0   96 -> 576, 40x40 -> 20x20
-    X5E(0, 5, 1, 20, 32, 10, 20, 8, 0, 0, 10),    // 5.1  160 -> 960, 20x20
+    X5M(0, 5, 1, 20, 32, 10, 20, 12, 0, 1, 3, 10), // 5.1  160 -> 960, 20x20: twelve waves = one halo block each, its 80 fragment registers resident (0.134 -> 0.119)
     X5E(0, 3, 1, 20, 32, 10, 20, 8, 1, 1, 10),    // 6.0  160 -> 960, 20x20
 #ifdef CF_EXPERIMENTS
+    X5E(8, 5, 1, 20, 32, 10, 20, 8, 0, 0, 10),      // 8: layer5.1 with eight waves, X re-read (the first table row); 6.0 on twelve waves
+    X5M(8, 3, 1, 20, 32, 10, 20, 12, 1, 1, 3, 10),
+    X5M(9, 5, 1, 20, 32, 10, 20, 12, 0, 1, 3, 30),  // 9: ... every chunk in one workgroup
+    X5M(9, 3, 1, 20, 32, 10, 20, 12, 1, 1, 3, 30),
     X5E(7, 5, 1, 8, 32, 10, 20, 8, 0, 0, 4),      // 7: two workgroups per CU, 10x20 tiles, X re-read (the first table row above)
     X5E(7, 5, 1, 12, 32, 10, 20, 8, 0, 0, 6),
     X5E(7, 5, 2, 12, 16, 5, 20, 8, 0, 0, 12),
