@@ -91,6 +91,7 @@ struct MbParams {
     int yblock;           // y (expdw: the depthwise tensor; mbconv_px: the block output) in pixel-block order
                           // [m / 32][C / 8][m % 32][8], m = linear pixel index over the batch (PwParams::xblock)
     int xblock;           // expdw_px_kernel: x in pixel-block order
+    void* dbg;            // -DCF_X5_TIMING builds only: per-wave phase cycle sums (tools/x5_timing.py); nullptr otherwise
 };
 hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p);
 // cf_mbconv2.hip

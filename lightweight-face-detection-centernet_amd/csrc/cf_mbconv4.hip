@@ -160,10 +160,18 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
     };
 
     const CF_AS4 f32x4* wtab = (const CF_AS4 f32x4*)p.wdw;                       // [chunk][group of 4 channels][tap]
+#ifdef CF_X5_TIMING      // phase stamps (s_memtime), summed over the chunks of a wave: tools/x5_timing.py
+    unsigned long long tph[4] = {0, 0, 0, 0}, tq = 0;
+#define M4_STAMP(k) { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tph[k] += t_ - tq; tq = t_; }
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq) :: "memory");
+#else
+#define M4_STAMP(k)
+#endif
     stage_weights(0);
     for (int q = 0; q < nq; ++q) {
         const char* wx = Wst + (q & 1) * WXB;
         cf_sync_lds_dma();            // previous chunk's depthwise is done with E; this chunk's expand weights landed
+        M4_STAMP(0)
 
         // ---- phase 1: expand + Swish -> E
 #pragma unroll
@@ -173,7 +181,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
             if constexpr (XRELOAD) { load_block(ib, xf[0]); expand_block(ib, xf[0], wx); }
             else expand_block(ib, xf[t], wx);
         }
+        M4_STAMP(1)
         __syncthreads();
+        M4_STAMP(2)
         if (q + 1 < nq) stage_weights(q + 1);
 
         // ---- phase 2 + 3: depthwise + Swish on channel groups A, B; swap halves; project MFMAs of both pixel blocks
@@ -247,8 +257,15 @@ __global__ __launch_bounds__(NW * 64) void mbconv_f32_kernel(MbParams p) {
             for (int i = 0; i < NBO; ++i) { MMA::run(acc[0][i], wpc[i], x0); MMA::run(acc[1][i], wpc[i], x1); }
         }
         }
+        M4_STAMP(3)
     }
 
+#ifdef CF_X5_TIMING
+    if (p.dbg && lane == 0) {
+        unsigned long long* o = (unsigned long long*)p.dbg + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 4;
+        o[0] = tph[0]; o[1] = tph[1]; o[2] = tph[2]; o[3] = tph[3];
+    }
+#endif
     // ---- combine the k-groups through LDS (one output n-block of one pixel block at a time), in k-group order
     if constexpr (KG > 1) {
         float* red = reinterpret_cast<float*>(smem);

@@ -154,7 +154,25 @@ int cf_op_mbconv(int device, int dtype, const float* x, const float* w_exp, cons
     p.B = B; p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.Cin = Cin; p.hid = hid; p.Cout = Cout;
     p.k = k; p.s = stride; p.pad_lo = pd / 2; p.residual = (Cin == Cout && stride == 1) ? 1 : 0;
     p.HC = g.HC; p.nq = g.nq; p.NBE = g.NBE; p.JX = g.JX; p.HALF = g.HALF; p.rowb = g.rowb; p.lds_bytes = g.lds_bytes; p.kind = g.kind;
+#ifdef CF_X5_TIMING      // A/B build only: per-wave phase cycle sums of mbconv_f32_kernel (kind 7), printed to stderr
+    const size_t tn = (size_t)1 << 22;
+    unsigned long long* tdev = (unsigned long long*)sc.alloc(tn * 8);
+    (void)hipMemsetAsync(tdev, 0, tn * 8, sc.s); p.dbg = tdev;
+    for (int rep = 0; rep < 2 && sc.err == hipSuccess; ++rep) sc.chk(launch_mbconv(sc.s, dtype, p));
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, sc.s);
+#endif
     if (sc.err == hipSuccess) sc.chk(launch_mbconv(sc.s, dtype, p));
+#ifdef CF_X5_TIMING
+    (void)hipEventRecord(e1, sc.s); (void)hipStreamSynchronize(sc.s);
+    { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+      std::vector<unsigned long long> th(tn);
+      (void)hipMemcpy(th.data(), tdev, tn * 8, hipMemcpyDeviceToHost);
+      double sum[4] = {0, 0, 0, 0}; size_t nw = 0;
+      for (size_t i = 0; i + 3 < tn; i += 4) if (th[i] | th[i + 1] | th[i + 2] | th[i + 3]) { for (int k = 0; k < 4; ++k) sum[k] += (double)th[i + k]; ++nw; }
+      if (nw) fprintf(stderr, "mbconv timing (kind %d): %.1f us; %zu waves, %d chunks each; mean cycles per wave and chunk: wait-top %.0f  expand %.0f  barrier %.0f  dw+project %.0f  (sum %.0f)\n",
+                      g.kind, ms * 1e3, nw, g.nq, sum[0] / nw / g.nq, sum[1] / nw / g.nq, sum[2] / nw / g.nq, sum[3] / nw / g.nq, (sum[0] + sum[1] + sum[2] + sum[3]) / nw / g.nq); }
+#endif
     sc.to_host_nchw(dtype, p.y, y, B, Cout, Ho, Wo);
     return sc.result("cf_op_mbconv");
 }

@@ -69,8 +69,19 @@ void stem0_pack_proj(int dtype, const float* wp, void* out_host) {
 
 template <typename T> using S0Mma = CfMma<T>;
 
+#ifdef CF_X5_TIMING      // phase stamps of stem0_kernel, summed over all waves (tools/x5_timing.py reads them through cf_debug_stem_stamps)
+__device__ unsigned long long g_s0_stamps[8];
+__device__ unsigned long long g_s0_buf[204800 * 8];      // one record per wave of a B = 64, 640x640 launch (no atomics: they perturb the loads being timed)
+#define S0_STAMP(k) { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); s0t[k] += t_ - s0q; s0q = t_; }
+#else
+#define S0_STAMP(k)
+#endif
 template <typename T, int FMT>
 __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
+#ifdef CF_X5_TIMING
+    unsigned long long s0t[6] = {0, 0, 0, 0, 0, 0}, s0q;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(s0q) :: "memory");
+#endif
     constexpr int P = Elem<T>::PER16;
     constexpr bool F32 = sizeof(T) == 4;
     constexpr bool PRE = std::is_same<T, sp32_t>::value;          // split mode: -log2(e) in the stem weights, -ln 2 in the project weights (cf_runtime.hip)
@@ -78,8 +89,11 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
     constexpr int HALF = 32 * sizeof(T) / 16 / 2;                 // k-steps of the project GEMM per lane half
     constexpr int NIB = (S0_IPX + 31) / 32;                       // 11
     constexpr int NW = S0_NT / 64;
+    // split mode, uint8 input (round 5): the patch is staged with DWORD loads (below), its rows start 2 elements early and are 116 wide
+    constexpr bool DWST = PRE && FMT == CF_IN_U8_HWC_BGR;
+    constexpr int PROW = DWST ? 120 : S0_PROW, XOFF = DWST ? 2 : 0;
     __shared__ __attribute__((aligned(16))) char E[S0_IPX * ROWB];
-    __shared__ __attribute__((aligned(16))) T Xs[S0_PH * S0_PROW];
+    __shared__ __attribute__((aligned(16))) T Xs[S0_PH * PROW];
     __shared__ __attribute__((aligned(16))) float Wd[9 * 32];
     __shared__ float lut[FMT == CF_IN_U8_HWC_BGR ? 768 : 1];
 
@@ -97,7 +111,48 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
     constexpr int ECOLS = S0_PW * 3;                              // 111 elements per patch row
     constexpr int RSTEP = S0_NT / ECOLS;                          // 4 rows per pass (68 lanes idle)
     constexpr int NIT = (S0_PH + RSTEP - 1) / RSTEP;              // 10 passes over the 37 rows
-    {
+    if constexpr (DWST) {
+        // Round 5 (phase stamps, tools/x5_timing.py: the byte-wise staging below was 46 % of this kernel's wave time in the split mode --
+        // 4107 single-byte loads per tile, a table gather and a 4-byte LDS store each).  As in stem0_px_kernel: the patch row starts
+        // 6 (ox0 - 1) bytes into the image row = 2 bytes past a dword boundary, so it is read as 29 ALIGNED dwords starting 2 bytes early
+        // (a dword lies entirely inside or outside the image row); thread = one dword column walking down the rows; normalisation
+        // (u / 255 - mean) / std as one fma per byte (1 ulp from the reference's two divisions: the exact mode keeps its table, this mode
+        // is held to 1e-3); outside the image: exact 0 (ZeroPad2d).  Element e of a patch row sits at position e + 2.
+        constexpr int ND = (S0_PW * 3 + 2 + 3) / 4, RG = S0_NT / ND, NITD = (S0_PH + RG - 1) / RG;   // 29 dwords cover a patch row (+2 bytes in front)
+        const int d = tid % ND, rg = tid / ND;
+        const bool tact = rg < RG;
+        const int boff = ix0 * 3 - 2 + 4 * d;
+        const bool din = tact && boff >= 0 && boff + 4 <= p.W * 3;
+        const int cboff = min(max(boff, 0), p.W * 3 - 4);
+        float sc[4], sh[4]; bool bok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * d - 2 + i;
+            bok[i] = din && e >= 0 && e < S0_PW * 3;
+            const int ci = (e + 3) % 3;
+            sc[i] = ci == 0 ? 1.0f / (255.0f * 0.289f) : ci == 1 ? 1.0f / (255.0f * 0.274f) : 1.0f / (255.0f * 0.278f);
+            sh[i] = ci == 0 ? -0.408f / 0.289f : ci == 1 ? -0.447f / 0.274f : -0.470f / 0.278f;
+        }
+        uint32_t v[NITD];
+#pragma unroll
+        for (int it = 0; it < NITD; ++it) {
+            const int cy = min(max(iy0 + rg + it * RG, 0), p.H - 1);
+            v[it] = *reinterpret_cast<const uint32_t*>((const uint8_t*)p.x + ((size_t)b * p.H + cy) * p.W * 3 + cboff);
+        }
+        for (int i = tid; i < 9 * 32; i += S0_NT) Wd[i] = p.wdw[i];
+#pragma unroll
+        for (int it = 0; it < NITD; ++it) {
+            const int r = rg + it * RG, iy = iy0 + r;
+            const bool rowok = (unsigned)iy < (unsigned)p.H;
+            float f[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float u = (float)((v[it] >> (8 * i)) & 0xffu);             // v_cvt_f32_ubyteN
+                f[i] = (rowok && bok[i]) ? fmaf(u, sc[i], sh[i]) : 0.0f;
+            }
+            if (tact && r < S0_PH) st16(reinterpret_cast<char*>(Xs) + (r * PROW + 4 * d) * 4, pack16<float>(f));
+        }
+    } else {
         const int e = tid % ECOLS, r0 = tid / ECOLS;
         const bool tact = r0 < RSTEP;
         const int col = e / 3, ci = e - col * 3;
@@ -136,12 +191,14 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
                 val = idx == 0xffffffffu ? 0.0f : lut[idx];
             }
             if (tact && r < S0_PH) {
-                if constexpr (F32) reinterpret_cast<float*>(Xs)[r * S0_PROW + e] = val;
-                else Xs[r * S0_PROW + e] = (T)(pack_bf16x2(val, 0.0f) & 0xffffu);
+                if constexpr (F32) reinterpret_cast<float*>(Xs)[r * PROW + e] = val;
+                else Xs[r * PROW + e] = (T)(pack_bf16x2(val, 0.0f) & 0xffffu);
             }
         }
     }
+    S0_STAMP(0)
     __syncthreads();
+    S0_STAMP(1)
 
     // ---- phase 1: stem conv on MFMA + Swish -> E
     u32x4 ws[F32 ? 4 : 2];
@@ -154,7 +211,7 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
         const int y = oy0 - 1 + ty, x = ox0 - 1 + tx;
         const bool inmap = (unsigned)y < (unsigned)Ho && (unsigned)x < (unsigned)Wo;
         typedef typename std::conditional<F32, float, T>::type XT;
-        const XT* xp = reinterpret_cast<const XT*>(Xs) + (2 * ty) * S0_PROW + (2 * tx) * 3;
+        const XT* xp = reinterpret_cast<const XT*>(Xs) + (2 * ty) * PROW + (2 * tx) * 3 + XOFF;
         f32x16 a;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = 0.0f;
@@ -164,7 +221,7 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
             for (int s = 0; s < 16; ++s) {
                 const int t = 2 * s + h;
                 const int ky = t / 9, rr = t - 9 * ky;
-                v[s] = t < 27 ? xp[ky * S0_PROW + rr] : 0.0f;
+                v[s] = t < 27 ? xp[ky * PROW + rr] : 0.0f;
             }
             mma_chain<T, 4>(a, [&](int c) { return ws[c]; }, [&](int c) { return pack16<float>(&v[4 * c]); });
         } else {
@@ -175,8 +232,8 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
                 for (int e2 = 0; e2 < 4; ++e2) {
                     const int t0 = c * 16 + h * 8 + 2 * e2, t1 = t0 + 1;
                     const int ky0 = t0 / 9, r0 = t0 - 9 * ky0, ky1 = t1 / 9, r1 = t1 - 9 * ky1;
-                    const uint32_t lo = t0 < 27 ? (uint32_t)xp[ky0 * S0_PROW + r0] : 0u;
-                    const uint32_t hi = t1 < 27 ? (uint32_t)xp[ky1 * S0_PROW + r1] : 0u;
+                    const uint32_t lo = t0 < 27 ? (uint32_t)xp[ky0 * PROW + r0] : 0u;
+                    const uint32_t hi = t1 < 27 ? (uint32_t)xp[ky1 * PROW + r1] : 0u;
                     w4[e2] = lo | (hi << 16);
                 }
                 u32x4 xc; xc.x = w4[0]; xc.y = w4[1]; xc.z = w4[2]; xc.w = w4[3];
@@ -198,7 +255,9 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
             }
         }
     }
+    S0_STAMP(2)
     __syncthreads();
+    S0_STAMP(3)
 
     // ---- phase 2 + 3: depthwise 3x3 + Swish -> project 32->16
     const int o = wave * 32 + (F32 ? lds_group_pixel(pl) : pl);                 // fp32 tile: conflict-free ds_read_b128 groups (cf_common.h)
@@ -231,6 +290,13 @@ __global__ __launch_bounds__(S0_NT) void stem0_kernel(Stem0Params p) {
         return pack16<T>(d);
     };
     mma_chain<T, HALF>(acc, [&](int j) { return ld16((const char*)p.wproj + ((size_t)j * 64 + lane) * 16); }, dw_chunk);
+    S0_STAMP(4)
+#ifdef CF_X5_TIMING
+    if (lane == 0) {
+        const size_t wv = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave;
+        if (wv < 204800) { for (int k = 0; k < 5; ++k) g_s0_buf[wv * 8 + k] = s0t[k]; g_s0_buf[wv * 8 + 5] = 1ull; }
+    }
+#endif
     const int gy = oy0 + oy, gx = ox0 + ox;
     if (h != 0 || gy >= Ho || gx >= Wo) return;                  // channels 0..15 live in the h == 0 lanes
     T* out = (T*)p.y + (((size_t)b * Ho + gy) * Wo + gx) * 16;
@@ -837,4 +903,15 @@ hipError_t launch_stem0(hipStream_t s, int dtype, const Stem0Params& p) {
     return hipGetLastError();
 }
 
+#ifdef CF_X5_TIMING
+}  // namespace cf
+extern "C" int cf_debug_stem_stamps(unsigned long long* out6, int reset) {
+    static unsigned long long host[204800 * 8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(cf::g_s0_buf), sizeof host) != hipSuccess) return -1;
+    if (out6) { for (int k = 0; k < 6; ++k) out6[k] = 0; for (size_t w = 0; w < 204800; ++w) for (int k = 0; k < 6; ++k) out6[k] += host[w * 8 + k]; }
+    if (reset) { static unsigned long long z[204800 * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(cf::g_s0_buf), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+namespace cf {
+#endif
 }  // namespace cf
