@@ -99,7 +99,8 @@ __global__ __launch_bounds__(NW * 64, MW) void expdw_f32_kernel(MbParams p) {
             const bool isw = c < WXB / 1024;
             const char* src = (isw ? srcx + c * 1024 : srct + (c - WXB / 1024) * 1024) + lane * 16;
             const unsigned dst = __builtin_amdgcn_readfirstlane(isw ? wst + c * 1024 : tdst + (c - WXB / 1024) * 1024);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "m0");
+            unsigned m0save;                                       // m0 is the compiler's: saved and restored around the DMA
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0" : "=&s"(m0save) : "s"(dst), "v"(src));
         }
     };
 
