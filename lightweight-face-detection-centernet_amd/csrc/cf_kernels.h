@@ -122,6 +122,12 @@ void mb6_pack(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* w
               void* wexp_host, float* wdw_host, void* wproj_host);
 hipError_t mb6_launch(hipStream_t s, const MbParams& p);
 
+// cf_mbconv7.hip: as cf_mbconv6.hip, the depthwise feeding the project MFMAs directly (MbGeom::kind = 10; experiments switch CF_M7)
+bool mb7_geometry(int dtype, MbGeom& g, int Cin, int hid, int Cout, int k, int s);
+void mb7_pack(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
+              void* wexp_host, float* wdw_host, void* wproj_host);
+hipError_t mb7_launch(hipStream_t s, const MbParams& p);
+
 // cf_mbconv3.hip: depthwise on the matrix cores (v_mfma_f32_4x4x4_16b_f16, Toeplitz operands), stride 1, bf16 storage.
 // MbGeom::kind 4 = expand + depthwise (project stays a GEMM launch)
 MbGeom expdw_mx_geometry(int dtype, int Cin, int hid, int k, int s);

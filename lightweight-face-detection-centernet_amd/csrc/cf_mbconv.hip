@@ -48,6 +48,7 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
     if (g.kind == 4) { mx_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 5) { mx_fused_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 6) { mx_fused2_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
+    if (g.kind == 10) { mb7_pack(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 9) { mb6_pack(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 8) {                       // cf_mbconv5.hip: this file's expand fragments, taps as [chunk][group of 4 channels][tap][4]
         MbGeom g0 = g; g0.kind = 0; g0.NBO = 0; g0.HALF = 0; g0.wproj_bytes = 0;
@@ -503,6 +504,7 @@ MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
     if (dtype == 1 && mx_fused_geometry(g, Cin, hid, Cout, k, s)) return g;      // stride 1: depthwise on the matrix cores
     if (dtype == 1 && mx_fused2_geometry(g, Cin, hid, Cout, k, s)) return g;     // stride 2
     if (dtype == 1 && mb2_geometry(g, Cin, hid, Cout, k, s)) return g;
+    if (dtype == 2 && mb7_geometry(dtype, g, Cin, hid, Cout, k, s)) return g;     // (experiments switch CF_M7=1)
     if (dtype == 2 && mb6_geometry(dtype, g, Cin, hid, Cout, k, s)) return g;     // round 5: register-window depthwise (cf_mbconv6.hip)
     if (dtype != 1 && mb4_geometry(dtype, g, Cin, hid, Cout, k, s)) return g;
     g.JX = (Cin * sz / 16 + 1) / 2;
@@ -532,6 +534,7 @@ hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p) {
     if (p.kind == 7) return dtype != 1 ? mb4_launch(s, dtype, p) : hipErrorInvalidValue;
     if (p.kind == 8) return expdw_f32_launch(s, dtype, p);
     if (p.kind == 9) return dtype == 2 ? mb6_launch(s, p) : hipErrorInvalidValue;
+    if (p.kind == 10) return dtype == 2 ? mb7_launch(s, p) : hipErrorInvalidValue;
     const MbEntry* e = mb_find(dtype, p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
     if (!e || e->hc != p.HC) return hipErrorInvalidValue;
     return e->fn(s, p);
