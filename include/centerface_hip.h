@@ -107,6 +107,19 @@ int cf_forward(cf_ctx* ctx, const void* in, int in_format, int in_on_device, int
  * (11-bit coefficients, int32 passes; csrc/cf_util.hip restates it) and fed to the network.  Pinned to the
  * published algorithm, not to a particular cv2 binary (cv2 is not installable where this was built). */
 int cf_forward_resized(cf_ctx* ctx, const void* imgs_u8, int in_on_device, int B, int h, int w);
+/* The same for a batch held as B SEPARATE host images, imgs[b] -> uint8 [h,w,3] BGR -- what the loop of eval_widerface.py:76-90
+ * has after B cv2.imread calls.  Every image is one asynchronous DMA into the context's buffer ((h, w) == (H, W): straight into
+ * the network input, no resize launch).  From page-locked memory (cf_host_alloc, cf_host_register) there is no host-side
+ * staging copy at all; pageable pointers work too, but then the call returns only once the runtime has staged them.  The images
+ * must stay unchanged until a blocking call on ctx has returned (as for cf_forward). */
+int cf_forward_images(cf_ctx* ctx, const void* const* imgs, int B, int h, int w);
+/* The two halves of cf_forward_images: cf_upload_images only enqueues the host -> device copies (large batches: on the device's
+ * copy streams, shared by every context of the process, in call order), cf_forward_uploaded enqueues resize + forward on what the
+ * last cf_upload_images of ctx brought over (CF_ESTATE without one; any other upload or forward on ctx in between replaces it).
+ * A host that keeps several contexts in flight issues the uploads of the next batches BEFORE the forwards of the earlier ones, so
+ * that the copy queue never stands behind a forward (CenterFaceBuckets: 5 contexts, 128 VGA images, profiles/r05_vga_pipeline.md). */
+int cf_upload_images(cf_ctx* ctx, const void* const* imgs, int B, int h, int w);
+int cf_forward_uploaded(cf_ctx* ctx);
 /* the resized uint8 [B,H,W,3] batch of the last cf_forward_resized (tests) */
 int cf_get_resized_input(cf_ctx* ctx, void* out_u8, int B);
 /* copies the four head maps of the last forward to host as NCHW float32: hm [B,1,h,w] raw logits
@@ -158,6 +171,10 @@ int cf_decode_threshold_ex(cf_ctx* ctx, int mode, float score_thresh, float nms_
  * whatever the input size (eval_widerface.py:88); cf_decode_threshold[_ex] clamp to the context's (H, W). */
 int cf_decode_threshold_sized(cf_ctx* ctx, int mode, float score_thresh, float nms_thresh, int img_h, int img_w,
                               int max_out, float* dets, float* lms, int32_t* counts);
+/* centerface.py:55-62 on the device: from now on the threshold decodes of ctx write floor(x / scale_w) and floor(y / scale_h) for
+ * the box corners and the landmark points (numpy's float32 `//`: the exact floor of the quotient), so the host has nothing left to
+ * do per box.  scale_h = scale_w = 0 switches it off (the default: network coordinates).  CF_EINVAL for negative / mixed values. */
+int cf_set_rescale(cf_ctx* ctx, float scale_h, float scale_w);
 /* Optional asynchronous first half: enqueue the decode kernels right behind the last forward, no host wait.  A later
  * cf_decode_threshold_sized (or _ex / plain, which call it) with the SAME parameters then only waits and copies the results out;
  * with other parameters, or after another forward, it launches its own decode as usual.  For hosts that keep several contexts
@@ -273,6 +290,10 @@ int cf_graph_stats(cf_ctx* ctx, int* n_graphs, int* n_uncapturable);
  * (cf_forward from pageable memory stages through the driver and blocks the caller for the copy) */
 int cf_host_alloc(cf_ctx* ctx, uint64_t bytes, void** hptr);
 int cf_host_free(cf_ctx* ctx, void* hptr);
+/* Page-lock / release memory the caller owns (no context needed; any device may then DMA from it).  For buffers that are reused:
+ * registering costs a page-table walk (~0.1 ms per MB).  Errors: cf_op_last_error(). */
+int cf_host_register(void* hptr, uint64_t bytes);
+int cf_host_unregister(void* hptr);
 /* device memory helpers so a host language without a GPU allocator can keep inputs resident */
 int cf_device_alloc(cf_ctx* ctx, uint64_t bytes, void** dptr);
 int cf_device_free(cf_ctx* ctx, void* dptr);

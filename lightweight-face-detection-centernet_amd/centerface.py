@@ -12,9 +12,11 @@ reference's ``weight/model_epoch_100.pt`` is not distributed), ``dtype=`` ('fp32
 'bf16' throughput mode), ``device=``, ``max_batch=``, ``collapse_heads=``; methods ``forward``,
 ``detect_batch``, ``decode_topk`` (the ``ctdet_decode`` path of centerface_ext.py:52-82).
 """
+import bisect
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -144,6 +146,40 @@ class Engine(object):
         self._keep_in = x
         self._chk(self._L.cf_forward_resized(self._h, _lib.ptr(x), 0, x.shape[0], x.shape[1], x.shape[2]))
         self.last_B = x.shape[0]
+
+    def forward_images_enqueue(self, images, upload_only=False):
+        """The batch as a LIST of uint8 [h,w,3] BGR arrays of one common size (``cf_forward_images``): one asynchronous DMA per
+        image, resize on the device when (h, w) is not the network size.  With page-locked arrays (``pinned_empty`` / ``pin``)
+        nothing is copied on the host."""
+        arrs = [np.asarray(im) for im in images]
+        if not arrs:
+            raise ValueError("forward_images_enqueue needs at least one image")
+        shp = arrs[0].shape
+        for a in arrs:
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape != shp or a.shape[2] != 3:
+                raise ValueError("images must be uint8 [h,w,3] arrays of one common size, got %s %s (first: %s)" % (a.dtype, a.shape, shp))
+        arrs = [a if a.flags["C_CONTIGUOUS"] else np.ascontiguousarray(a) for a in arrs]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        self._keep_in = arrs
+        self._chk((self._L.cf_upload_images if upload_only else self._L.cf_forward_images)(self._h, ptrs, len(arrs), int(shp[0]), int(shp[1])))
+        if upload_only:
+            self._uploaded_B = len(arrs)
+        else:
+            self.last_B = len(arrs)
+
+    def upload_images(self, images):
+        """First half of ``forward_images_enqueue`` (``cf_upload_images``): only the host -> device copies are enqueued."""
+        self.forward_images_enqueue(images, upload_only=True)
+
+    def forward_uploaded(self):
+        """Second half (``cf_forward_uploaded``): resize + forward on what the last ``upload_images`` brought over."""
+        self._chk(self._L.cf_forward_uploaded(self._h))
+        self.last_B = self._uploaded_B
+
+    def set_rescale(self, scale_h=0.0, scale_w=0.0):
+        """centerface.py:55-62 on the device (``cf_set_rescale``): the threshold decodes of this engine return
+        ``x // scale_w``, ``y // scale_h``; (0, 0) = off."""
+        self._chk(self._L.cf_set_rescale(self._h, float(scale_h), float(scale_w)))
 
     def resized_input(self):
         """The resized uint8 [B,H,W,3] batch of the last forward_resized_enqueue (for tests)."""
@@ -468,9 +504,12 @@ class CenterFace(object):
         host time of a VGA-bucket batch."""
         return np.floor(a.astype(np.float64) / np.float64(np.float32(scale))).astype(np.float32)
 
-    def _postprocess(self, dets, lms):
-        # centerface.py:55-62: floor-division rescale, empty -> [0,5] / [0,10]
-        if len(dets) > 0:
+    def _postprocess(self, dets, lms, rescaled=False):
+        # centerface.py:55-62: floor-division rescale (``rescaled``: already done by the decode kernel, Engine.set_rescale),
+        # empty -> [0,5] / [0,10]
+        if len(dets) > 0 and rescaled:
+            pass
+        elif len(dets) > 0:
             dets[:, 0:4:2], dets[:, 1:4:2] = self._floordiv(dets[:, 0:4:2], self.scale_w), self._floordiv(dets[:, 1:4:2], self.scale_h)
             if self.landmarks:
                 lms[:, 0:10:2], lms[:, 1:10:2] = self._floordiv(lms[:, 0:10:2], self.scale_w), self._floordiv(lms[:, 1:10:2], self.scale_h)
@@ -480,9 +519,12 @@ class CenterFace(object):
                 lms = np.empty(shape=[0, 10], dtype=np.float32)
         return (dets, lms) if self.landmarks else dets
 
-    def _postprocess_many(self, results):
+    def _postprocess_many(self, results, rescaled=False):
         """_postprocess for a list of (dets, lms) that share one (scale_h, scale_w): ONE floor division over the
-        concatenated rows (elementwise, so identical to per-image calls), then split again."""
+        concatenated rows (elementwise, so identical to per-image calls), then split again.  ``rescaled``: the decode kernel
+        has divided already (Engine.set_rescale) -- only the reference's empty-result shapes are left to do."""
+        if rescaled:
+            return [self._postprocess(d, l, True) for d, l in results]
         n = [len(d) for d, _ in results]
         if sum(n) == 0:
             return [self._postprocess(d, l) for d, l in results]
@@ -506,16 +548,24 @@ class CenterFace(object):
         """Batched ``__call__`` (the shape of eval_widerface.get_detections, :76-90).  The reference's
         decode ignores ``threshold`` and uses 0.3 (centerface.py:77); so does this."""
         del threshold
-        batch = np.stack([np.asarray(im, dtype=np.uint8) for im in imgs])    # one common (h, w) per instance
-        identity = batch.shape[1:3] == (self.img_h_new, self.img_w_new)
+        imgs = [np.asarray(im, dtype=np.uint8) for im in imgs]
+        direct = all(is_pinned(im) for im in imgs)                           # page-locked images: one DMA each, no host copy
+        batch = imgs if direct else np.stack(imgs)                           # one common (h, w) per instance
+        identity = batch[0].shape[:2] == (self.img_h_new, self.img_w_new)
         out = []
-        for i in range(0, len(batch), self.engine.max_batch):
-            chunk = batch[i:i + self.engine.max_batch]
-            if identity:
-                self.engine.forward_enqueue(chunk)
-            else:
-                self.engine.forward_resized_enqueue(chunk)           # cv2.resize stand-in, on the device
-            out.extend(self._postprocess_many(self.engine.decode_threshold(0.3, self.nms_thresh, self.max_dets)))
+        self.engine.set_rescale(self.scale_h, self.scale_w)                  # centerface.py:55-62 inside the decode kernel
+        try:
+            for i in range(0, len(batch), self.engine.max_batch):
+                chunk = batch[i:i + self.engine.max_batch]
+                if direct:
+                    self.engine.forward_images_enqueue(chunk)
+                elif identity:
+                    self.engine.forward_enqueue(chunk)
+                else:
+                    self.engine.forward_resized_enqueue(chunk)               # cv2.resize stand-in, on the device
+                out.extend(self._postprocess_many(self.engine.decode_threshold(0.3, self.nms_thresh, self.max_dets), rescaled=True))
+        finally:
+            self.engine.set_rescale(0.0, 0.0)
         return out
 
     def detect_stream(self, imgs, threshold=0.2):
@@ -534,14 +584,21 @@ class CenterFace(object):
         nb = self.engine.max_batch
 
         def enqueue(e, chunk):
-            batch = np.stack([np.asarray(im, dtype=np.uint8) for im in chunk])
+            chunk = [np.asarray(im, dtype=np.uint8) for im in chunk]
+            e.set_rescale(self.scale_h, self.scale_w)
+            if all(is_pinned(im) for im in chunk):
+                return e.forward_images_enqueue(chunk)
+            batch = np.stack(chunk)
             if batch.shape[1:3] == (self.img_h_new, self.img_w_new):
                 e.forward_enqueue(batch)
             else:
                 e.forward_resized_enqueue(batch)
 
         def finish(e):
-            return self._postprocess_many(e.decode_threshold(0.3, self.nms_thresh, self.max_dets))
+            try:
+                return self._postprocess_many(e.decode_threshold(0.3, self.nms_thresh, self.max_dets), rescaled=True)
+            finally:
+                e.set_rescale(0.0, 0.0)
         it, k, pending = iter(imgs), 0, None
         while True:
             chunk = []
@@ -599,6 +656,66 @@ class CenterFace(object):
         _lib.check(L.cf_op_nms(self.device, _lib.ptr(boxes), _lib.ptr(scores), n, float(nms_thresh),
                                _lib.ptr(keep), C.byref(nk)), op=True)
         return [int(k) for k in keep[:nk.value]]
+
+
+# ---- page-locked caller memory ------------------------------------------------------------------------------------------
+_pin_lock = threading.Lock()
+_pin_bases, _pin_sizes = [], {}          # sorted base addresses / base -> bytes, of everything pin() registered
+
+
+def _unregister(addr):
+    with _pin_lock:
+        if _pin_sizes.pop(addr, None) is None:
+            return
+        _pin_bases.remove(addr)
+    try:
+        _lib.lib().cf_host_unregister(C.c_void_p(addr))
+    except Exception:                                              # noqa: BLE001  (interpreter shutdown)
+        pass
+
+
+def pin(arr):
+    """Page-lock the memory of a C-contiguous numpy array in place (``cf_host_register``) and return it: batches taken from
+    it reach the GPU by asynchronous DMA with no staging copy (``Engine.forward_images_enqueue``, ``CenterFaceBuckets``).
+    Worth it for buffers that are REUSED (a decoder's frame pool): registering costs ~0.1 ms per MB.  ``unpin`` releases."""
+    if not isinstance(arr, np.ndarray) or not arr.flags["C_CONTIGUOUS"] or arr.nbytes == 0:
+        raise ValueError("pin needs a non-empty C-contiguous numpy array")
+    addr = arr.ctypes.data
+    with _pin_lock:
+        if addr in _pin_sizes:
+            if _pin_sizes[addr] >= arr.nbytes:
+                return arr
+            raise ValueError("a shorter range at the same address is already pinned")
+    _lib.check(_lib.lib().cf_host_register(C.c_void_p(addr), arr.nbytes), op=True)
+    with _pin_lock:
+        bisect.insort(_pin_bases, addr)
+        _pin_sizes[addr] = arr.nbytes
+    return arr
+
+
+def unpin(arr):
+    _unregister(arr.ctypes.data)
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """``np.empty`` in page-locked memory (page-aligned; released when the array and its views are gone)."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.empty(max(n, 1) + 4096, np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    body = raw[off:off + max(n, 1)]
+    pin(body)
+    weakref.finalize(raw, _unregister, body.ctypes.data)           # views keep ``raw`` alive through .base
+    return body[:n].view(dtype).reshape(shape)
+
+
+def is_pinned(arr):
+    """True when the array's bytes lie inside a range registered by ``pin`` / ``pinned_empty``."""
+    if not isinstance(arr, np.ndarray) or not arr.flags["C_CONTIGUOUS"]:
+        return False
+    addr = arr.ctypes.data
+    with _pin_lock:
+        k = bisect.bisect_right(_pin_bases, addr) - 1
+        return k >= 0 and addr + arr.nbytes <= _pin_bases[k] + _pin_sizes[_pin_bases[k]]
 
 
 _copy_pool, _copy_pool_lock = None, threading.Lock()
@@ -720,10 +837,12 @@ class CenterFaceBuckets(object):
 
         def collect(item):
             eng, (h, w), idx = item
-            pp = CenterFace.__new__(CenterFace)                    # per chunk: the scales differ between raw sizes
+            pp = CenterFace.__new__(CenterFace)                    # only the reference's empty-result shapes are left to the host
             pp.landmarks = post.landmarks
-            pp.scale_h, pp.scale_w = eng.H / h, eng.W / w
-            res = pp._postprocess_many(eng.decode_threshold(0.3, self.nms_thresh, self.max_dets))
+            try:
+                res = pp._postprocess_many(eng.decode_threshold(0.3, self.nms_thresh, self.max_dets), rescaled=True)
+            finally:
+                eng.set_rescale(0.0, 0.0)
             for i, r in zip(idx, res):
                 out[i] = r
 
@@ -733,18 +852,43 @@ class CenterFaceBuckets(object):
             collector = self.__dict__["_collector"] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cf-collect")
         last, futs = {}, []
         main_exc = None
+        # Page-locked chunks are uploaded AHEAD: the copies of the next chunks (one per context at most) are enqueued before the
+        # forward of this one, so the device's copy queue holds nothing but copies back to back and never stands behind a forward.
+        direct = [all(is_pinned(imgs[i]) and imgs[i].dtype == np.uint8 for i in idx) for _, _, idx in order]
+        uploaded, up_next = {}, 0              # id(engine) -> index into ``order`` of the chunk whose copies are enqueued
+
+        def upload_ahead(k):
+            # the copies of chunks k, k+1, ... in order, while they are page-locked and their context has no upload waiting
+            nonlocal up_next
+            up_next = max(up_next, k)
+            while up_next < len(order) and up_next <= k + len(work):
+                e2, _, idx2 = order[up_next]
+                if not direct[up_next] or id(e2) in uploaded:
+                    return
+                e2.upload_images([imgs[i] for i in idx2])
+                uploaded[id(e2)] = up_next
+                up_next += 1
         try:
-            for item in order:
+            for k, item in enumerate(order):
                 eng, (h, w), idx = item
                 prev = last.get(id(eng))
                 if prev is not None:
                     prev.result()                                  # this context's earlier chunk has been collected
-                stage = self._staging(eng, len(idx), h, w)
-                _stage_copy_begin(stage, [imgs[i] for i in idx])()
-                if (h, w) == (eng.H, eng.W):
-                    eng.forward_enqueue(stage)
+                eng.set_rescale(eng.H / h, eng.W / w)              # this chunk's scale_h, scale_w (centerface.py:68-71)
+                if direct[k]:
+                    upload_ahead(k)                                # (a no-op when an earlier step has uploaded this chunk already)
+                    if uploaded.pop(id(eng), None) != k:
+                        raise RuntimeError("CenterFaceBuckets: upload order lost track of chunk %d" % k)
+                    eng.forward_uploaded()                         # page-locked images (pin / pinned_empty): DMA straight from them
+                    upload_ahead(k + 1)                            # (after the forward: a context holds ONE upload at a time)
                 else:
-                    eng.forward_resized_enqueue(stage)
+                    chunk = [imgs[i] for i in idx]
+                    stage = self._staging(eng, len(idx), h, w)
+                    _stage_copy_begin(stage, chunk)()
+                    if (h, w) == (eng.H, eng.W):
+                        eng.forward_enqueue(stage)
+                    else:
+                        eng.forward_resized_enqueue(stage)
                 eng.decode_threshold_enqueue(0.3, self.nms_thresh, self.max_dets)       # decode + NMS run as soon as the forward is done
                 f = collector.submit(collect, item)                # FIFO on one worker: collected in enqueue order
                 last[id(eng)] = f

@@ -667,15 +667,28 @@ __global__ __launch_bounds__(64) void thresh_sweep_kernel(ThreshParams p) {
         if (pos >= p.max_out) continue;
         const float* c = cand + (size_t)order[r] * 16;
         float* d = p.dets + ((size_t)b * p.max_out + pos) * 5;
+        float* l = p.lms ? p.lms + ((size_t)b * p.max_out + pos) * 10 : nullptr;
+        if (p.rs_w > 0.f) {                        // centerface.py:55-62: x // scale_w, y // scale_h (exact floor of the quotient)
+            const double sw = (double)p.rs_w, sh = (double)p.rs_h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = (float)floor((double)c[j] / ((j & 1) ? sh : sw));
+            d[4] = c[4];
+            if (l) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) l[j] = (float)floor((double)c[5 + j] / ((j & 1) ? sh : sw));
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 5; ++j) d[j] = c[j];
-        if (p.lms) {
-            float* l = p.lms + ((size_t)b * p.max_out + pos) * 10;
+        if (l) {
 #pragma unroll
             for (int j = 0; j < 10; ++j) l[j] = c[5 + j];
         }
     }
     if (lane == 0) p.counts[b] = kept;            // may exceed max_out: rows past max_out are not written, the caller sees the truncation
+    if (lane == 0 && p.host_counts) p.host_counts[b] = kept;
+    if (lane == 0 && b == 0 && p.host_overflow) p.host_overflow[0] = *p.overflow;      // final: thresh_collect_kernel finished launches ago
 }
 
 __global__ void affine_boxes_kernel(float* dets, const double* trans, int B, int K, int stride) {

@@ -292,6 +292,9 @@ struct ThreshParams {
     float* lms;           // [B][max_out][10] or nullptr
     int* counts;          // [B]
     int* overflow;        // [1] largest candidate count seen when some image exceeded cap (else untouched)
+    float rs_h, rs_w;     // > 0: emit floor(y / rs_h), floor(x / rs_w) (centerface.py:55-62); 0 = network coordinates
+    int* host_counts;     // optional page-locked HOST mirrors, written by the sweep kernel over PCIe ([B] counts, [1] the final overflow word):
+    int* host_overflow;   // with dets / lms in page-locked memory too the host needs no copy command at all, only an event wait
 };
 hipError_t launch_decode_threshold(hipStream_t s, const ThreshParams& p);
 // apply per-image 2x3 affines to the (x1,y1),(x2,y2) corners of dets [B][K][stride] in place (utils/post_process.py:83-90)
@@ -315,6 +318,8 @@ hipError_t launch_box_match(hipStream_t s, const OverlapParams& p);
 
 // bilinear stretch-resize of uint8 HWC images (cv2.resize(img, (W, H)) at centerface.py:30; half-pixel centres)
 hipError_t launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int B, int h, int w, int H, int W);
+// B page-locked host images (device-visible addresses, 16-byte aligned, `bytes` each) -> dst [B][bytes], read over PCIe by a kernel
+hipError_t launch_upload_images(hipStream_t s, const void* const* imgs, uint8_t* dst, int B, long long bytes);
 
 // layout converters used by cf_get_heads and the per-op test entry points
 hipError_t launch_nchw_to_nhwc(hipStream_t s, int dtype, const float* src /*f32 NCHW*/, void* dst /*T NHWC*/,

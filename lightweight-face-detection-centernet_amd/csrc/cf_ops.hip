@@ -99,6 +99,30 @@ extern "C" {
 
 const char* cf_op_last_error(void) { return g_op_error.c_str(); }
 
+// Page-lock memory the caller already owns (a numpy array, cv2.imread's result, a decoder's output buffer) so that cf_forward /
+// cf_forward_resized / cf_forward_images read it by asynchronous DMA, without the staging copy into cf_host_alloc memory.  Costs a
+// page-table walk per call (~0.1 ms per MB): for buffers that are reused, not for one-shot images.
+int cf_host_register(void* hptr, uint64_t bytes) {
+    if (!hptr || bytes == 0) { g_op_error = "cf_host_register: null pointer or zero size"; return CF_EINVAL; }
+    const hipError_t e = hipHostRegister(hptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g_op_error = std::string("hipHostRegister: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP;
+    }
+    return CF_OK;
+}
+int cf_host_unregister(void* hptr) {
+    if (!hptr) { g_op_error = "cf_host_unregister: null pointer"; return CF_EINVAL; }
+    const hipError_t e = hipHostUnregister(hptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g_op_error = std::string("hipHostUnregister: ") + hipGetErrorString(e);
+        return CF_EHIP;
+    }
+    return CF_OK;
+}
+
 int cf_op_dwconv(int device, int dtype, const float* x, const float* w, const float* bias, float* y,
                  int B, int C, int H, int W, int k, int stride, int pad_lo, int pad_hi, int act) {
     if (bad_dtype(dtype) || !x || !w || !y || (C % 8) || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return CF_EINVAL;

@@ -88,7 +88,9 @@ struct cf_ctx {
     int buf_in = -1, buf_heads = -1, buf_resized = -1;
     // host inputs: H2D copies run on their own stream into two alternating staging buffers, so the copy of
     // batch i+1 overlaps the forward of batch i (PCIe-inclusive rate ~ max(copy, compute), not their sum)
-    hipStream_t stream_in = nullptr; int buf_in2 = -1; int in_slot = 0; int in_slot_used = -1;
+    hipStream_t stream_in = nullptr, stream_in2 = nullptr; hipEvent_t ev_copy2 = nullptr; int buf_in2 = -1; int in_slot = 0; int in_slot_used = -1;
+    struct Upload { bool pending; int B, h, w, slot; bool small; } up = {false, 0, 0, 0, 0, false};      // cf_upload_images -> cf_forward_uploaded
+    hipEvent_t ev_src_copy = nullptr, ev_src_free = nullptr; bool src_busy = false;     // src_stage: filled on stream_in, read by the resize on stream
     hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_slot_free[2] = {nullptr, nullptr}; bool slot_busy[2] = {false, false};
     bool weights_loaded = false;
     int last_B = 0;
@@ -107,8 +109,11 @@ struct cf_ctx {
     float* t_cand = nullptr; int* t_count = nullptr; int* t_order = nullptr; unsigned long long* t_mask = nullptr; int t_B = 0;
     float* t_dets = nullptr; float* t_lms = nullptr; int* t_counts = nullptr; int* t_overflow = nullptr;
     int t_cap = 0, t_maxout = 0;
+    // results of the threshold decode in page-locked host memory (written by the kernels over PCIe): [overflow | counts | dets | lms]
+    uint8_t* h_thr = nullptr; bool t_host = false; hipEvent_t ev_thr = nullptr;
     // cf_decode_threshold_enqueue: the decode kernels of the last forward are already in the stream with these parameters
-    bool thr_pending = false; int thr_mode = 0, thr_h = 0, thr_w = 0, thr_maxout = 0, thr_B = 0; float thr_score = 0.f, thr_nms = 0.f;
+    bool thr_pending = false; int thr_mode = 0, thr_h = 0, thr_w = 0, thr_maxout = 0, thr_B = 0; float thr_score = 0.f, thr_nms = 0.f, thr_rs_h = 0.f, thr_rs_w = 0.f;
+    float rs_h = 0.f, rs_w = 0.f;      // cf_set_rescale: the threshold decode floor-divides x by rs_w and y by rs_h (0 = off)
     // hipGraph replay of the backbone + neck launches, one executable graph per (input pointer,
     // input format, batch): the second forward with a key captures it, later ones replay it
     struct FwdGraph { const void* in; int fmt, B; hipGraphExec_t exec; bool broken; unsigned long long used; };
@@ -449,24 +454,31 @@ __global__ void cf_comm_unpack_kernel(const float* slots, int world, size_t slot
 // behind its kernels: 28-39k img/s host-fed with two contexts against 39.5k with one.  Host-fed serving is PCIe-bound
 // at ~39k img/s either way; use one context for it.)
 namespace {
-struct CopyStream { hipStream_t s = nullptr; int refs = 0; };
+struct CopyStream { hipStream_t s = nullptr, s2 = nullptr; int refs = 0; };
 std::mutex g_copy_mu;
 CopyStream g_copy[64];
-hipError_t acquire_copy_stream(int device, hipStream_t* out) {
+hipError_t acquire_copy_stream(int device, hipStream_t* out, hipStream_t* out2) {
     std::lock_guard<std::mutex> lk(g_copy_mu);
     CopyStream& cs = g_copy[device & 63];
     if (!cs.s) {
-        hipError_t e = hipStreamCreateWithFlags(&cs.s, hipStreamNonBlocking);
-        if (e != hipSuccess) { cs.s = nullptr; return e; }
+        // highest priority: HIP folds a process's streams onto a few hardware queues, and a copy stream that shares its queue with
+        // some context's main stream stands behind that context's whole forward (the uploads of a five-context VGA batch then span
+        // 4.5 ms instead of 2.2: profiles/r05_vga_pipeline.md); streams of another priority get a hardware queue of their own
+        int lo = 0, hi = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        static const bool prio = cf_ab_int("CF_COPY_PRIO", 1) != 0;
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&cs.s, hipStreamNonBlocking, prio ? hi : lo);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&cs.s2, hipStreamNonBlocking, prio ? hi : lo);
+        if (e != hipSuccess) { if (cs.s) hipStreamDestroy(cs.s); cs.s = cs.s2 = nullptr; return e; }
     }
     ++cs.refs;
-    *out = cs.s;
+    *out = cs.s; *out2 = cs.s2;
     return hipSuccess;
 }
 void release_copy_stream(int device) {
     std::lock_guard<std::mutex> lk(g_copy_mu);
     CopyStream& cs = g_copy[device & 63];
-    if (--cs.refs == 0 && cs.s) { hipStreamDestroy(cs.s); cs.s = nullptr; }
+    if (--cs.refs == 0 && cs.s) { hipStreamDestroy(cs.s); hipStreamDestroy(cs.s2); cs.s = cs.s2 = nullptr; }
 }
 }  // namespace
 
@@ -516,7 +528,7 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fwd, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
-    if ((e = acquire_copy_stream(c->device, &c->stream_in)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
+    if ((e = acquire_copy_stream(c->device, &c->stream_in, &c->stream_in2)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     for (int i = 0; i < 2; ++i) {
         if ((e = hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&c->ev_slot_free[i], hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
@@ -554,8 +566,11 @@ int cf_destroy(cf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->ev_fwd) hipEventDestroy(c->ev_fwd);
-    if (c->stream_in) { hipStreamSynchronize(c->stream_in); release_copy_stream(c->device); }
+    if (c->stream_in) { hipStreamSynchronize(c->stream_in); hipStreamSynchronize(c->stream_in2); release_copy_stream(c->device); }
     for (int i = 0; i < 2; ++i) { if (c->ev_copy[i]) hipEventDestroy(c->ev_copy[i]); if (c->ev_slot_free[i]) hipEventDestroy(c->ev_slot_free[i]); }
+    if (c->ev_copy2) hipEventDestroy(c->ev_copy2);
+    if (c->ev_src_copy) hipEventDestroy(c->ev_src_copy);
+    if (c->ev_src_free) hipEventDestroy(c->ev_src_free);
     if (c->ev_dec) hipEventDestroy(c->ev_dec);
     if (c->ev_gather) { hipEventSynchronize(c->ev_gather); hipEventDestroy(c->ev_gather); }
     if (c->ev_main_dec) hipEventDestroy(c->ev_main_dec);
@@ -564,8 +579,10 @@ int cf_destroy(cf_ctx* c) {
     for (auto& b : c->bufs) if (b.p) hipFree(b.p);
     for (void* p : c->owned) hipFree(p);
     for (void* p : {(void*)c->src_stage, (void*)c->d_trans, (void*)c->hm_plane, (void*)c->keys, (void*)c->key_count, (void*)c->big, (void*)c->d_slot, (void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->t_cand, (void*)c->t_count,
-                    (void*)c->t_order, (void*)c->t_mask, (void*)c->t_dets, (void*)c->t_lms, (void*)c->t_counts, (void*)c->t_overflow})
+                    (void*)c->t_order, (void*)c->t_mask, (void*)(c->t_host ? nullptr : c->t_dets), (void*)(c->t_host ? nullptr : c->t_lms), (void*)c->t_counts, (void*)c->t_overflow})
         if (p) hipFree(p);
+    if (c->h_thr) hipHostFree(c->h_thr);
+    if (c->ev_thr) hipEventDestroy(c->ev_thr);
     for (auto& ev : c->events) if (ev) hipEventDestroy(ev);
     for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -1028,6 +1045,7 @@ hipError_t launch_plan_at(cf_ctx* c, size_t i, const void* net_in, int in_format
 
 int launch_all_ops(cf_ctx* c, const void* net_in, int in_format, int B) {
     c->thr_pending = false;                               // an enqueued threshold decode belongs to the forward before this one
+    c->up.pending = false;                                // ... and so does an upload nobody asked to run
     hipGraphExec_t exec = (c->flags & CF_FLAG_NO_GRAPH) ? nullptr : forward_graph(c, net_in, in_format, B);
     if (exec) HIPCHK(c, hipGraphLaunch(exec, c->stream));
     for (size_t i = 0; i < c->ops.size();) {
@@ -1058,6 +1076,33 @@ extern "C" {
 #else
 #define CF_FLUSH_LANE(c) do { } while (0)
 #endif
+
+// Host images of a size other than the network's land in src_stage first (the resize kernel reads them from there).  The copies go
+// on the device's ONE copy stream, like the network-sized batches of stage_input: with several contexts in flight (CenterFaceBuckets:
+// one per network shape) copies issued on each context's own stream share the PCIe link, ALL finish late and no forward can start
+// under them; queued on one stream the first chunk is complete after 1/n of the time and its forward runs under the other copies.
+// Small batches (single-image calls) stay on the main stream: nothing to overlap, and the event round trip costs 0.3 ms of latency.
+static hipStream_t src_stage_stream(cf_ctx* c, size_t bytes) { return bytes < ((size_t)8 << 20) ? c->stream : c->stream_in; }
+static int src_stage_begin(cf_ctx* c, size_t bytes) {
+    if (!c->ev_src_copy) HIPCHK(c, hipEventCreateWithFlags(&c->ev_src_copy, hipEventDisableTiming));
+    if (!c->ev_src_free) HIPCHK(c, hipEventCreateWithFlags(&c->ev_src_free, hipEventDisableTiming));
+    if (c->src_stage_bytes < bytes) {
+        if (c->src_stage) HIPCHK(c, hipFree(c->src_stage));        // (a device-wide synchronisation: no reader is left)
+        c->src_stage = nullptr; c->src_stage_bytes = 0; c->src_busy = false;
+        HIPCHK(c, hipMalloc((void**)&c->src_stage, bytes));
+        c->src_stage_bytes = bytes;
+    }
+    hipStream_t cs = src_stage_stream(c, bytes);
+    if (c->src_busy && cs != c->stream) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_src_free, 0));      // the resize of the batch before has read it
+    return CF_OK;
+}
+static int src_stage_resize(cf_ctx* c, size_t bytes, uint8_t* dst, int B, int h, int w) {
+    if (src_stage_stream(c, bytes) != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_src_copy, 0));      // recorded behind the copies
+    HIPCHK(c, launch_resize_u8(c->stream, c->src_stage, dst, B, h, w, c->H, c->W));
+    HIPCHK(c, hipEventRecord(c->ev_src_free, c->stream));
+    c->src_busy = true;
+    return CF_OK;
+}
 
 int cf_forward(cf_ctx* c, const void* in, int in_format, int in_on_device, int B) {
     if (!c) return CF_EINVAL;
@@ -1162,23 +1207,134 @@ int cf_forward_resized(cf_ctx* c, const void* imgs, int in_on_device, int B, int
     if (B < 1 || B > c->max_batch) return c->fail(CF_EINVAL, "cf_forward_resized: B=%d outside [1, %d]", B, c->max_batch);
     HIPCHK(c, hipSetDevice(c->device));
     CF_FLUSH_LANE(c);
-    const uint8_t* src = (const uint8_t*)imgs;
+    uint8_t* dst = (uint8_t*)c->bufs[c->buf_resized].p;
     if (!in_on_device) {
         const size_t bytes = (size_t)B * h * w * 3;
-        if (c->src_stage_bytes < bytes) {
-            if (c->src_stage) HIPCHK(c, hipFree(c->src_stage));
-            c->src_stage = nullptr; c->src_stage_bytes = 0;
-            HIPCHK(c, hipMalloc((void**)&c->src_stage, bytes));
-            c->src_stage_bytes = bytes;
-        }
-        HIPCHK(c, hipMemcpyAsync(c->src_stage, imgs, bytes, hipMemcpyHostToDevice, c->stream));
-        src = c->src_stage;
+        int r = src_stage_begin(c, bytes); if (r) return r;
+        HIPCHK(c, hipMemcpyAsync(c->src_stage, imgs, bytes, hipMemcpyHostToDevice, src_stage_stream(c, bytes)));
+        if (src_stage_stream(c, bytes) != c->stream) HIPCHK(c, hipEventRecord(c->ev_src_copy, c->stream_in));
+        r = src_stage_resize(c, bytes, dst, B, h, w); if (r) return r;
+    } else {
+        HIPCHK(c, launch_resize_u8(c->stream, (const uint8_t*)imgs, dst, B, h, w, c->H, c->W));
     }
-    uint8_t* dst = (uint8_t*)c->bufs[c->buf_resized].p;
-    HIPCHK(c, launch_resize_u8(c->stream, src, dst, B, h, w, c->H, c->W));
     int r = launch_all_ops(c, dst, CF_IN_U8_HWC_BGR, B);
     if (r) return r;
     c->last_B = B;
+    return CF_OK;
+}
+
+// The batch as B separate host images (one pointer each) instead of one [B,h,w,3] block: what a caller holds after B cv2.imread calls
+// (eval_widerface.py:76-90).  Each image is its own asynchronous DMA into the context's device buffer -- from page-locked memory
+// (cf_host_alloc / cf_host_register) without any host-side staging copy, which was the largest host cost of a mixed-size batch
+// (2.7 of 5.8 ms per 128 VGA images).  Pageable pointers are accepted too (the runtime stages them: correct, slower, and the call
+// then returns only when the copies have left the caller's memory).
+int cf_upload_images(cf_ctx* c, const void* const* imgs, int B, int h, int w) {
+    if (!c || !imgs || h < 1 || w < 1) return CF_EINVAL;
+    if (!c->weights_loaded) return c->fail(CF_ESTATE, "cf_upload_images before cf_load_weights");
+    if (B < 1 || B > c->max_batch) return c->fail(CF_EINVAL, "cf_upload_images: B=%d outside [1, %d]", B, c->max_batch);
+    for (int b = 0; b < B; ++b) if (!imgs[b]) return c->fail(CF_EINVAL, "cf_upload_images: image %d is a null pointer", b);
+    HIPCHK(c, hipSetDevice(c->device));
+    CF_FLUSH_LANE(c);
+    const size_t one = (size_t)h * w * 3;
+    // page-locked images (device-visible, 16-byte aligned): ONE kernel reads them all over PCIe instead of one DMA command each
+    std::vector<const void*> dev;
+    static const bool use_kernel = cf_ab_int("CF_UPLOAD_KERNEL", 0) != 0;      // measured: the kernel reaches 53 GB/s but doubles the time of forwards running beside it
+    if (use_kernel && one % 16 == 0) {
+        dev.resize(B);
+        for (int b = 0; b < B; ++b) {
+            void* dp = nullptr;
+            if ((reinterpret_cast<uintptr_t>(imgs[b]) & 15) || hipHostGetDevicePointer(&dp, const_cast<void*>(imgs[b]), 0) != hipSuccess || !dp ||
+                (reinterpret_cast<uintptr_t>(dp) & 15)) {
+                (void)hipGetLastError();
+                dev.clear();
+                break;
+            }
+            dev[b] = dp;
+        }
+    }
+    auto copy_in = [&](uint8_t* dst, hipStream_t cs) -> hipError_t {
+        if (!dev.empty()) return launch_upload_images(cs, dev.data(), dst, B, (long long)one);
+        // One DMA command per run of images that are adjacent in host memory (a caller's frame pool often is).  A command costs the
+        // engine 8-10 us of idle link on top of ~22 us per VGA image, so large batches alternate between the device's two copy streams
+        // (two engines): one's set-up hides under the other's transfer.  Stream 2 starts behind everything stream 1 has been asked to
+        // wait for, and stream 1 ends behind stream 2, so the caller's event on stream 1 covers both.
+        static const bool dual_ok = cf_ab_int("CF_COPY_DUAL", 1) != 0;
+        const bool dual = dual_ok && cs == c->stream_in && B > 1;
+        hipError_t e = hipSuccess;
+        if (dual) {
+            if (!c->ev_copy2 && (e = hipEventCreateWithFlags(&c->ev_copy2, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventRecord(c->ev_copy2, c->stream_in)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(c->stream_in2, c->ev_copy2, 0)) != hipSuccess) return e;
+        }
+        int k = 0;
+        for (int b = 0; b < B;) {
+            int n = 1;
+            while (b + n < B && (const uint8_t*)imgs[b + n] == (const uint8_t*)imgs[b] + (size_t)n * one) ++n;
+            e = hipMemcpyAsync(dst + b * one, imgs[b], one * n, hipMemcpyHostToDevice, (dual && (k++ & 1)) ? c->stream_in2 : cs);
+            if (e != hipSuccess) return e;
+            b += n;
+        }
+        if (dual) {
+            if ((e = hipEventRecord(c->ev_copy2, c->stream_in2)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(c->stream_in, c->ev_copy2, 0)) != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    if (h == c->H && w == c->W) {                           // network-sized: straight into an input slot, on the copy stream
+        static const bool own_stream = cf_ab_int("CF_UPLOAD_STREAM", 1) == 0;      // A/B: uploads on the context's main stream
+        const bool small = own_stream || one * B < ((size_t)8 << 20);             // as in stage_input: slot 0 on the main stream, no event round trip
+        const int slot = small ? 0 : (c->in_slot ^= 1);
+        hipStream_t cs = small ? c->stream : c->stream_in;
+        uint8_t* dst = (uint8_t*)c->bufs[slot == 0 ? c->buf_in : c->buf_in2].p;
+        if (c->slot_busy[slot]) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_slot_free[slot], 0));
+        HIPCHK(c, copy_in(dst, cs));
+        if (!small) HIPCHK(c, hipEventRecord(c->ev_copy[slot], cs));
+        c->up = {true, B, h, w, slot, small};
+        return CF_OK;
+    }
+    int r = src_stage_begin(c, one * B); if (r) return r;
+    HIPCHK(c, copy_in(c->src_stage, src_stage_stream(c, one * B)));
+    if (src_stage_stream(c, one * B) != c->stream) HIPCHK(c, hipEventRecord(c->ev_src_copy, c->stream_in));
+    c->up = {true, B, h, w, -1, false};
+    return CF_OK;
+}
+
+int cf_forward_uploaded(cf_ctx* c) {
+    if (!c) return CF_EINVAL;
+    if (!c->up.pending) return c->fail(CF_ESTATE, "cf_forward_uploaded without a cf_upload_images before it");
+    HIPCHK(c, hipSetDevice(c->device));
+    const cf_ctx::Upload u = c->up;
+    c->up.pending = false;
+    const uint8_t* net_in;
+    if (u.slot >= 0) {
+        if (!u.small) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy[u.slot], 0));
+        c->in_slot_used = u.slot;
+        net_in = (const uint8_t*)c->bufs[u.slot == 0 ? c->buf_in : c->buf_in2].p;
+    } else {
+        uint8_t* dst = (uint8_t*)c->bufs[c->buf_resized].p;
+        int r = src_stage_resize(c, (size_t)u.B * u.h * u.w * 3, dst, u.B, u.h, u.w); if (r) return r;
+        net_in = dst;
+    }
+    int r = launch_all_ops(c, net_in, CF_IN_U8_HWC_BGR, u.B);
+    if (r) return r;
+    c->last_B = u.B;
+    return CF_OK;
+}
+
+int cf_forward_images(cf_ctx* c, const void* const* imgs, int B, int h, int w) {
+    int r = cf_upload_images(c, imgs, B, h, w);
+    return r ? r : cf_forward_uploaded(c);
+}
+
+
+// centerface.py:55-62 on the device: the threshold decode writes floor(x / scale_w), floor(y / scale_h) for the four box corners and
+// the five landmark points (numpy's float32 `//` by a python float: the exact floor of the quotient -- evaluated here as the floor of
+// the float64 quotient, which is identical, see CenterFace._floordiv).  0, 0 switches it off (boxes in network coordinates).
+int cf_set_rescale(cf_ctx* c, float scale_h, float scale_w) {
+    if (!c) return CF_EINVAL;
+    if (!(scale_h >= 0.f) || !(scale_w >= 0.f) || (scale_h == 0.f) != (scale_w == 0.f))
+        return c->fail(CF_EINVAL, "cf_set_rescale: scales must both be positive, or both 0 (off); got %g, %g", (double)scale_h, (double)scale_w);
+    c->rs_h = scale_h; c->rs_w = scale_w;
     return CF_OK;
 }
 
@@ -1291,6 +1447,8 @@ static void free_thresh_ws(cf_ctx* c) {
 // pinning GBs of HBM for the life of the context.  Practical limit: cap^2 / 8 bytes x B must fit the free HBM.
 static constexpr size_t kThreshKeepBytes = (size_t)512 << 20;
 static size_t thresh_mask_bytes(int B, int cap) { return (size_t)B * cap * ((cap + 63) / 64) * sizeof(unsigned long long); }
+static constexpr size_t kThreshHostBytes = (size_t)16 << 20;          // larger result tables (max_out grown after an overflow) stay on the device
+static size_t thr_host_head(cf_ctx* c) { return (256 + (size_t)c->max_batch * sizeof(int) + 255) / 256 * 256; }     // [overflow: 256 B][counts]
 static int ensure_thresh_ws(cf_ctx* c, int max_out, int cap, int B) {
     if (c->t_cap < cap || c->t_B < B) {
         cap = std::max(cap, c->t_cap); B = std::max(B, c->t_B);
@@ -1311,13 +1469,26 @@ static int ensure_thresh_ws(cf_ctx* c, int max_out, int cap, int B) {
         c->t_cap = cap; c->t_B = B;
     }
     if (c->t_maxout < max_out) {
-        if (c->t_dets) hipFree(c->t_dets);
-        if (c->t_lms) hipFree(c->t_lms);
-        c->t_dets = nullptr; c->t_lms = nullptr;
-        HIPCHK(c, hipMalloc((void**)&c->t_dets, (size_t)c->max_batch * max_out * 5 * sizeof(float)));
-        HIPCHK(c, hipMalloc((void**)&c->t_lms, (size_t)c->max_batch * max_out * 10 * sizeof(float)));
+        if (!c->t_host && c->t_dets) hipFree(c->t_dets);
+        if (!c->t_host && c->t_lms) hipFree(c->t_lms);
+        if (c->h_thr) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipHostFree(c->h_thr); }
+        c->t_dets = nullptr; c->t_lms = nullptr; c->h_thr = nullptr; c->t_host = false; c->t_maxout = 0;
+        const size_t nd = (size_t)c->max_batch * max_out * 5 * sizeof(float), nl = 2 * nd, head = thr_host_head(c);
+        if (nd + nl <= kThreshHostBytes) {
+            // the usual case: the sweep kernel writes the few hundred result rows straight into page-locked host memory.  Copy
+            // commands cost more than the data here (two synchronising round trips and three staged copies per collected batch,
+            // and a hipStreamSynchronize that came back milliseconds late with five contexts in flight: profiles/r05_vga_pipeline.md)
+            HIPCHK(c, hipHostMalloc((void**)&c->h_thr, head + nd + nl, hipHostMallocDefault));
+            memset(c->h_thr, 0, head);
+            c->t_dets = (float*)(c->h_thr + head); c->t_lms = (float*)(c->h_thr + head + nd);
+            c->t_host = true;
+        } else {
+            HIPCHK(c, hipMalloc((void**)&c->t_dets, nd));
+            HIPCHK(c, hipMalloc((void**)&c->t_lms, nl));
+        }
         c->t_maxout = max_out;
     }
+    if (!c->ev_thr) HIPCHK(c, hipEventCreateWithFlags(&c->ev_thr, hipEventDisableTiming));
     return CF_OK;
 }
 
@@ -1341,8 +1512,11 @@ static int thresh_launch(cf_ctx* c, int mode, float score_thresh, float nms_thre
     p.img_h = img_h; p.img_w = img_w; p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.cap = c->t_cap; p.mode = mode;
     p.cand = c->t_cand; p.cand_count = c->t_count; p.order = c->t_order; p.mask = c->t_mask;
     p.max_out = max_out; p.dets = c->t_dets; p.lms = c->t_lms; p.counts = c->t_counts; p.overflow = c->t_overflow;
+    p.rs_h = c->rs_h; p.rs_w = c->rs_w;
+    if (c->t_host) { p.host_overflow = (int*)c->h_thr; p.host_counts = (int*)(c->h_thr + 256); }
     HIPCHK(c, hipMemsetAsync(c->t_overflow, 0, sizeof(int), c->stream));
     HIPCHK(c, launch_decode_threshold(c->stream, p));
+    HIPCHK(c, hipEventRecord(c->ev_thr, c->stream));
     return CF_OK;
 }
 
@@ -1358,7 +1532,7 @@ int cf_decode_threshold_enqueue(cf_ctx* c, int mode, float score_thresh, float n
     const int cap = c->t_cap > 0 ? c->t_cap : (HW < 4096 ? (HW + 63) / 64 * 64 : 4096);
     int r = thresh_launch(c, mode, score_thresh, nms_thresh, img_h, img_w, max_out, cap); if (r) return r;
     c->thr_pending = true; c->thr_mode = mode; c->thr_h = img_h; c->thr_w = img_w; c->thr_maxout = max_out; c->thr_B = c->last_B;
-    c->thr_score = score_thresh; c->thr_nms = nms_thresh;
+    c->thr_score = score_thresh; c->thr_nms = nms_thresh; c->thr_rs_h = c->rs_h; c->thr_rs_w = c->rs_w;
     return CF_OK;
 }
 
@@ -1373,7 +1547,7 @@ int cf_decode_threshold_sized(cf_ctx* c, int mode, float score_thresh, float nms
     // count, the workspace is reallocated and the decode reruns
     int cap = c->t_cap > 0 ? c->t_cap : (HW < 4096 ? (HW + 63) / 64 * 64 : 4096);
     bool launched = c->thr_pending && c->thr_mode == mode && c->thr_h == img_h && c->thr_w == img_w && c->thr_maxout == max_out && c->thr_B == B &&
-                    c->thr_score == score_thresh && c->thr_nms == nms_thresh;      // cf_decode_threshold_enqueue did the launch
+                    c->thr_score == score_thresh && c->thr_nms == nms_thresh && c->thr_rs_h == c->rs_h && c->thr_rs_w == c->rs_w;      // cf_decode_threshold_enqueue did the launch
     c->thr_pending = false;
     // the pre-enqueued launch is only valid while the workspace it wrote still exists with the geometry it was launched on
     if (launched && (!c->t_overflow || !c->t_counts || c->t_B < B || c->t_cap < 1 || c->t_maxout < max_out)) launched = false;
@@ -1381,11 +1555,17 @@ int cf_decode_threshold_sized(cf_ctx* c, int mode, float score_thresh, float nms
         if (!launched) { int r = thresh_launch(c, mode, score_thresh, nms_thresh, img_h, img_w, max_out, cap); if (r) return r; }
         launched = false;
         int overflow = 0;
-        // `overflow` lives on this stack frame: never return while a copy into it may still be in flight
-        const hipError_t e1 = hipMemcpyAsync(&overflow, c->t_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        const hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(counts, c->t_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream) : e1;
-        const hipError_t e3 = hipStreamSynchronize(c->stream);
-        HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
+        if (c->t_host) {                           // results are in page-locked host memory once the decode's event has fired
+            HIPCHK(c, hipEventSynchronize(c->ev_thr));
+            overflow = *(volatile int*)c->h_thr;
+            memcpy(counts, c->h_thr + 256, (size_t)B * sizeof(int));
+        } else {
+            // `overflow` lives on this stack frame: never return while a copy into it may still be in flight
+            const hipError_t e1 = hipMemcpyAsync(&overflow, c->t_overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            const hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(counts, c->t_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream) : e1;
+            const hipError_t e3 = hipStreamSynchronize(c->stream);
+            HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
+        }
         if (overflow > c->t_cap && attempt == 0) { cap = (std::min(overflow, HW) + 63) / 64 * 64; continue; }
         if (overflow > c->t_cap) return c->fail(CF_EOVERFLOW, "more than %d cells above the score threshold in one image", c->t_cap);
         break;
@@ -1393,7 +1573,14 @@ int cf_decode_threshold_sized(cf_ctx* c, int mode, float score_thresh, float nms
     // only the rows that exist: [B][rows][5 | 10] out of [B][max_out][.] (the rows past an image's count are never read by the caller)
     int rows = 0;
     for (int b = 0; b < B; ++b) rows = std::max(rows, std::min((int)counts[b], max_out));
-    if (rows > 0) {
+    if (rows > 0 && c->t_host) {
+        for (int b = 0; b < B; ++b) {
+            const size_t n = (size_t)std::min((int)counts[b], max_out);
+            if (!n) continue;
+            memcpy(dets + (size_t)b * max_out * 5, c->t_dets + (size_t)b * max_out * 5, n * 5 * sizeof(float));
+            if (lms) memcpy(lms + (size_t)b * max_out * 10, c->t_lms + (size_t)b * max_out * 10, n * 10 * sizeof(float));
+        }
+    } else if (rows > 0) {
         HIPCHK(c, hipMemcpy2DAsync(dets, (size_t)max_out * 5 * sizeof(float), c->t_dets, (size_t)max_out * 5 * sizeof(float),
                                    (size_t)rows * 5 * sizeof(float), B, hipMemcpyDeviceToHost, c->stream));
         if (lms) HIPCHK(c, hipMemcpy2DAsync(lms, (size_t)max_out * 10 * sizeof(float), c->t_lms, (size_t)max_out * 10 * sizeof(float),

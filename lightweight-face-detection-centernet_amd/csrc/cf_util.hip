@@ -65,6 +65,50 @@ __global__ void resize_u8_kernel(const uint8_t* src, uint8_t* dst, int B, int h,
         d[c] = (uint8_t)min(max(v, 0), 255);
     }
 }
+// ---- host images -> HBM by a kernel (zero-copy reads of page-locked host memory over PCIe) -------------------------------------
+// One launch moves up to 64 separately allocated images: the DMA engines need one command per image (8-10 us of idle link between
+// two ~22 us copies of a VGA image) and ~0.3 ms from the end of a copy to the start of a kernel that waits for it on another stream
+// (profiles/r05_vga_pipeline.md); a kernel has neither.  blockIdx.y = image, 16-byte loads, UNR in flight per lane: 48 workgroups x
+// 256 lanes x 4 x 16 B = 786 KB in flight covers the link's bandwidth-delay product many times.
+struct UploadPtrs { const uint8_t* src[64]; };
+template <int UNR>
+__global__ void __launch_bounds__(256) upload_images_kernel(UploadPtrs tab, uint8_t* dst, long long bytes) {
+    const uint8_t* src = tab.src[blockIdx.y];
+    uint8_t* out = dst + (size_t)blockIdx.y * bytes;
+    const long long nvec = bytes >> 4;                                   // both ends 16-byte aligned (checked by the launcher)
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
+    u32x4* d4 = reinterpret_cast<u32x4*>(out);
+    for (; i + (UNR - 1) * stride < nvec; i += UNR * stride) {
+        u32x4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = __builtin_nontemporal_load(s4 + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) d4[i + u * stride] = v[u];
+    }
+    for (; i < nvec; i += stride) d4[i] = __builtin_nontemporal_load(s4 + i);
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) out[(nvec << 4) + threadIdx.x] = src[(nvec << 4) + threadIdx.x];
+}
+// imgs: DEVICE-visible addresses of B page-locked host images of `bytes` each; dst: [B][bytes] on the device (16-byte aligned)
+hipError_t launch_upload_images(hipStream_t s, const void* const* imgs, uint8_t* dst, int B, long long bytes) {
+    if (B <= 0 || bytes <= 0) return hipSuccess;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int nb = B - b0 < 64 ? B - b0 : 64;
+        UploadPtrs tab{};
+        for (int b = 0; b < nb; ++b) tab.src[b] = (const uint8_t*)imgs[b0 + b];
+        int gx = (int)((bytes / 16 + 256 * 4 - 1) / (256 * 4));
+        const int want = (96 + nb - 1) / nb;                             // ~96 workgroups per launch: the link, not the CUs, is the limit
+        if (gx > want) gx = want;
+        if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(upload_images_kernel<4>, dim3(gx, nb), dim3(256), 0, s, tab, dst + (size_t)b0 * bytes, bytes);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_resize_u8(hipStream_t s, const uint8_t* src, uint8_t* dst, int B, int h, int w, int H, int W) {
     const long long n = (long long)B * H * W;
     if (n <= 0) return hipSuccess;

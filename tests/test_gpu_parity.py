@@ -938,6 +938,91 @@ def test_variable_size_buckets_product_configuration_128_images():
     pool.close()
 
 
+def test_device_rescale_equals_numpy_floor_divide():
+    """centerface.py:55-62 inside the decode kernel (cf_set_rescale): bit-identical to numpy's float32 `//` by the python-float
+    scales of transform(), applied to the same engine's un-rescaled decode -- on scales that are not representable (480/470,
+    736/730), on scale 1.0 (still a floor) and after switching it off again."""
+    rng = np.random.default_rng(99)
+    total = 0
+    for (h, w) in [(470, 730), (640, 640), (300, 500)]:
+        H, W, sh, sw = cfa.CenterFace.transform(None, h, w)
+        eng = cfa.Engine(H, W, max_batch=3, dtype="fp32")
+        x = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+        eng.forward_resized_enqueue(x)
+        plain = eng.decode_threshold(0.3, 0.3, 1024)
+        eng.set_rescale(sh, sw)
+        eng.decode_threshold_enqueue(0.3, 0.3, 1024)            # the pre-enqueued launch carries the scales too
+        scaled = eng.decode_threshold(0.3, 0.3, 1024)
+        eng.set_rescale(0.0, 0.0)
+        off = eng.decode_threshold(0.3, 0.3, 1024)
+        for (d, l), (ds, ls), (d0, l0) in zip(plain, scaled, off):
+            want_d, want_l = d.copy(), l.copy()
+            want_d[:, 0:4:2], want_d[:, 1:4:2] = d[:, 0:4:2] // sw, d[:, 1:4:2] // sh            # the reference's own statement
+            want_l[:, 0:10:2], want_l[:, 1:10:2] = l[:, 0:10:2] // sw, l[:, 1:10:2] // sh
+            assert np.array_equal(ds, want_d) and np.array_equal(ls, want_l)
+            assert np.array_equal(d0, d) and np.array_equal(l0, l)
+            total += len(d)
+        with pytest.raises(ValueError):
+            eng.set_rescale(1.0, 0.0)
+        eng.close()
+    assert total > 0
+
+
+def test_pinned_images_reach_the_gpu_without_staging_and_match():
+    """Page-locked caller images (cfa.pinned_empty / cfa.pin) go through cf_forward_images -- one DMA per image, no staging copy --
+    in CenterFaceBuckets and CenterFace.detect_batch, with the results of the staged path; pageable images keep the staged path."""
+    rng = np.random.default_rng(5)
+    shapes = [(480, 640), (640, 480), (640, 640), (470, 730)]
+    pageable = [rng.integers(0, 256, shapes[i % 4] + (3,), dtype=np.uint8) for i in range(22)]
+    pinned = []
+    for k, im in enumerate(pageable):
+        if k % 2:
+            a = cfa.pinned_empty(im.shape)
+            a[...] = im
+        else:
+            a = cfa.pin(im.copy())
+        assert cfa.is_pinned(a) and cfa.is_pinned(a[10:20]) and not cfa.is_pinned(im)
+        pinned.append(a)
+    calls = {"direct": 0, "staged": 0}
+    real_i, real_f, real_r = cfa.Engine.forward_images_enqueue, cfa.Engine.forward_enqueue, cfa.Engine.forward_resized_enqueue
+
+    def count(key, f):
+        def g(self, *a, **k):
+            calls[key] += 1
+            return f(self, *a, **k)
+        return g
+    cfa.Engine.forward_images_enqueue = count("direct", real_i)
+    cfa.Engine.forward_enqueue, cfa.Engine.forward_resized_enqueue = count("staged", real_f), count("staged", real_r)
+    try:
+        with cfa.CenterFaceBuckets(dtype="bf16", max_batch=4, max_buckets=4) as pool:
+            want = pool.detect(pageable)
+            assert calls["direct"] == 0 and calls["staged"] > 0
+            calls["staged"] = 0
+            got = pool.detect(pinned)
+            assert calls["staged"] == 0 and calls["direct"] > 0
+            mixed = pool.detect([pinned[i] if i % 3 else pageable[i] for i in range(22)])       # a chunk with one pageable image is staged
+        one = cfa.CenterFace(470, 730, dtype="bf16", max_batch=4)
+        sel = [i for i in range(22) if pageable[i].shape[:2] == (470, 730)]
+        calls["direct"] = calls["staged"] = 0
+        a = one.detect_batch([pageable[i] for i in sel])
+        b = one.detect_batch([pinned[i] for i in sel])
+        assert calls["direct"] > 0 and calls["staged"] > 0
+        one.close()
+    finally:
+        cfa.Engine.forward_images_enqueue, cfa.Engine.forward_enqueue, cfa.Engine.forward_resized_enqueue = real_i, real_f, real_r
+    assert sum(len(r[0]) for r in want) > 0
+    for w_, g_, m_ in zip(want, got, mixed):
+        assert np.array_equal(w_[0], g_[0]) and np.array_equal(w_[1], g_[1])
+        assert np.array_equal(w_[0], m_[0]) and np.array_equal(w_[1], m_[1])
+    for (d1, l1), (d2, l2), i in zip(a, b, sel):
+        assert np.array_equal(d1, d2) and np.array_equal(l1, l2)
+        assert np.array_equal(d1, want[i][0]) and np.array_equal(l1, want[i][1])
+    for k, arr in enumerate(pinned):
+        if k % 2 == 0:
+            cfa.unpin(arr)
+            assert not cfa.is_pinned(arr)
+
+
 @pytest.mark.parametrize("size,B", [((96, 128), 3), ((160, 224), 2), ((352, 640), 2), ((32, 32), 1), ((64, 416), 2)])
 def test_fused_neck_bit_equal_to_three_kernels(size, B):
     """cf_neck.hip (conv_last + up1 + up2 as one launch, the 1/32 and 1/16 maps only in LDS) performs the same arithmetic in the

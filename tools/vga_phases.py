@@ -13,12 +13,18 @@ def wrap(obj, name, key):
 pass
 wrap(c.Engine, "forward_enqueue", "enqueue")
 wrap(c.Engine, "forward_resized_enqueue", "enqueue_resized")
+wrap(c.Engine, "forward_images_enqueue", "enqueue_images")
 wrap(c.Engine, "decode_threshold", "decode_threshold")
 wrap(c.CenterFace, "_postprocess_many", "postprocess")
 rng = np.random.default_rng(0)
 shapes = [(480, 640), (640, 480), (640, 640), (448, 640), (640, 416)]
 imgs = [rng.integers(0, 256, shapes[i % 5] + (3,), dtype=np.uint8) for i in range(128)]
 pool = cfa.CenterFaceBuckets(dtype="bf16", max_batch=32, max_buckets=8)
+if os.environ.get("VGA_PINNED", "1") == "1":
+    pimgs = []
+    for im in imgs:
+        a = cfa.pinned_empty(im.shape); a[...] = im; pimgs.append(a)
+    imgs = pimgs
 pool.detect(imgs); pool.detect(imgs)
 T.clear()
 t0 = time.perf_counter()
