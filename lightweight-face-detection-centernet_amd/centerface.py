@@ -167,6 +167,13 @@ class Engine(object):
         else:
             self.last_B = len(arrs)
 
+    def _upload_addrs(self, addrs, h, w, keep):
+        """``upload_images`` for callers that have validated the batch already (CenterFaceBuckets: one raw size per chunk, page-locked
+        uint8 arrays): the host addresses go straight into the pointer table."""
+        self._keep_in = keep
+        self._chk(self._L.cf_upload_images(self._h, (C.c_void_p * len(addrs))(*addrs), len(addrs), int(h), int(w)))
+        self._uploaded_B = len(addrs)
+
     def upload_images(self, images):
         """First half of ``forward_images_enqueue`` (``cf_upload_images``): only the host -> device copies are enqueued."""
         self.forward_images_enqueue(images, upload_only=True)
@@ -661,6 +668,7 @@ class CenterFace(object):
 # ---- page-locked caller memory ------------------------------------------------------------------------------------------
 _pin_lock = threading.Lock()
 _pin_bases, _pin_sizes = [], {}          # sorted base addresses / base -> bytes, of everything pin() registered
+_pin_ids = {}                            # id(array object handed out by pin / pinned_empty) -> its address (the per-image fast path)
 
 
 def _unregister(addr):
@@ -690,10 +698,28 @@ def pin(arr):
     with _pin_lock:
         bisect.insort(_pin_bases, addr)
         _pin_sizes[addr] = arr.nbytes
+    _remember(arr)
     return arr
 
 
+def _remember(arr):
+    key = id(arr)
+    _pin_ids[key] = arr.ctypes.data
+    weakref.finalize(arr, _pin_ids.pop, key, None)
+
+
+def _direct_addr(im):
+    """Address of a page-locked C-contiguous uint8 array, else None (one dict probe for the objects pin / pinned_empty returned)."""
+    if type(im) is not np.ndarray or im.dtype != np.uint8:
+        return None
+    addr = _pin_ids.get(id(im))
+    if addr is not None and im.flags.c_contiguous:
+        return addr
+    return im.ctypes.data if is_pinned(im) else None
+
+
 def unpin(arr):
+    _pin_ids.pop(id(arr), None)
     _unregister(arr.ctypes.data)
 
 
@@ -705,7 +731,9 @@ def pinned_empty(shape, dtype=np.uint8):
     body = raw[off:off + max(n, 1)]
     pin(body)
     weakref.finalize(raw, _unregister, body.ctypes.data)           # views keep ``raw`` alive through .base
-    return body[:n].view(dtype).reshape(shape)
+    out = body[:n].view(dtype).reshape(shape)
+    _remember(out)
+    return out
 
 
 def is_pinned(arr):
@@ -804,19 +832,24 @@ class CenterFaceBuckets(object):
     def detect(self, imgs, threshold=0.2):
         del threshold                                              # ignored by the reference's decode (centerface.py:77)
         groups = {}                                                # network shape -> raw shape -> indices
+        net = self.__dict__.setdefault("_net_shape", {})           # raw (h, w) -> network (H, W): transform() once per size
+        addrs = []                                                 # per image: address if page-locked uint8 (pin / pinned_empty), else None
         for i, im in enumerate(imgs):
-            h, w = np.asarray(im).shape[:2]
-            H, W = CenterFace.transform(None, h, w)[:2]
-            groups.setdefault((H, W), {}).setdefault((h, w), []).append(i)
+            hw = im.shape[:2] if type(im) is np.ndarray else np.asarray(im).shape[:2]
+            HW = net.get(hw)
+            if HW is None:
+                HW = net[hw] = CenterFace.transform(None, hw[0], hw[1])[:2]
+            groups.setdefault(HW, {}).setdefault(hw, []).append(i)
+            addrs.append(_direct_addr(im))
         out = [None] * len(imgs)
         post = CenterFace.__new__(CenterFace)                      # only for _postprocess (no engine of its own)
         post.landmarks = self.landmarks
         keys = list(groups)
         for g0 in range(0, len(keys), self.max_buckets):           # at most max_buckets contexts alive at a time (LRU eviction)
-            self._run_buckets({k: groups[k] for k in keys[g0:g0 + self.max_buckets]}, imgs, out, post)
+            self._run_buckets({k: groups[k] for k in keys[g0:g0 + self.max_buckets]}, imgs, out, post, addrs)
         return out
 
-    def _run_buckets(self, groups, imgs, out, post):
+    def _run_buckets(self, groups, imgs, out, post, addrs):
         # one work list per bucket (engine): chunks of one raw size, at most max_batch images
         work = []
         for (H, W), raws in groups.items():
@@ -854,7 +887,7 @@ class CenterFaceBuckets(object):
         main_exc = None
         # Page-locked chunks are uploaded AHEAD: the copies of the next chunks (one per context at most) are enqueued before the
         # forward of this one, so the device's copy queue holds nothing but copies back to back and never stands behind a forward.
-        direct = [all(is_pinned(imgs[i]) and imgs[i].dtype == np.uint8 for i in idx) for _, _, idx in order]
+        direct = [all(addrs[i] is not None for i in idx) for _, _, idx in order]
         uploaded, up_next = {}, 0              # id(engine) -> index into ``order`` of the chunk whose copies are enqueued
 
         def upload_ahead(k):
@@ -862,10 +895,10 @@ class CenterFaceBuckets(object):
             nonlocal up_next
             up_next = max(up_next, k)
             while up_next < len(order) and up_next <= k + len(work):
-                e2, _, idx2 = order[up_next]
+                e2, hw2, idx2 = order[up_next]
                 if not direct[up_next] or id(e2) in uploaded:
                     return
-                e2.upload_images([imgs[i] for i in idx2])
+                e2._upload_addrs([addrs[i] for i in idx2], hw2[0], hw2[1], [imgs[i] for i in idx2])
                 uploaded[id(e2)] = up_next
                 up_next += 1
         try:

@@ -89,7 +89,7 @@ struct cf_ctx {
     // host inputs: H2D copies run on their own stream into two alternating staging buffers, so the copy of
     // batch i+1 overlaps the forward of batch i (PCIe-inclusive rate ~ max(copy, compute), not their sum)
     hipStream_t stream_in = nullptr, stream_in2 = nullptr; hipEvent_t ev_copy2 = nullptr; int buf_in2 = -1; int in_slot = 0; int in_slot_used = -1;
-    struct Upload { bool pending; int B, h, w, slot; bool small; } up = {false, 0, 0, 0, 0, false};      // cf_upload_images -> cf_forward_uploaded
+    struct Upload { bool pending; int B, h, w, slot; bool small, dual; } up = {false, 0, 0, 0, 0, false, false};      // cf_upload_images -> cf_forward_uploaded
     hipEvent_t ev_src_copy = nullptr, ev_src_free = nullptr; bool src_busy = false;     // src_stage: filled on stream_in, read by the resize on stream
     hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_slot_free[2] = {nullptr, nullptr}; bool slot_busy[2] = {false, false};
     bool weights_loaded = false;
@@ -1252,19 +1252,20 @@ int cf_upload_images(cf_ctx* c, const void* const* imgs, int B, int h, int w) {
             dev[b] = dp;
         }
     }
-    auto copy_in = [&](uint8_t* dst, hipStream_t cs) -> hipError_t {
-        if (!dev.empty()) return launch_upload_images(cs, dev.data(), dst, B, (long long)one);
-        // One DMA command per run of images that are adjacent in host memory (a caller's frame pool often is).  A command costs the
-        // engine 8-10 us of idle link on top of ~22 us per VGA image, so large batches alternate between the device's two copy streams
-        // (two engines): one's set-up hides under the other's transfer.  Stream 2 starts behind everything stream 1 has been asked to
-        // wait for, and stream 1 ends behind stream 2, so the caller's event on stream 1 covers both.
-        static const bool dual_ok = cf_ab_int("CF_COPY_DUAL", 1) != 0;
-        const bool dual = dual_ok && cs == c->stream_in && B > 1;
+    // One DMA command per run of images that are adjacent in host memory (a caller's frame pool often is).  A command costs the engine
+    // 8-10 us of idle link on top of ~22 us per VGA image, so large batches alternate between the device's two copy streams (two
+    // engines): one's set-up hides under the other's transfer.  Both streams wait for `after` (the buffer's last reader), each records
+    // its own event behind its copies, and the forward waits for both -- no stream waits for the other (every such hop costs ~0.1 ms).
+    bool dual = false;
+    auto copy_in = [&](uint8_t* dst, hipStream_t cs, hipEvent_t after) -> hipError_t {
         hipError_t e = hipSuccess;
+        if (after && (e = hipStreamWaitEvent(cs, after, 0)) != hipSuccess) return e;
+        if (!dev.empty()) return launch_upload_images(cs, dev.data(), dst, B, (long long)one);
+        static const bool dual_ok = cf_ab_int("CF_COPY_DUAL", 1) != 0;
+        dual = dual_ok && cs == c->stream_in && B > 1;
         if (dual) {
             if (!c->ev_copy2 && (e = hipEventCreateWithFlags(&c->ev_copy2, hipEventDisableTiming)) != hipSuccess) return e;
-            if ((e = hipEventRecord(c->ev_copy2, c->stream_in)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(c->stream_in2, c->ev_copy2, 0)) != hipSuccess) return e;
+            if (after && (e = hipStreamWaitEvent(c->stream_in2, after, 0)) != hipSuccess) return e;
         }
         int k = 0;
         for (int b = 0; b < B;) {
@@ -1274,10 +1275,8 @@ int cf_upload_images(cf_ctx* c, const void* const* imgs, int B, int h, int w) {
             if (e != hipSuccess) return e;
             b += n;
         }
-        if (dual) {
-            if ((e = hipEventRecord(c->ev_copy2, c->stream_in2)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(c->stream_in, c->ev_copy2, 0)) != hipSuccess) return e;
-        }
+        if (dual && k < 2) dual = false;                    // (everything was one run: the second stream got nothing)
+        if (dual && (e = hipEventRecord(c->ev_copy2, c->stream_in2)) != hipSuccess) return e;
         return hipSuccess;
     };
     if (h == c->H && w == c->W) {                           // network-sized: straight into an input slot, on the copy stream
@@ -1286,16 +1285,24 @@ int cf_upload_images(cf_ctx* c, const void* const* imgs, int B, int h, int w) {
         const int slot = small ? 0 : (c->in_slot ^= 1);
         hipStream_t cs = small ? c->stream : c->stream_in;
         uint8_t* dst = (uint8_t*)c->bufs[slot == 0 ? c->buf_in : c->buf_in2].p;
-        if (c->slot_busy[slot]) HIPCHK(c, hipStreamWaitEvent(cs, c->ev_slot_free[slot], 0));
-        HIPCHK(c, copy_in(dst, cs));
+        HIPCHK(c, copy_in(dst, cs, c->slot_busy[slot] ? c->ev_slot_free[slot] : nullptr));
         if (!small) HIPCHK(c, hipEventRecord(c->ev_copy[slot], cs));
-        c->up = {true, B, h, w, slot, small};
+        c->up = {true, B, h, w, slot, small, dual};
         return CF_OK;
     }
-    int r = src_stage_begin(c, one * B); if (r) return r;
-    HIPCHK(c, copy_in(c->src_stage, src_stage_stream(c, one * B)));
-    if (src_stage_stream(c, one * B) != c->stream) HIPCHK(c, hipEventRecord(c->ev_src_copy, c->stream_in));
-    c->up = {true, B, h, w, -1, false};
+    const size_t bytes = one * B;
+    if (!c->ev_src_copy) HIPCHK(c, hipEventCreateWithFlags(&c->ev_src_copy, hipEventDisableTiming));
+    if (!c->ev_src_free) HIPCHK(c, hipEventCreateWithFlags(&c->ev_src_free, hipEventDisableTiming));
+    if (c->src_stage_bytes < bytes) {
+        if (c->src_stage) HIPCHK(c, hipFree(c->src_stage));        // (a device-wide synchronisation: no reader is left)
+        c->src_stage = nullptr; c->src_stage_bytes = 0; c->src_busy = false;
+        HIPCHK(c, hipMalloc((void**)&c->src_stage, bytes));
+        c->src_stage_bytes = bytes;
+    }
+    hipStream_t cs = src_stage_stream(c, bytes);
+    HIPCHK(c, copy_in(c->src_stage, cs, c->src_busy && cs != c->stream ? c->ev_src_free : nullptr));
+    if (cs != c->stream) HIPCHK(c, hipEventRecord(c->ev_src_copy, cs));
+    c->up = {true, B, h, w, -1, false, dual};
     return CF_OK;
 }
 
@@ -1306,6 +1313,7 @@ int cf_forward_uploaded(cf_ctx* c) {
     const cf_ctx::Upload u = c->up;
     c->up.pending = false;
     const uint8_t* net_in;
+    if (u.dual) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy2, 0));
     if (u.slot >= 0) {
         if (!u.small) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy[u.slot], 0));
         c->in_slot_used = u.slot;

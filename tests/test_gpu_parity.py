@@ -992,6 +992,8 @@ def test_pinned_images_reach_the_gpu_without_staging_and_match():
             return f(self, *a, **k)
         return g
     cfa.Engine.forward_images_enqueue = count("direct", real_i)
+    real_u = cfa.Engine._upload_addrs
+    cfa.Engine._upload_addrs = count("direct", real_u)                 # CenterFaceBuckets' validated fast path into cf_upload_images
     cfa.Engine.forward_enqueue, cfa.Engine.forward_resized_enqueue = count("staged", real_f), count("staged", real_r)
     try:
         with cfa.CenterFaceBuckets(dtype="bf16", max_batch=4, max_buckets=4) as pool:
@@ -1010,6 +1012,7 @@ def test_pinned_images_reach_the_gpu_without_staging_and_match():
         one.close()
     finally:
         cfa.Engine.forward_images_enqueue, cfa.Engine.forward_enqueue, cfa.Engine.forward_resized_enqueue = real_i, real_f, real_r
+        cfa.Engine._upload_addrs = real_u
     assert sum(len(r[0]) for r in want) > 0
     for w_, g_, m_ in zip(want, got, mixed):
         assert np.array_equal(w_[0], g_[0]) and np.array_equal(w_[1], g_[1])

@@ -28,7 +28,9 @@ if os.environ.get("VGA_EVENTS", "1") == "1":
     for n in ("forward_enqueue", "forward_resized_enqueue", "forward_images_enqueue"):
         wrap_ev(n, 0, 1)
     wrap_ev("decode_threshold_enqueue", None, 2)
-for n in ("forward_enqueue", "forward_resized_enqueue", "forward_images_enqueue", "decode_threshold_enqueue", "decode_threshold", "set_rescale"):
+    wrap_ev("_upload_addrs", 0, 3)
+    wrap_ev("forward_uploaded", None, 1)
+for n in ("forward_enqueue", "forward_resized_enqueue", "forward_images_enqueue", "_upload_addrs", "forward_uploaded", "decode_threshold_enqueue", "decode_threshold", "set_rescale"):
     wrap(c.Engine, n)
 rng = np.random.default_rng(0)
 shapes = [(480, 640), (640, 480), (640, 640), (448, 640), (640, 416)]
