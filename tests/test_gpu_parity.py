@@ -1026,6 +1026,56 @@ def test_pinned_images_reach_the_gpu_without_staging_and_match():
             assert not cfa.is_pinned(arr)
 
 
+def test_upload_forward_split_and_its_error_paths():
+    """cf_upload_images / cf_forward_uploaded / cf_forward_images through the C ABI: the split call equals the block call bit for bit
+    (network-sized and resized, page-locked and pageable pointers, images adjacent in memory = one DMA run, a batch large enough for
+    the shared copy streams); a forward without an upload is CF_ESTATE, an upload replaced by another forward is gone, null images and
+    oversized batches are CF_EINVAL; cf_host_register rejects null / empty ranges."""
+    import ctypes as C
+    L = cfa._lib.lib()
+    rng = np.random.default_rng(17)
+    for (h, w, H, W, B) in [(64, 96, 64, 96, 3), (50, 70, 64, 96, 3), (640, 640, 640, 640, 9)]:
+        eng = cfa.Engine(H, W, max_batch=B, dtype="bf16")
+        block = cfa.pinned_empty((B, h, w, 3))                      # adjacent images: cf_upload_images coalesces them into one copy
+        block[...] = rng.integers(0, 256, block.shape, dtype=np.uint8)
+        loose = [block[b].copy() for b in range(B)]                 # pageable, separately allocated
+        pinned = [cfa.pin(block[b].copy()) for b in range(B)]       # page-locked, separately allocated
+        if (h, w) == (H, W):
+            eng.forward_enqueue(block)
+        else:
+            eng.forward_resized_enqueue(block)
+        want = eng.heads()
+        for imgs in ([block[b] for b in range(B)], loose, pinned):
+            eng.forward_images_enqueue(imgs)
+            got = eng.heads()
+            for k in want:
+                assert np.array_equal(want[k], got[k]), (k, h, w)
+            eng.upload_images(imgs)
+            eng.forward_uploaded()
+            got = eng.heads()
+            for k in want:
+                assert np.array_equal(want[k], got[k]), (k, h, w)
+        with pytest.raises(cfa._lib.CenterFaceError, match="without a cf_upload_images"):
+            eng.forward_uploaded()
+        eng.upload_images(pinned)
+        eng.forward_images_enqueue(loose)                           # another forward: the pending upload is dropped, not run later
+        with pytest.raises(cfa._lib.CenterFaceError, match="without a cf_upload_images"):
+            eng.forward_uploaded()
+        ptrs = (C.c_void_p * B)(*[a.ctypes.data for a in pinned])
+        assert L.cf_upload_images(eng._h, ptrs, B + 1, h, w) == -1
+        ptrs[B - 1] = None
+        assert L.cf_upload_images(eng._h, ptrs, B, h, w) == -1 and b"null pointer" in L.cf_last_error(eng._h)
+        assert L.cf_forward_uploaded(None) == -1 and L.cf_upload_images(None, ptrs, B, h, w) == -1
+        for a in pinned:
+            cfa.unpin(a)
+        eng.close()
+    assert L.cf_host_register(None, 16) == -1 and L.cf_host_unregister(None) == -1
+    buf = np.zeros(4096, np.uint8)
+    assert L.cf_host_register(C.c_void_p(buf.ctypes.data), 0) == -1
+    with pytest.raises(ValueError):
+        cfa.pin(np.zeros((4, 4), np.uint8)[:, ::2])                 # not C-contiguous
+
+
 @pytest.mark.parametrize("size,B", [((96, 128), 3), ((160, 224), 2), ((352, 640), 2), ((32, 32), 1), ((64, 416), 2)])
 def test_fused_neck_bit_equal_to_three_kernels(size, B):
     """cf_neck.hip (conv_last + up1 + up2 as one launch, the 1/32 and 1/16 maps only in LDS) performs the same arithmetic in the
