@@ -364,6 +364,155 @@ __global__ __launch_bounds__(NW * 64) void expdw_mxr_kernel(MbParams p) {
     }
     }
 }
+
+// Tile-persistent variant: a workgroup walks T consecutive tile units (tile x image) of ITS round of 32 hidden
+// channels: expand weights and the Toeplitz table are DMA'd once, and the first X fragments of unit t + 1 are loaded into registers
+// while the depthwise of unit t runs (the plain kernel starts every tile with a weight DMA + an exposed X load).
+template <int KS, int JX, int TOH, int TOW, int NW, int T>
+__global__ __launch_bounds__(NW * 64) void expdw_mxt_kernel(MbParams p) {
+    typedef Mx<KS, JX, TOH, TOW, NW, true> G;
+    constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, CP = G::CP, NSET = G::NSET, WXB = G::WXB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* E = smem;
+    char* Wst = smem + G::EBYTES;
+    char* Ats = Wst + WXB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.Wout + TOW - 1) / TOW, tiles = tiles_x * ((p.Hout + TOH - 1) / TOH);
+    const int units = tiles * p.B;
+    const int grp = blockIdx.y;
+    const int unit0 = blockIdx.x * T;
+    {
+        const char* srcx = (const char*)p.wexp + (size_t)grp * WXB;
+        for (int c = wave; c < WXB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(Wst + c * 1024), 16, 0, 0);
+        const char* srca = (const char*)p.wdw + (size_t)grp * G::ATB;
+        for (int c = wave; c < G::ATB / 1024; c += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+    auto load_x = [&](int b, int oy0, int ox0, int ib, u32x4* xf) -> bool {
+        const int ip = ib * 32 + pl;
+        const int ipc = ip < IPX ? ip : IPX - 1;
+        const int iy = ipc / IWP, ix = ipc - iy * IWP;
+        const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
+        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
+        if (p.xblock) {
+            const char* xb = (const char*)p.x + blk_off(((size_t)b * p.Hin + cy) * p.Win + cx, p.Cin / 8, h * JX);
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xf[j] = ld16(xb + j * 512);
+        } else {
+            const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
+            const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * ((unsigned)p.Cin * 2) + (unsigned)(h * JX * 16);
+#pragma unroll
+            for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
+        }
+        return ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+    };
+    auto mask_x = [&](u32x4* xf, bool valid) {
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            xf[j].x = valid ? xf[j].x : 0u; xf[j].y = valid ? xf[j].y : 0u; xf[j].z = valid ? xf[j].z : 0u; xf[j].w = valid ? xf[j].w : 0u;
+        }
+    };
+    auto unit_origin = [&](int unit, int& b, int& oy0, int& ox0) {
+        b = unit / tiles;
+        const int tile = unit - b * tiles;
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        oy0 = tyi * TOH; ox0 = txi * TOW;
+    };
+    static_assert(NIB >= NW, "every wave issues the X loads the wait below keeps in flight");
+    static constexpr SetMap<TOH, TOW, IWQ> kSets{};
+    const int kg = lane >> 4;
+
+    u32x4 xa[JX];
+    bool va = false;
+    int b, oy0, ox0;
+    if (unit0 >= units) return;
+    unit_origin(unit0, b, oy0, ox0);
+    va = load_x(b, oy0, ox0, wave, xa);
+    cf_sync_lds_dma_keep<JX>();              // weights / table landed for every wave
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const int unit = unit0 + t;
+        if (unit >= units) break;
+        mask_x(xa, va);
+        // ---- phase 1: expand + Swish -> quad cells
+        for (int ib = wave; ib < NIB; ib += NW) {
+            u32x4 xn[JX];
+            const bool more = ib + NW < NIB;
+            bool vn = false;
+            if (more) vn = load_x(b, oy0, ox0, ib + NW, xn);
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+            const char* wb = Wst + lane * 16;
+#pragma unroll
+            for (int j = 0; j < JX; ++j) {
+                const u32x4 wv = ld16(wb + j * 1024);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xa[j]),
+                                                            __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
+            }
+            char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)CP + pl * 8;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x2 u0, u1; u0.x = a[4 * tt]; u0.y = a[4 * tt + 1]; u1.x = a[4 * tt + 2]; u1.y = a[4 * tt + 3];
+                const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
+                u32x2 d;
+                d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
+                d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
+                *reinterpret_cast<u32x2*>(ecell + 2 * tt * CP) = d;
+            }
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < JX; ++j) xa[j] = xn[j];
+                mask_x(xa, vn);
+            }
+        }
+        __syncthreads();
+        // the next unit's first X fragments travel while this unit's depthwise runs
+        const int bc = b, oyc = oy0, oxc = ox0;
+        if (t + 1 < T && unit + 1 < units) {
+            unit_origin(unit + 1, b, oy0, ox0);
+            va = load_x(b, oy0, ox0, wave, xa);
+        }
+        // ---- phase 2: depthwise on the matrix cores + Swish
+        for (int set = wave; set < NSET; set += NW) {
+            const uint32_t e = kSets.v[set * 16 + (lane & 15)];
+            const int oy = (e >> 6) & 0x1ff, oxq = e & 63;
+            const bool live = (e & 0x8000u) == 0;
+            f32x4 acc[8];
+            const char* bb = E + (unsigned)(oy * IWQ + oxq) * (unsigned)CP + kg * 64;
+            mx_depthwise_lds<KS, IWQ, CP>(bb, Ats + lane * 8, acc);
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
+                    const f32x2 y = swish2_pre(u) * kNegLn23;
+                    acc[g][i] = y.x; acc[g][i + 1] = y.y;
+                }
+            const int gy = oyc + oy, gx0 = oxc + 4 * oxq;
+            if (!live || gy >= p.Hout) continue;
+            const size_t opix0 = ((size_t)bc * p.Hout + gy) * p.Wout + gx0;
+            const int chunk = grp * 4 + kg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (gx0 + i >= p.Wout) break;
+                u32x4 o;
+                o.x = packb(acc[0][i], acc[1][i]); o.y = packb(acc[2][i], acc[3][i]);
+                o.z = packb(acc[4][i], acc[5][i]); o.w = packb(acc[6][i], acc[7][i]);
+                const size_t opix = opix0 + i;
+                st16((char*)p.y + (p.yblock ? blk_off(opix, p.hid / 8, chunk) : (opix * p.hid + (size_t)chunk * 8) * 2), o);
+            }
+        }
+        __syncthreads();                      // every wave is done reading E before the next unit's expand overwrites it
+    }
+}
 #endif  // CF_EXPERIMENTS
 
 // ================================================================== fully fused block: expand -> depthwise -> project (+residual)
@@ -1256,6 +1405,27 @@ static hipError_t xmxr_launch_t(hipStream_t s, const MbParams& p) {
     return hipGetLastError();
 }
 #endif
+#ifdef CF_EXPERIMENTS
+template <int KS, int JX, int TOH, int TOW, int NW, int T>
+static hipError_t xmxt_launch_t(hipStream_t s, const MbParams& p) {
+    typedef Mx<KS, JX, TOH, TOW, NW, true> G;
+    auto kfn = expdw_mxt_kernel<KS, JX, TOH, TOW, NW, T>;
+    static thread_local bool configured_dev[32] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool& configured = configured_dev[dev & 31];
+    if (G::LDS > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int units = ((p.Wout + TOW - 1) / TOW) * ((p.Hout + TOH - 1) / TOH) * p.B;
+    dim3 grid((units + T - 1) / T, p.hid / 32, 1), blk(NW * 64);
+    set_kernel_tag("void cf::expdw_mxt_kernel<%d, %d, %d, %d, %d, %d>(cf::MbParams)", KS, JX, TOH, TOW, NW, T);
+    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
+    return hipGetLastError();
+}
+#endif
+#define XMT(V, KS, JX, TOH, TOW, NW, T) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, true>::LDS, &xmxt_launch_t<KS, JX, TOH, TOW, NW, T>}
 #define XMR(V, KS, JX, TOH, TOW, NW, R) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, true>::EBYTES + 2 * (Mx<KS, JX, TOH, TOW, NW, true>::WXB + Mx<KS, JX, TOH, TOW, NW, true>::ATB), &xmxr_launch_t<KS, JX, TOH, TOW, NW, R>}
 #define XMX(V, KS, JX, TOH, TOW, NW, AL) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, (AL != 0)>::LDS, &xmx_launch_t<KS, JX, TOH, TOW, NW, (AL != 0)>}
 static const MxEntry kXmxTable[] = {
@@ -1293,8 +1463,14 @@ static const MxEntry kXmxTable[] = {
     XMR(7, 5, 6, 10, 40, 4, 6),
     XMR(7, 5, 10, 20, 20, 4, 6),
     XMR(7, 3, 10, 20, 20, 4, 6),
+    // tile-persistent workgroups (expdw_mxt_kernel): T consecutive tile units per workgroup
+    XMT(8, 5, 4, 10, 40, 8, 2), XMT(8, 5, 6, 10, 40, 8, 2), XMT(8, 5, 10, 20, 20, 4, 2), XMT(8, 3, 10, 10, 20, 4, 2),
+    XMT(9, 5, 4, 10, 40, 8, 4), XMT(9, 5, 6, 10, 40, 8, 4), XMT(9, 5, 10, 20, 20, 4, 4), XMT(9, 3, 10, 10, 20, 4, 4),
+    XMT(10, 5, 4, 10, 40, 8, 8), XMT(10, 5, 6, 10, 40, 8, 8), XMT(10, 5, 10, 20, 20, 4, 8), XMT(10, 3, 10, 10, 20, 4, 8),
+    XMT(11, 5, 4, 10, 40, 8, 16), XMT(11, 5, 6, 10, 40, 8, 16), XMT(11, 5, 10, 20, 20, 4, 16), XMT(11, 3, 10, 10, 20, 4, 16),
 #endif  // CF_EXPERIMENTS
 };
+#undef XMT
 #undef XMX
 #undef XMR
 static const MxEntry* xmx_find(int k, int jx) {
