@@ -457,28 +457,42 @@ namespace {
 struct CopyStream { hipStream_t s = nullptr, s2 = nullptr; int refs = 0; };
 std::mutex g_copy_mu;
 CopyStream g_copy[64];
-hipError_t acquire_copy_stream(int device, hipStream_t* out, hipStream_t* out2) {
+// highest priority: HIP folds a process's streams onto a few hardware queues, and a copy stream that shares its queue with some context's
+// main stream stands behind that context's whole forward; streams of another priority get hardware queues of their own
+static hipError_t make_copy_stream(hipStream_t* out) {
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    static const bool prio = cf_ab_int("CF_COPY_PRIO", 1) != 0;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio ? hi : lo);
+    if (e != hipSuccess) *out = nullptr;
+    return e;
+}
+hipError_t acquire_copy_stream(int device, hipStream_t* out) {
     std::lock_guard<std::mutex> lk(g_copy_mu);
     CopyStream& cs = g_copy[device & 63];
-    if (!cs.s) {
-        // highest priority: HIP folds a process's streams onto a few hardware queues, and a copy stream that shares its queue with
-        // some context's main stream stands behind that context's whole forward (the uploads of a five-context VGA batch then span
-        // 4.5 ms instead of 2.2: profiles/r05_vga_pipeline.md); streams of another priority get a hardware queue of their own
-        int lo = 0, hi = 0;
-        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        static const bool prio = cf_ab_int("CF_COPY_PRIO", 1) != 0;
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&cs.s, hipStreamNonBlocking, prio ? hi : lo);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&cs.s2, hipStreamNonBlocking, prio ? hi : lo);
-        if (e != hipSuccess) { if (cs.s) hipStreamDestroy(cs.s); cs.s = cs.s2 = nullptr; return e; }
-    }
+    if (!cs.s) { hipError_t e = make_copy_stream(&cs.s); if (e != hipSuccess) return e; }
     ++cs.refs;
-    *out = cs.s; *out2 = cs.s2;
+    *out = cs.s;
+    return hipSuccess;
+}
+// The device's SECOND copy stream (cf_upload_images deals large batches of separately allocated images to both) is created at its first
+// use, not with the first context: one more stream at context-creation time changes which hardware queues the contexts' own streams
+// get, and the two-context ring lost its overlap to that (54.4 k -> 47.2 k img/s at 64 x 640x640; profiles/r05_vga_pipeline.md section 4).
+hipError_t second_copy_stream(int device, hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    CopyStream& cs = g_copy[device & 63];
+    if (!cs.s2) { hipError_t e = make_copy_stream(&cs.s2); if (e != hipSuccess) return e; }
+    *out = cs.s2;
     return hipSuccess;
 }
 void release_copy_stream(int device) {
     std::lock_guard<std::mutex> lk(g_copy_mu);
     CopyStream& cs = g_copy[device & 63];
-    if (--cs.refs == 0 && cs.s) { hipStreamDestroy(cs.s); hipStreamDestroy(cs.s2); cs.s = cs.s2 = nullptr; }
+    if (--cs.refs == 0 && cs.s) {
+        hipStreamDestroy(cs.s);
+        if (cs.s2) hipStreamDestroy(cs.s2);
+        cs.s = cs.s2 = nullptr;
+    }
 }
 }  // namespace
 
@@ -528,7 +542,7 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fwd, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
-    if ((e = acquire_copy_stream(c->device, &c->stream_in, &c->stream_in2)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
+    if ((e = acquire_copy_stream(c->device, &c->stream_in)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     for (int i = 0; i < 2; ++i) {
         if ((e = hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&c->ev_slot_free[i], hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
@@ -566,7 +580,7 @@ int cf_destroy(cf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->ev_fwd) hipEventDestroy(c->ev_fwd);
-    if (c->stream_in) { hipStreamSynchronize(c->stream_in); hipStreamSynchronize(c->stream_in2); release_copy_stream(c->device); }
+    if (c->stream_in) { hipStreamSynchronize(c->stream_in); if (c->stream_in2) hipStreamSynchronize(c->stream_in2); release_copy_stream(c->device); }
     for (int i = 0; i < 2; ++i) { if (c->ev_copy[i]) hipEventDestroy(c->ev_copy[i]); if (c->ev_slot_free[i]) hipEventDestroy(c->ev_slot_free[i]); }
     if (c->ev_copy2) hipEventDestroy(c->ev_copy2);
     if (c->ev_src_copy) hipEventDestroy(c->ev_src_copy);
@@ -1264,6 +1278,7 @@ int cf_upload_images(cf_ctx* c, const void* const* imgs, int B, int h, int w) {
         static const bool dual_ok = cf_ab_int("CF_COPY_DUAL", 1) != 0;
         dual = dual_ok && cs == c->stream_in && B > 1;
         if (dual) {
+            if (!c->stream_in2 && (e = second_copy_stream(c->device, &c->stream_in2)) != hipSuccess) return e;
             if (!c->ev_copy2 && (e = hipEventCreateWithFlags(&c->ev_copy2, hipEventDisableTiming)) != hipSuccess) return e;
             if (after && (e = hipStreamWaitEvent(c->stream_in2, after, 0)) != hipSuccess) return e;
         }
