@@ -282,6 +282,8 @@ int cf_get_streams(cf_ctx* ctx, void** main_stream, void** decode_stream);
  * old ones are destroyed, so they land on other queues; the context must be idle; captured graphs stay valid).  A host that
  * keeps two contexts calls the pair in a loop once, at start-up (EngineRing does). */
 int cf_streams_share_queue(cf_ctx* a, cf_ctx* b, int* shared);
+/* The same probe for any pair of the contexts' streams: which = 0 main, 1 decode, 2 the device's copy stream (a == b allowed). */
+int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, int* shared);
 int cf_reroll_streams(cf_ctx* ctx);
 /* hipGraph replay state: number of captured forward graphs held by the context, and how many
  * (input, format, batch) keys could not be captured and run as eager launches instead. */

@@ -326,6 +326,12 @@ class Engine(object):
         self._chk(self._L.cf_streams_share_queue(other._h, self._h, C.byref(sh)))
         return bool(sh.value)
 
+    def queue_shared(self, which, other, which_other):
+        """The same probe for any pair of streams (``cf_streams_share_queue_ex``): which = 0 main, 1 decode, 2 the device's copy stream."""
+        sh = C.c_int(0)
+        self._chk(self._L.cf_streams_share_queue_ex(other._h, int(which_other), self._h, int(which), C.byref(sh)))
+        return bool(sh.value)
+
     def reroll_streams(self):
         """Replace the main and decode streams by newly created ones (cf_reroll_streams).  The context must be idle."""
         self._chk(self._L.cf_reroll_streams(self._h))

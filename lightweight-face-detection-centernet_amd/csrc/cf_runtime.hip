@@ -540,7 +540,6 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
         return code;
     };
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fwd, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
     if ((e = acquire_copy_stream(c->device, &c->stream_in)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     for (int i = 0; i < 2; ++i) {
@@ -667,7 +666,7 @@ int cf_load_weights(cf_ctx* c, const cf_tensor_desc* tensors, int n) {
     // allocated until cf_destroy -- drain the streams, drop every graph, free the previous weight set.
     if (c->weights_loaded) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
         HIPCHK(c, hipStreamSynchronize(c->stream_in));
         c->dec_pending = false;
         for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
@@ -799,6 +798,16 @@ namespace {
 // are addressed from image img0, the depthwise tensor between the two launches always from the start of its buffer (every
 // sub-batch reuses the same few MB, which the Infinity Cache can keep between the write and the read)
 hipError_t launch_plan_at(cf_ctx* c, size_t i, const void* net_in, int in_format, int B, int* consumed);
+// The decode stream (device-output top-K decode and the gather records run on it, underneath the next forward) exists from its first use:
+// contexts that only ever decode on their main stream (threshold decode: CenterFace.__call__, CenterFaceBuckets) never own one, and every
+// stream a process creates takes a share of HIP's four hardware queues (five two-stream contexts: three main streams on one queue).
+int ensure_decode_stream(cf_ctx* c) {
+    if (c->stream2) return CF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    return CF_OK;
+}
+
 hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format, int B, int img0 = 0) {
     auto bp = [&](int id) -> void* { return id < 0 ? nullptr : c->bufs[id].p; };
     // byte offset of image img0 in a [B][H][W][C] tensor, NHWC or pixel-block order (whole 32-pixel blocks: checked by the caller)
@@ -956,7 +965,7 @@ int ensure_topk_ws(cf_ctx* c, int K) {
     }
     if (c->decK < K) {
         HIPCHK(c, hipStreamSynchronize(c->stream));           // a decode in flight may still write the old buffers
-        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
         if (c->gather_pending) { HIPCHK(c, hipEventSynchronize(c->ev_gather)); c->gather_pending = false; }   // ... and a gather may still read d_rec
         for (void* p : {(void*)c->d_dets, (void*)c->d_lms, (void*)c->d_inds, (void*)c->d_slot, (void*)c->big}) if (p) hipFree(p);
         c->d_dets = nullptr; c->d_lms = nullptr; c->d_inds = nullptr; c->d_slot = nullptr; c->d_rec = nullptr; c->big = nullptr; c->big_stride = 0;
@@ -1371,7 +1380,7 @@ int cf_get_resized_input(cf_ctx* c, void* out_u8, int B) {
 int cf_synchronize(cf_ctx* c) {
     if (!c) return CF_EINVAL;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     if (c->gather_pending) { HIPCHK(c, hipEventSynchronize(c->ev_gather)); c->gather_pending = false; }   // the communicator's stream
     return CF_OK;
 }
@@ -1406,6 +1415,7 @@ int cf_decode_topk(cf_ctx* c, int K, int use_reg, float* dets, float* lms, int64
     if (out_on_device) {
         static const bool overlap = cf_env_int("CF_DECODE_OVERLAP", 1) != 0;      // product switch
         if (!overlap) return enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds);
+        r = ensure_decode_stream(c); if (r) return r;
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
         r = enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds, nullptr, c->stream2);
         if (r) return r;
@@ -1777,33 +1787,42 @@ int cf_ctdet_loss(cf_ctx* c, const float* gt_hm, const uint8_t* reg_mask, const 
 int cf_get_streams(cf_ctx* c, void** main_stream, void** decode_stream) {
     if (!c) return CF_EINVAL;
     if (main_stream) *main_stream = (void*)c->stream;
-    if (decode_stream) *decode_stream = (void*)c->stream2;
+    if (decode_stream) { int r = ensure_decode_stream(c); if (r) return r; *decode_stream = (void*)c->stream2; }
     return CF_OK;
 }
 
-int cf_streams_share_queue(cf_ctx* a, cf_ctx* b, int* shared) {
-    if (!a || !b || !shared || a == b) return CF_EINVAL;
+static hipStream_t pick_stream(cf_ctx* c, int which) {
+    if (which == 1 && ensure_decode_stream(c) != CF_OK) return nullptr;
+    return which == 0 ? c->stream : which == 1 ? c->stream2 : which == 2 ? c->stream_in : nullptr;
+}
+
+// which_a / which_b: 0 = the context's main stream, 1 = its decode stream, 2 = the device's copy stream
+int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, int* shared) {
+    if (!a || !b || !shared) return CF_EINVAL;
+    hipStream_t sa = pick_stream(a, which_a), sb = pick_stream(b, which_b);
+    if (!sa || !sb) return a->fail(CF_EINVAL, "cf_streams_share_queue_ex: stream selector outside 0..2");
     if (a->device != b->device) { *shared = 0; return CF_OK; }
+    if (sa == sb) { *shared = 1; return CF_OK; }
     HIPCHK(a, hipSetDevice(a->device));
-    HIPCHK(a, hipStreamSynchronize(a->stream));
-    HIPCHK(a, hipStreamSynchronize(b->stream));
+    HIPCHK(a, hipStreamSynchronize(sa));
+    HIPCHK(a, hipStreamSynchronize(sb));
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     hipError_t err = hipSuccess;
     for (int i = 0; i < 3 && err == hipSuccess; ++i) err = hipEventCreate(&ev[i]);
-    // ~0.3 ms spin on a's main stream, then an empty kernel on b's: on one hardware queue the second waits for the first.
+    // ~0.3 ms spin on the first stream, then an empty kernel on the second: on one hardware queue the second waits for the first.
     // One timing sample can be fooled by anything else using the GPU: three probes, majority decides.
     int votes = 0;
     for (int rep = 0; rep < 3 && err == hipSuccess; ++rep) {
         auto step = [&](hipError_t e) { if (err == hipSuccess) err = e; };
-        step(hipEventRecord(ev[0], a->stream));
-        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, a->stream, (long long)30000);
+        step(hipEventRecord(ev[0], sa));
+        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, sa, (long long)30000);
         step(hipGetLastError());
-        step(hipEventRecord(ev[1], a->stream));
-        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, b->stream, (long long)0);
+        step(hipEventRecord(ev[1], sa));
+        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, sb, (long long)0);
         step(hipGetLastError());
-        step(hipEventRecord(ev[2], b->stream));
-        step(hipStreamSynchronize(a->stream));
-        step(hipStreamSynchronize(b->stream));
+        step(hipEventRecord(ev[2], sb));
+        step(hipStreamSynchronize(sa));
+        step(hipStreamSynchronize(sb));
         float ta = 0.0f, tb = 0.0f;
         step(hipEventElapsedTime(&ta, ev[0], ev[1]));
         step(hipEventElapsedTime(&tb, ev[0], ev[2]));
@@ -1816,16 +1835,22 @@ int cf_streams_share_queue(cf_ctx* a, cf_ctx* b, int* shared) {
     return CF_OK;
 }
 
+int cf_streams_share_queue(cf_ctx* a, cf_ctx* b, int* shared) {
+    if (!a || !b || !shared || a == b) return CF_EINVAL;
+    return cf_streams_share_queue_ex(a, 0, b, 0, shared);
+}
+
 int cf_reroll_streams(cf_ctx* c) {
     if (!c) return CF_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     HIPCHK(c, hipStreamSynchronize(c->stream_in));
     hipStream_t s1 = nullptr, s2 = nullptr;
     HIPCHK(c, hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));     // new ones first: the old ones still hold their queues
-    HIPCHK(c, hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-    hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2);
+    if (c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipStreamDestroy(c->stream);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     c->stream = s1; c->stream2 = s2;
     c->dec_pending = false; c->main_dec_pending = false;               // everything was drained above
     for (int i = 0; i < 2; ++i) c->slot_busy[i] = false;
@@ -2183,6 +2208,7 @@ int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, in
         // gather stream of the communicator (one per rank, shared by all its contexts): [wait that event] header, all-gather,
         // header check + unpack (-> D2H).  With ONE communicator and ONE stream per rank every rank enqueues its collectives in
         // the same order as long as it calls cf_gather_topk in the same order -- no cross-communicator ordering to get wrong.
+        r = ensure_decode_stream(c); if (r) return r;
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
         if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_gather, 0));
         r = enqueue_topk(c, B, K, use_reg, nullptr, nullptr, nullptr, nullptr, c->stream2, c->d_rec);
