@@ -58,8 +58,9 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--topk", type=int, default=100)
-    ap.add_argument("--depth", type=int, default=2,
-                    help="contexts per GPU used round-robin (batches in flight); 1 = a single context, every step on one stream chain")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="contexts per GPU used round-robin (batches in flight); 1 = a single context, every step on one stream chain; "
+                         "0 = automatic: 2, or 3 (decodes on the main streams) when a step is small (batch x size^2 <= 8 M pixels, e.g. four 1280x1280 images)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32_split"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_with_h2d / tolerance_mode / exact_fp32_mode / parity (profiling runs)")
@@ -490,7 +491,7 @@ def main():
     d_ins = [d_in] + [torch.from_numpy(np.random.default_rng(1000 * (j + 1) + rank).integers(0, 256, (B, S, S, 3), dtype=np.uint8)).to(dev)
                       for j in range(max(1, args.input_buffers) - 1)]
     d_in_ptrs = [t.data_ptr() for t in d_ins]
-    D = max(1, args.depth)
+    D = args.depth if args.depth > 0 else (3 if B * S * S <= (8 << 20) else 2)
     outs = [{"dets": torch.empty((B, K, 6), dtype=torch.float32, device=dev),
              "lms": torch.empty((B, K, 10), dtype=torch.float32, device=dev),
              "inds": torch.empty((B, K), dtype=torch.int64, device=dev),
@@ -692,7 +693,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "image": [S, S], "topk": K,
                        "parallelism": "dp%d" % world,
                        "contexts_per_gpu": len(engs), "input_buffers": len(d_ins),
-                       "gather": {"none": None, "cf": "cf_gather_topk (C ABI: decode on the context's decode stream, ONE ncclAllGather per step on the rank's one gather stream / one communicator; slot header validated on the device)",
+                       "gather": {"none": None, "cf": "cf_gather_topk (C ABI: decode on the context's %s stream, ONE ncclAllGather per step on the rank's one gather stream / one communicator; slot header validated on the device)" % ("decode" if len(engs) < 3 else "main"),
                                   "torch": "torch.distributed.all_gather_into_tensor"}[gather],
                        "gather_fallback": fallback},
             "windows": {"n": len(wins), "steps_each": args.steps, "median_ms": round(1e3 * med, 3),

@@ -58,6 +58,10 @@ extern "C" {
                                         collapsed heads fuse them, the neck output stays in LDS) */
 #define CF_FLAG_NO_NECK        16u   /* keep conv_last and the first two IDAUp stages as three kernels (bf16 fuses them
                                         into one: the 1/32 and 1/16 neck maps stay in LDS) */
+#define CF_FLAG_NO_DECODE_STREAM 32u  /* device-output decodes (cf_decode_topk, cf_gather_topk) run on the context's main stream instead of a
+                                      * decode stream of its own.  For hosts that keep THREE OR MORE contexts in flight (small batches):
+                                      * HIP has four hardware queues per process, and three main + three decode streams share them
+                                      * (configs[4] shard, B = 4: 3 contexts 9.5 k img/s with decode streams, 12.2 k without; 2 contexts 11.3 k) */
 
 typedef struct cf_ctx cf_ctx;
 

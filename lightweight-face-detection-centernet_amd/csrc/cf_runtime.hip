@@ -1414,7 +1414,7 @@ int cf_decode_topk(cf_ctx* c, int K, int use_reg, float* dets, float* lms, int64
     int r = ensure_topk_ws(c, K); if (r) return r;
     if (out_on_device) {
         static const bool overlap = cf_env_int("CF_DECODE_OVERLAP", 1) != 0;      // product switch
-        if (!overlap) return enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds);
+        if (!overlap || (c->flags & CF_FLAG_NO_DECODE_STREAM)) return enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds);
         r = ensure_decode_stream(c); if (r) return r;
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
         r = enqueue_topk(c, B, K, use_reg, dets, lms, (long long*)inds, nullptr, c->stream2);
@@ -2208,12 +2208,16 @@ int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, in
         // gather stream of the communicator (one per rank, shared by all its contexts): [wait that event] header, all-gather,
         // header check + unpack (-> D2H).  With ONE communicator and ONE stream per rank every rank enqueues its collectives in
         // the same order as long as it calls cf_gather_topk in the same order -- no cross-communicator ordering to get wrong.
-        r = ensure_decode_stream(c); if (r) return r;
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fwd, 0));
-        if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_gather, 0));
-        r = enqueue_topk(c, B, K, use_reg, nullptr, nullptr, nullptr, nullptr, c->stream2, c->d_rec);
+        hipStream_t ds = c->stream;                          // CF_FLAG_NO_DECODE_STREAM: the decode stays on the main stream
+        if (!(c->flags & CF_FLAG_NO_DECODE_STREAM)) {
+            r = ensure_decode_stream(c); if (r) return r;
+            ds = c->stream2;
+            HIPCHK(c, hipStreamWaitEvent(ds, c->ev_fwd, 0));
+        }
+        if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(ds, c->ev_gather, 0));
+        r = enqueue_topk(c, B, K, use_reg, nullptr, nullptr, nullptr, nullptr, ds, c->d_rec);
         if (r) return r;
-        HIPCHK(c, hipEventRecord(c->ev_dec, c->stream2));
+        HIPCHK(c, hipEventRecord(c->ev_dec, ds));
         c->dec_pending = true;
         HIPCHK(c, hipStreamWaitEvent(m->stream, c->ev_dec, 0));
     } else {

@@ -154,7 +154,7 @@ def test_bench_gather_fallback_records_the_path():
                          capture_output=True, text=True, timeout=600, cwd=REPO)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
-    assert d["config"]["gather_fallback"] is None and "cf_gather_topk" in d["config"]["gather"] and d["config"]["contexts_per_gpu"] == 2
+    assert d["config"]["gather_fallback"] is None and "cf_gather_topk" in d["config"]["gather"] and d["config"]["contexts_per_gpu"] == 3
 
 
 def test_bench_first_gather_deadline_covers_the_first_collective():
@@ -306,6 +306,19 @@ def test_engine_ring_matches_single_engine_bitwise():
     d, l, ind = ring.collect(t)
     assert np.array_equal(d, want[0][0]) and np.array_equal(l, want[0][1]) and np.array_equal(ind, want[0][2])
     ring.close()
+    # three contexts: the device-output decodes run on the main streams (CF_FLAG_NO_DECODE_STREAM; six streams would share HIP's four
+    # hardware queues) -- same results, three batches in flight
+    ring3 = cfa.EngineRing(S, S, depth=3, max_batch=8, dtype="bf16")
+    tickets = [ring3.submit(x, K=k) for x, k in zip(batches[:3], ks[:3])]
+    for j in (2, 0, 1):
+        d, l, ind = ring3.collect(tickets[j])
+        assert np.array_equal(d, want[j][0]) and np.array_equal(l, want[j][1]) and np.array_equal(ind, want[j][2]), j
+    ring3.close()
+    one = cfa.Engine(S, S, max_batch=8, dtype="bf16", decode_stream=False)
+    one.forward_enqueue(batches[0])
+    d, l, ind = one.decode_topk(ks[0])
+    assert np.array_equal(d, want[0][0]) and np.array_equal(ind, want[0][2])
+    one.close()
 
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
@@ -324,7 +337,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["unit"] == "images/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert "workload" in d["config"] and d["config"]["contexts_per_gpu"] == 2 and "model" not in d["config"]
+    # --depth 0 (default) = automatic: a step this small (4 x 160 x 160) runs on three contexts whose decodes stay on their main streams
+    assert "workload" in d["config"] and d["config"]["contexts_per_gpu"] == 3 and "model" not in d["config"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in r, k
