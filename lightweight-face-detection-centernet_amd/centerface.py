@@ -440,10 +440,14 @@ class EngineRing(object):
         o = self._out[slot]
         if o is None or o[0] < K:
             if o is not None:
-                for q in o[1:4]:
-                    e.device_free(q)
+                e.synchronize()
+                for q in o[4]:
+                    e.pinned_free(q)
             nb = e.max_batch
-            o = (int(K), e.device_alloc(nb * K * 6 * 4), e.device_alloc(nb * K * 10 * 4), e.device_alloc(nb * K * 8))
+            # the decode's "device" outputs are page-locked HOST buffers (device-visible): the select kernel writes the B x K rows over
+            # PCIe itself, and collect() is a wait + three numpy copies instead of three blocking device -> pageable transfers
+            raw = [e.pinned_raw(nb * K * 6 * 4)[0], e.pinned_raw(nb * K * 10 * 4)[0], e.pinned_raw(nb * K * 8)[0]]
+            o = (int(K), raw[0].value, raw[1].value, raw[2].value, raw)
         self._out[slot] = o
         e.decode_topk_device(K, o[1], o[2], o[3], use_reg=use_reg)
         return (slot, int(K), e.last_B)
@@ -453,10 +457,12 @@ class EngineRing(object):
         slot, K, B = ticket
         e, o = self.engines[slot], self._out[slot]
         # the decode wrote compact [B][K] rows (the K of its call) at the start of the slot's buffers
-        dets = np.empty((B, K, 6), np.float32); lms = np.empty((B, K, 10), np.float32); inds = np.empty((B, K), np.int64)
         e.synchronize()
-        e.memcpy_d2h(dets, o[1]); e.memcpy_d2h(lms, o[2]); e.memcpy_d2h(inds, o[3])
-        return dets, lms, inds
+
+        def host(addr, shape, dtype):
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_char * n).from_address(addr), dtype=dtype).reshape(shape).copy()
+        return host(o[1], (B, K, 6), np.float32), host(o[2], (B, K, 10), np.float32), host(o[3], (B, K), np.int64)
 
     def load_state_dict(self, sd):
         for e in self.engines:
@@ -468,11 +474,7 @@ class EngineRing(object):
 
     def close(self):
         for slot, e in enumerate(self.engines):
-            o = self._out[slot]
-            if o is not None and getattr(e, "_h", None):
-                for q in o[1:4]:
-                    e.device_free(q)
-            self._out[slot] = None
+            self._out[slot] = None                # (the page-locked output buffers belong to the engine: freed with it)
             e.close()
 
     def __del__(self):
