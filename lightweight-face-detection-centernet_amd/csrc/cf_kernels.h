@@ -250,7 +250,7 @@ struct NeckParams {
     void* y;              // up2 output [B][4h][4w][24] bf16 rows
     int B, h, w;          // h, w: the 1/32 map
 };
-hipError_t launch_neck(hipStream_t s, const NeckParams& p);
+hipError_t launch_neck(hipStream_t s, int dtype, const NeckParams& p);
 
 // ------------------------------------------------------------------ decode
 // D3: 3x3 peak test + top-K (radix select + bitonic sort) + gather: a multi-workgroup collect kernel + one select

@@ -1,4 +1,4 @@
-// conv_last + the first two IDAUp stages as ONE kernel (bf16 storage): three tiny launches (9 + 12 + 12 us at B = 64, each the
+// conv_last + the first two IDAUp stages as ONE kernel (bf16 storage; round 5: the split-bf16 tolerance mode too): three tiny launches (9 + 12 + 12 us at B = 64, each the
 // latency of its own K chain at every batch size) become one whose loads are all in flight from the start.
 //
 // Replaces, fused: conv_1x1_bn(320, 24) + Swish (model/centernet.py:179-184, :236) and IDAUp.forward for up1 and up2
@@ -13,56 +13,70 @@
 
 namespace cf {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
-
-__device__ __forceinline__ f32x16 nk_mma(f32x16 acc, const u32x4& w, const u32x4& x) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, w), __builtin_bit_cast(mfma_bf16x8, x), acc, 0, 0, 0);
-}
-
 constexpr int NK_CH = 4, NK_CW = 8;                 // conv_last cells per workgroup = one 32-pixel MFMA block
-constexpr int NK_N = 24, NK_PIT = 48;               // neck channels, bytes per cell in LDS
+constexpr int NK_N = 24;                            // neck channels
 
-// address of 16-byte chunk `chunk` of pixel m: rows [m][K] or pixel-block order [m / 32][K / 8][m % 32][8]
+// address of 16-byte chunk `chunk` of pixel m: rows [m][K] or pixel-block order [m / 32][chunks][m % 32][16 B]
 __device__ __forceinline__ const char* nk_chunk(const void* base, int blocked, size_t m, int NC, int chunk) {
     return blocked ? (const char*)base + blk_off(m, NC, chunk) : (const char*)base + (m * (size_t)NC + (size_t)chunk) * 16;
 }
 
-// bias (+ Swish | ReLU) (+ IDAUp up-branch from a low-resolution cell held in LDS) on this lane's 16 accumulators -> bf16 pieces;
-// `bias`, `upw`, `upb` are indexed by channel (LDS tables, or this lane's preloaded bias with ch0 = its first channel)
-template <int ACT, bool UP>
+// bias (+ Swish | ReLU) (+ IDAUp up-branch from a low-resolution cell held in LDS) on this lane's 16 accumulators -> 16-byte pieces
+// of the storage type (bf16: two pieces of eight channels, fp32 storage: four of four); `bias`, `upw`, `upb` are indexed by channel
+// (LDS tables, or this lane's preloaded bias with ch0 = its first channel)
+template <typename T, int ACT, bool UP>
 __device__ __forceinline__ void nk_epilogue(const f32x16& acc, int h, const float* bias, int ch0, const char* lowcell, const float* upw, const float* upb,
-                                            int tap, u32x4* out /*[2]*/) {
+                                            int tap, u32x4* out /*[16 / P]*/) {
+    constexpr int P = Elem<T>::PER16, ES = 16 / P;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int ch = h * 16 + g * 8;
+    for (int g = 0; g < 16 / P; ++g) {
+        const int ch = h * 16 + g * P;
         if (ch >= NK_N) break;
-        float v[8];
+        float v[P];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[g * 8 + e] + bias[ch - ch0 + e];
-        act_arr<ACT, 8>(v);
+        for (int e = 0; e < P; ++e) v[e] = acc[g * P + e] + bias[ch - ch0 + e];
+        act_arr<ACT, P>(v);
         if constexpr (UP) {
-            float r[8];
-            unpack16<bf16_t>(ld16(lowcell + ch * 2), r);
+            float r[P];
+            unpack16<T>(ld16(lowcell + ch * ES), r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += relu_f(r[e] * upw[tap * NK_N + ch + e] + upb[ch + e]);
+            for (int e = 0; e < P; ++e) v[e] += relu_f(r[e] * upw[tap * NK_N + ch + e] + upb[ch + e]);
         }
-        out[g] = pack16<bf16_t>(v);
+        out[g] = pack16<T>(v);
+    }
+}
+// the pieces of a cell: into an LDS tile / a row of the output tensor (`valid` false: zeros, tile only)
+template <typename T>
+__device__ __forceinline__ void nk_store(char* cell, int h, const u32x4* o, bool valid) {
+    constexpr int P = Elem<T>::PER16, ES = 16 / P;
+#pragma unroll
+    for (int g = 0; g < 16 / P; ++g) {
+        const int ch = h * 16 + g * P;
+        if (ch >= NK_N) break;
+        st16(cell + ch * ES, valid ? o[g] : zero16());
     }
 }
 
+// T = bf16_t (round 3) or sp32_t (round 5: the tolerance mode; fp32 tiles, every product through CfMma<sp32_t>'s pair steps in
+// pw_kernel<sp32_t>'s order)
+template <typename T>
 __global__ __launch_bounds__(256) void neck_kernel(NeckParams p) {
-    __shared__ __attribute__((aligned(16))) char Cs[NK_CH * NK_CW * NK_PIT];            // conv_last tile (4 x 8 cells), bf16
-    __shared__ __attribute__((aligned(16))) char U1[4 * NK_CH * NK_CW * NK_PIT];        // up1 tile (8 x 16 cells), bf16
-    __shared__ float Tb[2 * (NK_N + 4 * NK_N + NK_N)];                                  // b1, upw1, upb1, b2, upw2, upb2
+    constexpr int P = Elem<T>::PER16, ES = 16 / P, PIT = NK_N * ES;
+    constexpr bool WIDE = ES == 4;                         // fp32 storage: twice the fragments per K chain
+    __shared__ __attribute__((aligned(16))) char Cs[NK_CH * NK_CW * PIT];            // conv_last tile (4 x 8 cells)
+    __shared__ __attribute__((aligned(16))) char U1[4 * NK_CH * NK_CW * PIT];        // up1 tile (8 x 16 cells)
+    __shared__ float Tb[2 * (NK_N + 4 * NK_N + NK_N)];                               // b1, upw1, upb1, b2, upw2, upb2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 31, h = lane >> 5;
     const int cx0 = blockIdx.x * NK_CW, cy0 = blockIdx.y * NK_CH, b = blockIdx.z;
     const int h1 = 2 * p.h, w1 = 2 * p.w, h2 = 4 * p.h, w2 = 4 * p.w;
-    constexpr int NC0 = 40, NCh0 = 20;                     // K = 320
-    constexpr int NC1 = 12, NCh1 = 6;                      // K = 96
-    constexpr int NC2 = 4, NCh2 = 2;                       // K = 32
+    constexpr int NC0 = 320 / P, NCh0 = NC0 / 2;           // 16-byte chunks of a pixel's K values, per lane half
+    constexpr int NC1 = 96 / P, NCh1 = NC1 / 2;
+    constexpr int NC2 = 32 / P, NCh2 = NC2 / 2;
+    constexpr int KB = WIDE ? 8 : 5;                       // conv_last weight fragments per batch (even in the split mode: pair steps)
     constexpr int TN = 6 * NK_N;                           // floats per stage in Tb
+    static_assert(NCh0 % KB == 0 && (!WIDE || (NCh1 % 2 == 0 && NCh2 % 2 == 0)), "K chains in whole batches / pairs");
 
     // ---- every global load of the workgroup is issued up front: the three K chains and their epilogue tables cost one memory
     //      round trip instead of eight (the chain of dependent loads was the kernel time at every batch size)
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(256) void neck_kernel(NeckParams p) {
     const int gy1 = 2 * cy0 + uy, gx1 = 2 * cx0 + ux;
     const bool ok1 = gy1 < h1 && gx1 < w1;
     u32x4 x1[NCh1], wq1[NCh1], wq2[NCh2];
-    {
+    auto load_p2 = [&]() {
         const size_t m1 = ((size_t)b * h1 + min(gy1, h1 - 1)) * w1 + min(gx1, w1 - 1);
 #pragma unroll
         for (int j = 0; j < NCh1; ++j) {
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) void neck_kernel(NeckParams p) {
         }
 #pragma unroll
         for (int j = 0; j < NCh2; ++j) wq2[j] = ld16((const char*)p.w2 + ((size_t)j * 64 + lane) * 16);
-    }
+    };
     // phase 3: wave w owns pixel blocks 4 w .. 4 w + 3 of the 16x32 up2 tile (block = one tile row of 32 cells); wave 0 issues
     // these loads after its conv_last chain (registers), the other waves -- idle until the first barrier -- now
     u32x4 x2[4][NCh2];
@@ -100,6 +114,7 @@ __global__ __launch_bounds__(256) void neck_kernel(NeckParams p) {
             for (int j = 0; j < NCh2; ++j) x2[t][j] = ld16(nk_chunk(p.skip2, p.skip2_blk, m2[t], NC2, h * NCh2 + j));
         }
     };
+    if (!WIDE || wave != 0) load_p2();                     // (fp32 storage: wave 0's conv_last fragments alone are 160 registers)
     if (wave != 0) load_x2();
 
     // ---- phase 1 (wave 0): conv_last on the 4x8 cells, bias + Swish -> LDS
@@ -116,24 +131,22 @@ __global__ __launch_bounds__(256) void neck_kernel(NeckParams p) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        u32x4 wq[2][5];                                    // weight fragments (L2-resident): batch k + 1 in flight under the MFMAs of batch k
+        u32x4 wq[2][KB];                                   // weight fragments (L2-resident): batch k + 1 in flight under the MFMAs of batch k
 #pragma unroll
-        for (int u = 0; u < 5; ++u) wq[0][u] = ld16((const char*)p.w0 + ((size_t)u * 64 + lane) * 16);
+        for (int u = 0; u < KB; ++u) wq[0][u] = ld16((const char*)p.w0 + ((size_t)u * 64 + lane) * 16);
 #pragma unroll
-        for (int k = 0; k < NCh0 / 5; ++k) {
-            if (k + 1 < NCh0 / 5) {
+        for (int k = 0; k < NCh0 / KB; ++k) {
+            if (k + 1 < NCh0 / KB) {
 #pragma unroll
-                for (int u = 0; u < 5; ++u) wq[(k + 1) & 1][u] = ld16((const char*)p.w0 + ((size_t)((k + 1) * 5 + u) * 64 + lane) * 16);
+                for (int u = 0; u < KB; ++u) wq[(k + 1) & 1][u] = ld16((const char*)p.w0 + ((size_t)((k + 1) * KB + u) * 64 + lane) * 16);
             }
-#pragma unroll
-            for (int u = 0; u < 5; ++u) acc = nk_mma(acc, wq[k & 1][u], x0[k * 5 + u]);
+            mma_chain<T, KB>(acc, [&](int u) -> const u32x4& { return wq[k & 1][u]; }, [&](int u) -> const u32x4& { return x0[k * KB + u]; });
         }
+        if (WIDE) load_p2();
         load_x2();
-        u32x4 o[2];
-        nk_epilogue<1, false>(acc, h, bb, h * 16, nullptr, nullptr, nullptr, 0, o);
-        if (!ok0) { o[0] = zero16(); o[1] = zero16(); }
-        st16(Cs + pl * NK_PIT + h * 32, o[0]);
-        if (h == 0) st16(Cs + pl * NK_PIT + 16, o[1]);
+        u32x4 o[16 / P];
+        nk_epilogue<T, 1, false>(acc, h, bb, h * 16, nullptr, nullptr, nullptr, 0, o);
+        nk_store<T>(Cs + pl * PIT, h, o, ok0);
     }
     __syncthreads();
 
@@ -142,14 +155,11 @@ __global__ __launch_bounds__(256) void neck_kernel(NeckParams p) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < NCh1; ++j) acc = nk_mma(acc, wq1[j], x1[j]);
+        mma_chain<T, NCh1>(acc, [&](int j) -> const u32x4& { return wq1[j]; }, [&](int j) -> const u32x4& { return x1[j]; });
         const int tap = ((uy & 1) << 1) | (ux & 1);         // tile origins are even: local parity = map parity
-        u32x4 o[2];
-        nk_epilogue<2, true>(acc, h, Tb, 0, Cs + ((uy >> 1) * NK_CW + (ux >> 1)) * NK_PIT, Tb + NK_N, Tb + 5 * NK_N, tap, o);
-        if (!ok1) { o[0] = zero16(); o[1] = zero16(); }
-        st16(U1 + o1 * NK_PIT + h * 32, o[0]);
-        if (h == 0) st16(U1 + o1 * NK_PIT + 16, o[1]);
+        u32x4 o[16 / P];
+        nk_epilogue<T, 2, true>(acc, h, Tb, 0, Cs + ((uy >> 1) * NK_CW + (ux >> 1)) * PIT, Tb + NK_N, Tb + 5 * NK_N, tap, o);
+        nk_store<T>(U1 + o1 * PIT, h, o, ok1);
     }
     __syncthreads();
 
@@ -159,25 +169,27 @@ __global__ __launch_bounds__(256) void neck_kernel(NeckParams p) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < NCh2; ++j) acc = nk_mma(acc, wq2[j], x2[t][j]);
+        mma_chain<T, NCh2>(acc, [&](int j) -> const u32x4& { return wq2[j]; }, [&](int j) -> const u32x4& { return x2[t][j]; });
         const int oy = wave * 4 + t, ox = pl;
         const int tap = ((oy & 1) << 1) | (ox & 1);
-        u32x4 o[2];
-        nk_epilogue<2, true>(acc, h, Tb + TN, 0, U1 + ((oy >> 1) * (2 * NK_CW) + (ox >> 1)) * NK_PIT, Tb + TN + NK_N, Tb + TN + 5 * NK_N, tap, o);
-        if (ok2[t]) {
-            char* dst = (char*)p.y + m2[t] * (size_t)(NK_N * 2);
-            st16(dst + h * 32, o[0]);
-            if (h == 0) st16(dst + 16, o[1]);
-        }
+        u32x4 o[16 / P];
+        nk_epilogue<T, 2, true>(acc, h, Tb + TN, 0, U1 + ((oy >> 1) * (2 * NK_CW) + (ox >> 1)) * PIT, Tb + TN + NK_N, Tb + TN + 5 * NK_N, tap, o);
+        if (ok2[t]) nk_store<T>((char*)p.y + m2[t] * (size_t)PIT, h, o, true);
     }
 }
 
-hipError_t launch_neck(hipStream_t s, const NeckParams& p) {
+hipError_t launch_neck(hipStream_t s, int dtype, const NeckParams& p) {
     if (p.B <= 0) return hipSuccess;
     dim3 grid((p.w + NK_CW - 1) / NK_CW, (p.h + NK_CH - 1) / NK_CH, p.B), blk(256);
-    set_kernel_tag("cf::neck_kernel(cf::NeckParams)");
-    hipLaunchKernelGGL(neck_kernel, grid, blk, 0, s, p);
+    if (dtype == 1) {
+        set_kernel_tag("void cf::neck_kernel<%s>(cf::NeckParams)", type_tag<bf16_t>());
+        hipLaunchKernelGGL(neck_kernel<bf16_t>, grid, blk, 0, s, p);
+    } else if (dtype == 2) {
+        set_kernel_tag("void cf::neck_kernel<%s>(cf::NeckParams)", type_tag<sp32_t>());
+        hipLaunchKernelGGL(neck_kernel<sp32_t>, grid, blk, 0, s, p);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -313,7 +313,7 @@ void build_plan(cf_ctx* c) {
         c->ops[ih].macs += c->ops[iu].macs;
     }
     static const bool neck_off = cf_ab_int("CF_NECK", 1) == 0;      // A/B in an experiments build; the product switch is CF_FLAG_NO_NECK
-    if (fuse && !neck_off && !(c->flags & CF_FLAG_NO_NECK) && c->dtype == CF_BF16 && cin == 320) {
+    if (fuse && !neck_off && !(c->flags & CF_FLAG_NO_NECK) && (c->dtype == CF_BF16 || c->dtype == CF_F32_SPLIT) && cin == 320) {
         int icl = -1, iu1 = -1, iu2 = -1;
         for (size_t i = 0; i < c->ops.size(); ++i) {
             if (c->ops[i].name == "conv_last") icl = (int)i;
@@ -828,7 +828,7 @@ hipError_t launch_op(cf_ctx* c, const Op& op, const void* net_in, int in_format,
         p.w1 = u1.wp; p.b1 = u1.bias; p.upw1 = u1.upw; p.upb1 = u1.upb;
         p.w2 = op.wp; p.b2 = op.bias; p.upw2 = op.upw; p.upb2 = op.upb;
         p.y = bp(op.out); p.B = B; p.h = cl.Hout; p.w = cl.Wout;
-        return launch_neck(c->stream, p);
+        return launch_neck(c->stream, c->dtype, p);
     }
     switch (op.kind) {
         case OP_STEM: {

@@ -1076,16 +1076,17 @@ def test_upload_forward_split_and_its_error_paths():
         cfa.pin(np.zeros((4, 4), np.uint8)[:, ::2])                 # not C-contiguous
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32_split"])
 @pytest.mark.parametrize("size,B", [((96, 128), 3), ((160, 224), 2), ((352, 640), 2), ((32, 32), 1), ((64, 416), 2)])
-def test_fused_neck_bit_equal_to_three_kernels(size, B):
+def test_fused_neck_bit_equal_to_three_kernels(size, B, dtype):
     """cf_neck.hip (conv_last + up1 + up2 as one launch, the 1/32 and 1/16 maps only in LDS) performs the same arithmetic in the
-    same order as three pw_kernel launches: the up2 tensor and everything after it are bit-identical (maps that are not multiples
+    same order as three pw_kernel launches (bf16, and the split-bf16 tolerance mode with fp32 tiles): the up2 tensor and everything after it are bit-identical (maps that are not multiples
     of the 2x4-cell tile, a one-cell map, batches)."""
     H, W = size
     rng = np.random.default_rng(H * 7 + W)
     x = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
-    ef = cfa.Engine(H, W, max_batch=B, dtype="bf16", neck=True)
-    e3 = cfa.Engine(H, W, max_batch=B, dtype="bf16", neck=False)
+    ef = cfa.Engine(H, W, max_batch=B, dtype=dtype, neck=True)
+    e3 = cfa.Engine(H, W, max_batch=B, dtype=dtype, neck=False)
     pf, p3 = ef.plan(), e3.plan()
     assert [o["name"] for o in pf if not o["fused_away"]].count("conv_last+up1+up2") == 1
     assert any(o["name"] == "conv_last" and not o["fused_away"] for o in p3)
