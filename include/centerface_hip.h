@@ -288,6 +288,12 @@ int cf_get_streams(cf_ctx* ctx, void** main_stream, void** decode_stream);
 int cf_streams_share_queue(cf_ctx* a, cf_ctx* b, int* shared);
 /* The same probe for any pair of the contexts' streams: which = 0 main, 1 decode, 2 the device's copy stream (a == b allowed). */
 int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, int* shared);
+/* Put the main streams (and the decode streams of contexts created without CF_FLAG_NO_DECODE_STREAM) of n idle contexts of one device on
+ * pairwise different hardware queues: candidates are created and probed one after the other, those that land on a used queue are kept as
+ * ballast until the end, so the runtime's fewest-streams-first placement moves on (a create-then-destroy re-roll can come back to the same
+ * queue forever in a process with unevenly loaded queues).  Main streams first; at most four queues exist.  *n_distinct (may be NULL) =
+ * streams placed on a queue of their own.  Captured graphs stay valid.  What EngineRing calls at construction. */
+int cf_spread_streams(cf_ctx** ctxs, int n, int* n_distinct);
 int cf_reroll_streams(cf_ctx* ctx);
 /* hipGraph replay state: number of captured forward graphs held by the context, and how many
  * (input, format, batch) keys could not be captured and run as eager launches instead. */

@@ -415,13 +415,20 @@ class EngineRing(object):
         # process created before.  When the MAIN streams of two contexts land on one queue their forwards run strictly one
         # after the other (42.0k img/s instead of 45.8k at 64 x 640x640, 4 of 5 start-up arrangements tried): test the pairs
         # and re-create the streams of the later context until no two main streams share a queue (profiles/r02_ablation.md).
+        # Round 5: the decode streams count too (a decode stream on the other context's main queue takes the overlap away just the same), and
+        # a ring created after other contexts of the process (bench.py's tolerance-mode ring) could not be fixed by re-rolling: it ran at its
+        # one-context rate.  If any two of the ring's streams share a queue, cf_spread_streams places them all afresh (candidates probed one by
+        # one, misplaced ones kept as ballast).  A ring whose streams are fine as created is left alone: the placement the runtime gives the
+        # first contexts of a process is also the fastest one measured (54.1 k against 51.9 k img/s after a spread, no queue shared in either).
         self.queue_rerolls = 0
-        for i in range(1, len(self.engines)):
-            for _ in range(8):
-                if not any(self.engines[i].shares_queue_with(self.engines[j]) for j in range(i)):
-                    break
-                self.engines[i].reroll_streams()
-                self.queue_rerolls += 1
+        which = (0, 1) if engine_kwargs["decode_stream"] else (0,)
+        streams = [(e, w) for e in self.engines for w in which]
+        clash = any(a[0].queue_shared(a[1], b[0], b[1]) for k, a in enumerate(streams) for b in streams[:k])
+        if clash:
+            hs = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+            nd = C.c_int(0)
+            self.engines[0]._chk(self.engines[0]._L.cf_spread_streams(hs, len(self.engines), C.byref(nd)))
+            self.queue_rerolls = 1
         self.depth = int(depth)
         self._n = 0
         self._out = [None] * self.depth               # per slot: (K, dets_ptr, lms_ptr, inds_ptr, B)

@@ -1796,21 +1796,15 @@ static hipStream_t pick_stream(cf_ctx* c, int which) {
     return which == 0 ? c->stream : which == 1 ? c->stream2 : which == 2 ? c->stream_in : nullptr;
 }
 
-// which_a / which_b: 0 = the context's main stream, 1 = its decode stream, 2 = the device's copy stream
-int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, int* shared) {
-    if (!a || !b || !shared) return CF_EINVAL;
-    hipStream_t sa = pick_stream(a, which_a), sb = pick_stream(b, which_b);
-    if (!sa || !sb) return a->fail(CF_EINVAL, "cf_streams_share_queue_ex: stream selector outside 0..2");
-    if (a->device != b->device) { *shared = 0; return CF_OK; }
+// Do two streams sit on one hardware queue?  ~0.3 ms spin on the first, then an empty kernel on the second: on one queue the second waits
+// for the first.  One timing sample can be fooled by anything else using the GPU: three probes, majority decides.  Both streams idle.
+static int streams_share(cf_ctx* a, hipStream_t sa, hipStream_t sb, int* shared) {
     if (sa == sb) { *shared = 1; return CF_OK; }
-    HIPCHK(a, hipSetDevice(a->device));
     HIPCHK(a, hipStreamSynchronize(sa));
     HIPCHK(a, hipStreamSynchronize(sb));
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     hipError_t err = hipSuccess;
     for (int i = 0; i < 3 && err == hipSuccess; ++i) err = hipEventCreate(&ev[i]);
-    // ~0.3 ms spin on the first stream, then an empty kernel on the second: on one hardware queue the second waits for the first.
-    // One timing sample can be fooled by anything else using the GPU: three probes, majority decides.
     int votes = 0;
     for (int rep = 0; rep < 3 && err == hipSuccess; ++rep) {
         auto step = [&](hipError_t e) { if (err == hipSuccess) err = e; };
@@ -1830,8 +1824,66 @@ int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, in
         if (rep == 1 && (votes == 0 || votes == 2)) break;        // decided after two agreeing probes
     }
     for (hipEvent_t e : ev) if (e) hipEventDestroy(e);          // on every path
-    if (err != hipSuccess) return a->fail(CF_EHIP, "cf_streams_share_queue: %s", hipGetErrorString(err));
+    if (err != hipSuccess) return a->fail(CF_EHIP, "hardware-queue probe: %s", hipGetErrorString(err));
     *shared = votes >= 2 ? 1 : 0;
+    return CF_OK;
+}
+
+// which_a / which_b: 0 = the context's main stream, 1 = its decode stream, 2 = the device's copy stream
+int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, int* shared) {
+    if (!a || !b || !shared) return CF_EINVAL;
+    hipStream_t sa = pick_stream(a, which_a), sb = pick_stream(b, which_b);
+    if (!sa || !sb) return a->fail(CF_EINVAL, "cf_streams_share_queue_ex: stream selector outside 0..2");
+    if (a->device != b->device) { *shared = 0; return CF_OK; }
+    HIPCHK(a, hipSetDevice(a->device));
+    return streams_share(a, sa, sb, shared);
+}
+
+// Put the main streams -- and the decode streams, for contexts that use one -- of n contexts of ONE device on pairwise different hardware
+// queues.  The runtime binds a new stream to the queue with the fewest streams on it (of at most four per priority), so what a context
+// gets depends on everything the process created before, and a create-then-destroy re-roll can land on the same crowded queue forever
+// (bench.py's second and third ring: both main streams on one queue through 12 re-rolls, the ring worth nothing).  Here candidates are
+// created one after the other and probed against the streams already chosen: a candidate on a new queue is adopted, one on a used queue
+// is kept alive as BALLAST until the end -- it weighs its queue down, so the next candidate goes elsewhere.  Main streams are placed
+// first.  *n_distinct = streams that ended up on queues of their own (= wanted when it worked).  All contexts idle.
+int cf_spread_streams(cf_ctx** ctxs, int n, int* n_distinct) {
+    if (!ctxs || n < 1 || n > 16) return CF_EINVAL;
+    for (int i = 0; i < n; ++i) if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device) return CF_EINVAL;
+    cf_ctx* c0 = ctxs[0];
+    HIPCHK(c0, hipSetDevice(c0->device));
+    struct Want { cf_ctx* c; bool decode; };
+    std::vector<Want> want;
+    for (int i = 0; i < n; ++i) want.push_back({ctxs[i], false});
+    for (int i = 0; i < n; ++i) if (!(ctxs[i]->flags & CF_FLAG_NO_DECODE_STREAM)) want.push_back({ctxs[i], true});
+    for (int i = 0; i < n; ++i) { int r = cf_synchronize(ctxs[i]); if (r) return r; }
+    std::vector<hipStream_t> chosen, ballast;
+    int rc = CF_OK;
+    for (int tries = 0; tries < 48 && chosen.size() < want.size() && chosen.size() < 4; ++tries) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, s, (long long)0);       // first use: the stream has its queue now
+        (void)hipStreamSynchronize(s);
+        bool clash = false;
+        for (hipStream_t t : chosen) {
+            int sh = 0;
+            rc = streams_share(c0, t, s, &sh);
+            if (rc) break;
+            if (sh) { clash = true; break; }
+        }
+        if (rc) { hipStreamDestroy(s); break; }
+        (clash ? ballast : chosen).push_back(s);
+    }
+    for (hipStream_t s : ballast) hipStreamDestroy(s);
+    if (rc) { for (hipStream_t s : chosen) hipStreamDestroy(s); return rc; }
+    for (size_t k = 0; k < chosen.size(); ++k) {                  // adopt: the contexts are idle (synchronised above)
+        cf_ctx* c = want[k].c;
+        hipStream_t& slot = want[k].decode ? c->stream2 : c->stream;
+        if (slot) hipStreamDestroy(slot);
+        slot = chosen[k];
+        c->dec_pending = false; c->main_dec_pending = false;
+        for (int i = 0; i < 2; ++i) c->slot_busy[i] = false;
+    }
+    if (n_distinct) *n_distinct = (int)chosen.size();
     return CF_OK;
 }
 
