@@ -503,7 +503,8 @@ class CenterFace(object):
         self.nms_thresh = nms_thresh
         self.max_dets = max_dets
         self.device = device
-        self._engine_kw = dict(max_batch=max_batch, dtype=dtype, device=device, weights=weights, collapse_heads=collapse_heads)
+        # (threshold decodes run on the main stream: these contexts never need a decode stream of their own)
+        self._engine_kw = dict(max_batch=max_batch, dtype=dtype, device=device, weights=weights, collapse_heads=collapse_heads, decode_stream=False)
         self.engine = Engine(self.img_h_new, self.img_w_new, **self._engine_kw)
         self._engine2 = None                      # second context of detect_stream, created on first use
 
@@ -601,10 +602,9 @@ class CenterFace(object):
         del threshold
         if self._engine2 is None:
             self._engine2 = Engine(self.img_h_new, self.img_w_new, **self._engine_kw)
-            for _ in range(8):                    # keep the two main streams on different hardware queues (see EngineRing)
-                if not self._engine2.shares_queue_with(self.engine):
-                    break
-                self._engine2.reroll_streams()
+            if self._engine2.shares_queue_with(self.engine):     # keep the two main streams on different hardware queues (see EngineRing)
+                hs = (C.c_void_p * 2)(self.engine._h, self._engine2._h)
+                self.engine._chk(self.engine._L.cf_spread_streams(hs, 2, None))
         engs = (self.engine, self._engine2)
         nb = self.engine.max_batch
 
@@ -825,7 +825,7 @@ class CenterFaceBuckets(object):
             if len(self._buckets) >= self.max_buckets:             # evict the least recently used context
                 old = next(iter(self._buckets))
                 self._buckets.pop(old).close()
-            eng = Engine(H, W, max_batch=self.max_batch, dtype=self.dtype, device=self.device, weights=self._weights,
+            eng = Engine(H, W, max_batch=self.max_batch, dtype=self.dtype, device=self.device, weights=self._weights, decode_stream=False,
                          collapse_heads=self.collapse_heads)
             self.created += 1
         self._buckets[key] = eng
