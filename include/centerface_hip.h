@@ -286,7 +286,10 @@ int cf_get_streams(cf_ctx* ctx, void** main_stream, void** decode_stream);
  * old ones are destroyed; the context must be idle; captured graphs stay valid).  Re-rolling helps in a fresh process; where it keeps
  * landing on the same queue, cf_spread_streams (below) is the tool.  What EngineRing calls at construction when its streams clash. */
 int cf_streams_share_queue(cf_ctx* a, cf_ctx* b, int* shared);
-/* The same probe for any pair of the contexts' streams: which = 0 main, 1 decode, 2 the device's copy stream (a == b allowed). */
+/* The same probe for any pair of the contexts' streams: which = 0 main, 1 decode, 2 the device's copy stream (a == b allowed).
+ * + 16 on either selector: the DISPATCH-PIPE probe -- the first stream runs a kernel whose grid cannot be resident at once (its pipe stays busy
+ * launching workgroups), so streams on different queues of one pipe are caught too: such a pair costs a ring of two contexts its overlap
+ * just like a shared queue (49-51 k instead of 53-54 k img/s; tools/queue_order_probe.py). */
 int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, int* shared);
 /* Put the main streams (and the decode streams of contexts created without CF_FLAG_NO_DECODE_STREAM) of n idle contexts of one device on
  * pairwise different hardware queues: candidates are created and probed one after the other, those that land on a used queue are kept as

@@ -400,6 +400,16 @@ __global__ void cf_spin_kernel(long long ticks) {
     while (wall_clock64() - t0 < ticks) { }
 }
 
+// The same with a grid that cannot be resident at once (64 KB of LDS per workgroup = two per CU): the dispatcher of the stream's hardware
+// PIPE stays busy launching workgroups for the whole run of the kernel, so a kernel on another queue of the SAME pipe has to wait --
+// which is what two forwards on such a pair do to each other, launch after launch (each kernel holds far more workgroups than fit)
+__global__ void cf_fat_spin_kernel(long long ticks) {
+    extern __shared__ char fat_lds[];
+    if (ticks < 0) fat_lds[threadIdx.x] = 0;             // (keeps the allocation)
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) { }
+}
+
 // Shard agreement of the gather (cf_comm_set_shard): publish this rank's (B, K), all-gather the pairs ONCE per geometry, ...
 __global__ void cf_comm_publish_kernel(int* mine, int B, int K) { mine[0] = B; mine[1] = K; }
 // ... and compare every rank's against ours; a mismatch is latched in host-visible memory
@@ -1798,8 +1808,15 @@ static hipStream_t pick_stream(cf_ctx* c, int which) {
 
 // Do two streams sit on one hardware queue?  ~0.3 ms spin on the first, then an empty kernel on the second: on one queue the second waits
 // for the first.  One timing sample can be fooled by anything else using the GPU: three probes, majority decides.  Both streams idle.
-static int streams_share(cf_ctx* a, hipStream_t sa, hipStream_t sb, int* shared) {
+static int streams_share(cf_ctx* a, hipStream_t sa, hipStream_t sb, int* shared, bool fat = false) {
     if (sa == sb) { *shared = 1; return CF_OK; }
+    if (fat) {
+        static thread_local bool configured_dev[64] = {};
+        if (!configured_dev[a->device & 63]) {
+            HIPCHK(a, hipFuncSetAttribute(reinterpret_cast<const void*>(cf_fat_spin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            configured_dev[a->device & 63] = true;
+        }
+    }
     HIPCHK(a, hipStreamSynchronize(sa));
     HIPCHK(a, hipStreamSynchronize(sb));
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -1809,7 +1826,8 @@ static int streams_share(cf_ctx* a, hipStream_t sa, hipStream_t sb, int* shared)
     for (int rep = 0; rep < 3 && err == hipSuccess; ++rep) {
         auto step = [&](hipError_t e) { if (err == hipSuccess) err = e; };
         step(hipEventRecord(ev[0], sa));
-        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, sa, (long long)30000);
+        if (fat) hipLaunchKernelGGL(cf_fat_spin_kernel, dim3(2560), dim3(64), 64 * 1024, sa, (long long)6000);       // 5 rounds of 60 us
+        else hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, sa, (long long)30000);
         step(hipGetLastError());
         step(hipEventRecord(ev[1], sa));
         hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, sb, (long long)0);
@@ -1832,11 +1850,12 @@ static int streams_share(cf_ctx* a, hipStream_t sa, hipStream_t sb, int* shared)
 // which_a / which_b: 0 = the context's main stream, 1 = its decode stream, 2 = the device's copy stream
 int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, int* shared) {
     if (!a || !b || !shared) return CF_EINVAL;
-    hipStream_t sa = pick_stream(a, which_a), sb = pick_stream(b, which_b);
+    const bool fat = ((which_a | which_b) & 16) != 0;                      // + 16: the dispatch-pipe probe (a grid that cannot be resident at once)
+    hipStream_t sa = pick_stream(a, which_a & 15), sb = pick_stream(b, which_b & 15);
     if (!sa || !sb) return a->fail(CF_EINVAL, "cf_streams_share_queue_ex: stream selector outside 0..2");
     if (a->device != b->device) { *shared = 0; return CF_OK; }
     HIPCHK(a, hipSetDevice(a->device));
-    return streams_share(a, sa, sb, shared);
+    return streams_share(a, sa, sb, shared, fat);
 }
 
 // Put the main streams -- and the decode streams, for contexts that use one -- of n contexts of ONE device on pairwise different hardware
@@ -1858,20 +1877,28 @@ int cf_spread_streams(cf_ctx** ctxs, int n, int* n_distinct) {
     for (int i = 0; i < n; ++i) { int r = cf_synchronize(ctxs[i]); if (r) return r; }
     std::vector<hipStream_t> chosen, ballast;
     int rc = CF_OK;
-    for (int tries = 0; tries < 48 && chosen.size() < want.size() && chosen.size() < 4; ++tries) {
-        hipStream_t s = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
-        hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, s, (long long)0);       // first use: the stream has its queue now
-        (void)hipStreamSynchronize(s);
-        bool clash = false;
-        for (hipStream_t t : chosen) {
-            int sh = 0;
-            rc = streams_share(c0, t, s, &sh);
-            if (rc) break;
-            if (sh) { clash = true; break; }
+    // Strict rounds: a candidate must clash with nothing placed so far.  The process's hardware queues may sit on fewer than four dispatch
+    // pipes, though: when a decode stream finds no pipe of its own it settles for one it shares with another DECODE stream only (two decodes
+    // of 0.15 ms per step on one pipe cost nothing measurable; a decode on the other context's main pipe costs the ring 8 %).
+    for (int relaxed = 0; relaxed < 2 && rc == CF_OK && chosen.size() < want.size(); ++relaxed) {
+        for (int tries = 0; tries < 24 && chosen.size() < want.size(); ++tries) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            hipLaunchKernelGGL(cf_spin_kernel, dim3(1), dim3(64), 0, s, (long long)0);       // first use: the stream has its queue now
+            (void)hipStreamSynchronize(s);
+            const bool placing_decode = want[chosen.size()].decode;
+            bool clash = false;
+            for (size_t k = 0; k < chosen.size() && !clash; ++k) {
+                if (relaxed && placing_decode && want[k].decode) continue;
+                int sh = 0;
+                rc = streams_share(c0, chosen[k], s, &sh, true);             // the dispatch-pipe probe: a shared queue fails it too
+                if (rc) break;
+                clash = sh != 0;
+            }
+            if (rc) { hipStreamDestroy(s); break; }
+            if (clash && relaxed && !placing_decode) { ballast.push_back(s); continue; }
+            (clash ? ballast : chosen).push_back(s);
         }
-        if (rc) { hipStreamDestroy(s); break; }
-        (clash ? ballast : chosen).push_back(s);
     }
     for (hipStream_t s : ballast) hipStreamDestroy(s);
     if (rc) { for (hipStream_t s : chosen) hipStreamDestroy(s); return rc; }

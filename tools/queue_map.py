@@ -10,4 +10,7 @@ label = lambda i, w: ("main%d" % i, "dec%d" % i, "copy")[w] if w < 2 else "copy"
 rows = {}
 for (i, w) in names:
     rows[label(i, w)] = [label(j, v) for (j, v) in names if (j, v) != (i, w) and ring.engines[i].queue_shared(w, ring.engines[j], v)]
-print(json.dumps({"depth": depth, "rerolls": ring.queue_rerolls, "shares_queue_with": rows}))
+pipes = {}
+for (i, w) in names[:-1]:
+    pipes[label(i, w)] = [label(j, v) for (j, v) in names[:-1] if (j, v) != (i, w) and ring.engines[i].queue_shared(w, ring.engines[j], v + 16)]
+print(json.dumps({"depth": depth, "placed_afresh": bool(ring.queue_rerolls), "shares_queue_with": rows, "waits_for_a_non_resident_grid_on": pipes}))
