@@ -294,10 +294,12 @@ int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, in
 /* Put the main streams (and the decode streams of contexts created without CF_FLAG_NO_DECODE_STREAM) of n idle contexts of one device on
  * pairwise different hardware queues: candidates are created and probed one after the other, those that land on a used queue are kept as
  * ballast until the end, so the runtime's fewest-streams-first placement moves on (a create-then-destroy re-roll can come back to the same
- * queue forever in a process with unevenly loaded queues).  Main streams first; at most four queues exist.  *n_distinct (may be NULL) =
+ * queue forever in a process with unevenly loaded queues).  Main streams first; at most four queues exist.  window = 0: all pairwise different;
+ * window = w > 0: a main stream only differs from those of the w contexts before it in ctxs (more contexts than pipes, used round-robin in
+ * that order).  Decode streams may end up sharing with each other, never with a main stream.  *n_distinct (may be NULL) =
  * streams placed on a queue of their own.  Captured graphs stay valid.  Call it only when streams clash as created: the placement the runtime
  * gives the first contexts of a process measured 4 % faster than a fresh one (54.1 against 51.9 k img/s, no queue shared in either). */
-int cf_spread_streams(cf_ctx** ctxs, int n, int* n_distinct);
+int cf_spread_streams(cf_ctx** ctxs, int n, int window, int* n_distinct);
 int cf_reroll_streams(cf_ctx* ctx);
 /* hipGraph replay state: number of captured forward graphs held by the context, and how many
  * (input, format, batch) keys could not be captured and run as eager launches instead. */

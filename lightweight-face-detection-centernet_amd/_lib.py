@@ -123,7 +123,7 @@ def lib():
         L.cf_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.cf_streams_share_queue.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.cf_streams_share_queue_ex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
-        L.cf_spread_streams.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+        L.cf_spread_streams.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.cf_reroll_streams.argtypes = [C.c_void_p]
         L.cf_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.cf_host_free.argtypes = [C.c_void_p, C.c_void_p]

@@ -428,7 +428,7 @@ class EngineRing(object):
         if clash:
             hs = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
             nd = C.c_int(0)
-            self.engines[0]._chk(self.engines[0]._L.cf_spread_streams(hs, len(self.engines), C.byref(nd)))
+            self.engines[0]._chk(self.engines[0]._L.cf_spread_streams(hs, len(self.engines), 0, C.byref(nd)))
             self.queue_rerolls = 1
         self.depth = int(depth)
         self._n = 0
@@ -605,7 +605,7 @@ class CenterFace(object):
             self._engine2 = Engine(self.img_h_new, self.img_w_new, **self._engine_kw)
             if self._engine2.shares_queue_with(self.engine):     # keep the two main streams on different hardware queues (see EngineRing)
                 hs = (C.c_void_p * 2)(self.engine._h, self._engine2._h)
-                self.engine._chk(self.engine._L.cf_spread_streams(hs, 2, None))
+                self.engine._chk(self.engine._L.cf_spread_streams(hs, 2, 0, None))
         engs = (self.engine, self._engine2)
         nb = self.engine.max_batch
 
@@ -829,6 +829,7 @@ class CenterFaceBuckets(object):
             eng = Engine(H, W, max_batch=self.max_batch, dtype=self.dtype, device=self.device, weights=self._weights, decode_stream=False,
                          collapse_heads=self.collapse_heads)
             self.created += 1
+            self._placement_dirty = True
         self._buckets[key] = eng
         return eng
 
@@ -875,6 +876,14 @@ class CenterFaceBuckets(object):
             eng = self._engine(H, W)
             work.append([eng, [((h, w), idx[j:j + eng.max_batch]) for (h, w), idx in raws.items()
                                for j in range(0, len(idx), eng.max_batch)]])
+        # New contexts since the last call: put the main streams on dispatch pipes such that contexts used one after the other never share
+        # one (cf_spread_streams, window 2).  A process's queues offer three or four pipes; five contexts as the runtime places them had
+        # three on one pipe (contexts 0, 3, 4), so the forwards of chunks 3 and 4 took turns kernel by kernel: 31.0 -> 33.9-35.4 k img/s on
+        # the configs[3] mix with (0, 3) (1, 4) (2) instead.  Costs ~15 ms, once per new context.
+        if self.__dict__.pop("_placement_dirty", False) and len(self._buckets) >= 2:
+            engs = list(self._buckets.values())
+            hs = (C.c_void_p * len(engs))(*[e._h for e in engs])
+            engs[0]._chk(engs[0]._L.cf_spread_streams(hs, len(engs), 2, None))
         # Software pipeline over the chunks, taken round-robin over the buckets, on TWO host threads: this thread copies chunk i into
         # its context's page-locked buffer (with the staging threads) and enqueues it (asynchronous DMA + resize + forward on that
         # context's own streams); a collector thread waits for the oldest chunk in flight (decode_threshold: the wait happens inside

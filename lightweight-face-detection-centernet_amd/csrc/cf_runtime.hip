@@ -1864,9 +1864,10 @@ int cf_streams_share_queue_ex(cf_ctx* a, int which_a, cf_ctx* b, int which_b, in
 // (bench.py's second and third ring: both main streams on one queue through 12 re-rolls, the ring worth nothing).  Here candidates are
 // created one after the other and probed against the streams already chosen: a candidate on a new queue is adopted, one on a used queue
 // is kept alive as BALLAST until the end -- it weighs its queue down, so the next candidate goes elsewhere.  Main streams are placed
-// first.  *n_distinct = streams that ended up on queues of their own (= wanted when it worked).  All contexts idle.
-int cf_spread_streams(cf_ctx** ctxs, int n, int* n_distinct) {
-    if (!ctxs || n < 1 || n > 16) return CF_EINVAL;
+// first.  window > 0: a main stream only has to differ from those of the `window` contexts before it in ctxs (a pool of more contexts than
+// there are pipes, used in that order round-robin: neighbours in time must not share).  *n_distinct = streams placed.  All contexts idle.
+int cf_spread_streams(cf_ctx** ctxs, int n, int window, int* n_distinct) {
+    if (!ctxs || n < 1 || n > 16 || window < 0) return CF_EINVAL;
     for (int i = 0; i < n; ++i) if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device) return CF_EINVAL;
     cf_ctx* c0 = ctxs[0];
     HIPCHK(c0, hipSetDevice(c0->device));
@@ -1890,6 +1891,7 @@ int cf_spread_streams(cf_ctx** ctxs, int n, int* n_distinct) {
             bool clash = false;
             for (size_t k = 0; k < chosen.size() && !clash; ++k) {
                 if (relaxed && placing_decode && want[k].decode) continue;
+                if (window > 0 && !placing_decode && (int)(chosen.size() - k) > window) continue;       // only the `window` contexts before this one
                 int sh = 0;
                 rc = streams_share(c0, chosen[k], s, &sh, true);             // the dispatch-pipe probe: a shared queue fails it too
                 if (rc) break;
