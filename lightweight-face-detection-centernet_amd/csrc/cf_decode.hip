@@ -359,9 +359,14 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
         const u64 key = BIG ? gbuf[sortn + t] : sel[t];
         const uint32_t idx = 0xffffffffu - (uint32_t)key;
         const float score = from_orderable((uint32_t)(key >> 32));
-        const float* rec = p.heads + ((size_t)b * HW + idx) * 16;
-        float xs = (float)(int)(idx % (uint32_t)p.w);
-        float ys = (float)(int)(idx / (uint32_t)p.w);
+        // the 64-byte head record as four 16-byte loads issued together (read field by field, each landmark's load -> store pair waited for
+        // the one before: ten dependent memory round trips, 14 of the 50 us of a K = 1000 decode)
+        const float4* r4 = reinterpret_cast<const float4*>(p.heads + ((size_t)b * HW + idx) * 16);
+        const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+        const float rec[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        const uint32_t yi = idx / (uint32_t)p.w;
+        float xs = (float)(int)(idx - yi * (uint32_t)p.w);
+        float ys = (float)(int)yi;
         if (p.use_reg) { xs = xs + rec[13]; ys = ys + rec[14]; }
         else { xs = xs + 0.5f; ys = ys + 0.5f; }
         const float hw0 = rec[1] / 2.0f, hw1 = rec[2] / 2.0f;
@@ -375,21 +380,20 @@ __global__ __launch_bounds__(NT) void topk_select_kernel(TopkParams p) {
             bx1 = (float)ax1; by1 = (float)ay1; bx2 = (float)ax2; by2 = (float)ay2;
         }
         const size_t o = (size_t)b * K + t;
-        if (p.dets) {
-            float* d = p.dets + o * 6;
-            d[0] = bx1; d[1] = by1; d[2] = bx2; d[3] = by2; d[4] = score; d[5] = 0.0f;
+        if (p.dets) {                                   // rows of 24 / 40 bytes: 8-byte aligned
+            float2* d = reinterpret_cast<float2*>(p.dets + o * 6);
+            d[0] = make_float2(bx1, by1); d[1] = make_float2(bx2, by2); d[2] = make_float2(score, 0.0f);
         }
         if (p.lms) {
-            float* l = p.lms + o * 10;
+            float2* l = reinterpret_cast<float2*>(p.lms + o * 10);
 #pragma unroll
-            for (int j = 0; j < 10; ++j) l[j] = rec[3 + j];
+            for (int j = 0; j < 5; ++j) l[j] = make_float2(rec[3 + 2 * j], rec[4 + 2 * j]);
         }
         if (p.inds) p.inds[o] = (long long)idx;
         if (p.rec16) {                                     // the gather record: box, score, class, landmarks
-            float* r = p.rec16 + o * 16;
-            r[0] = bx1; r[1] = by1; r[2] = bx2; r[3] = by2; r[4] = score; r[5] = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 10; ++j) r[6 + j] = rec[3 + j];
+            float4* r = reinterpret_cast<float4*>(p.rec16 + o * 16);       // 64-byte records
+            r[0] = make_float4(bx1, by1, bx2, by2); r[1] = make_float4(score, 0.0f, rec[3], rec[4]);
+            r[2] = make_float4(rec[5], rec[6], rec[7], rec[8]); r[3] = make_float4(rec[9], rec[10], rec[11], rec[12]);
         }
     }
 #ifdef CF_TOPK_TIMING
@@ -433,7 +437,9 @@ hipError_t launch_peak_topk(hipStream_t s, const TopkParams& p) {
 // barrier publishes the 16 counts, pass 2 re-scans the segment and writes every hit at segment base + running offset.
 // (The previous version walked the map in 1024-cell rounds with three workgroup barriers each: 74 us for one 160x160 map.)
 __device__ __forceinline__ void thresh_emit(const ThreshParams& p, const float* heads, float* cand, int i, uint32_t pos) {
-    const float* rec = heads + (size_t)i * 16;
+    const float4* r4 = reinterpret_cast<const float4*>(heads + (size_t)i * 16);      // the 64-byte record as four loads in flight together
+    const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+    const float rec[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
     const float s = rec[0];
     const int cy = i / p.w, cx = i - cy * p.w;
     // centerface.py:84-91 -- float32 sizes, float64 centre arithmetic, cast at the end
@@ -446,7 +452,7 @@ __device__ __forceinline__ void thresh_emit(const ThreshParams& p, const float* 
     x1 = fmin(x1, (double)p.img_w); y1 = fmin(y1, (double)p.img_h);
     const double x2 = fmin(x1 + (double)s0, (double)p.img_w);
     const double y2 = fmin(y1 + (double)s1, (double)p.img_h);
-    float* c = cand + (size_t)pos * 16;
+    float c[16];
     c[0] = (float)x1; c[1] = (float)y1; c[2] = (float)x2; c[3] = (float)y2; c[4] = s;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {                       // centerface.py:94-99
@@ -454,6 +460,9 @@ __device__ __forceinline__ void thresh_emit(const ThreshParams& p, const float* 
         c[6 + 2 * j] = (float)(((double)rec[4 + 2 * j] + (double)cy + 0.5) * 4.0);
     }
     c[15] = 0.0f;
+    float4* o = reinterpret_cast<float4*>(cand + (size_t)pos * 16);       // 64-byte candidate records
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = make_float4(c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
 }
 
 __global__ __launch_bounds__(1024) void thresh_collect_kernel(ThreshParams p) {
