@@ -674,7 +674,9 @@ __global__ __launch_bounds__(64) void thresh_sweep_kernel(ThreshParams p) {
         if (!((kb >> lane) & 1ull)) continue;
         const int pos = keptbase[blk] + __popcll(kb & ((1ull << lane) - 1ull));
         if (pos >= p.max_out) continue;
-        const float* c = cand + (size_t)order[r] * 16;
+        const float4* c4 = reinterpret_cast<const float4*>(cand + (size_t)order[r] * 16);      // the 64-byte candidate record: four loads in flight
+        const float4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+        const float c[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
         float* d = p.dets + ((size_t)b * p.max_out + pos) * 5;
         float* l = p.lms ? p.lms + ((size_t)b * p.max_out + pos) * 10 : nullptr;
         if (p.rs_w > 0.f) {                        // centerface.py:55-62: x // scale_w, y // scale_h (exact floor of the quotient)
