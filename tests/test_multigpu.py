@@ -321,6 +321,47 @@ def test_engine_ring_matches_single_engine_bitwise():
     one.close()
 
 
+def test_spread_streams_places_contexts_and_keeps_results():
+    """cf_spread_streams / cf_streams_share_queue_ex: three contexts' main streams (and one context's decode stream) are re-placed -- all pairwise
+    (window 0) and neighbours only (window 2); captured graphs and results stay valid, the probe answers for every selector, bad arguments are
+    CF_EINVAL; after a window-0 placement no two MAIN streams fail the dispatch-pipe probe (three pipes are always reachable)."""
+    import ctypes as C
+    L = cfa._lib.lib()
+    S, B = 160, 4
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    engs = [cfa.Engine(S, S, max_batch=B, dtype="bf16", decode_stream=(i == 0)) for i in range(3)]
+    want = []
+    for e in engs:
+        e.forward_enqueue(x); e.forward_enqueue(x)                   # second sighting: the graph is captured
+        want.append((e.heads(), e.decode_topk(20)))
+    hs = (C.c_void_p * 3)(*[e._h for e in engs])
+    nd = C.c_int(-1)
+    for window in (0, 2, 1):
+        assert L.cf_spread_streams(hs, 3, window, C.byref(nd)) == 0
+        assert 1 <= nd.value <= 4
+        for e, (h0, d0) in zip(engs, want):
+            e.forward_enqueue(x)
+            h1, d1 = e.heads(), e.decode_topk(20)
+            for k in h0:
+                assert np.array_equal(h0[k], h1[k]), (window, k)
+            for a, b2 in zip(d0, d1):
+                assert np.array_equal(a, b2)
+    assert L.cf_spread_streams(hs, 3, 0, None) == 0
+    for i in range(3):
+        for j in range(i):
+            assert not engs[i].queue_shared(16, engs[j], 0), (i, j)     # main streams: different pipes (hence different queues)
+            assert not engs[i].queue_shared(0, engs[j], 0)
+    sh = C.c_int(-1)
+    assert L.cf_streams_share_queue_ex(engs[0]._h, 0, engs[0]._h, 0, C.byref(sh)) == 0 and sh.value == 1      # a stream shares with itself
+    assert L.cf_streams_share_queue_ex(engs[0]._h, 2, engs[1]._h, 2, C.byref(sh)) == 0 and sh.value == 1      # the device's ONE copy stream
+    assert L.cf_streams_share_queue_ex(engs[0]._h, 1, engs[1]._h, 17, C.byref(sh)) == 0                       # decode streams exist from now on
+    assert L.cf_streams_share_queue_ex(engs[0]._h, 3, engs[1]._h, 0, C.byref(sh)) == -1
+    assert L.cf_spread_streams(hs, 0, 0, None) == -1 and L.cf_spread_streams(None, 3, 0, None) == -1 and L.cf_spread_streams(hs, 3, -1, None) == -1
+    for e in engs:
+        e.close()
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields():
     """bench.py as the driver runs it (small workload): exactly one line on stdout, the contract's fields, roofline and
     the per-run consistency the judge checks (value = images of the median window / its time)."""
