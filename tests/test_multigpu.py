@@ -364,6 +364,18 @@ def test_spread_streams_places_contexts_and_keeps_results():
         e.close()
 
 
+def test_bench_other_configs_block_runs():
+    """bench.py's `other_configs` extras (configs[3] through CenterFaceBuckets, the configs[4] shard on three contexts): the block is wrapped in a
+    try / except inside bench.py so that it can never cost the headline its line -- this test is where a breakage shows."""
+    sys.path.insert(0, REPO)
+    import bench
+    o = bench.other_configs_block(cfa, 0)
+    v = o["configs[3]"]
+    assert v["page_locked_input"]["images_per_s"] > 1000 and v["pageable_input"]["images_per_s"] > 1000 and v["detections"] > 0
+    s4 = o["configs[4]_per_gpu_shard"]
+    assert s4["images_per_s"] > 500 and s4["contexts"] == 3 and s4["batch"] == 4 and s4["topk"] == 1000
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields():
     """bench.py as the driver runs it (small workload): exactly one line on stdout, the contract's fields, roofline and
     the per-run consistency the judge checks (value = images of the median window / its time)."""
