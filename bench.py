@@ -749,8 +749,8 @@ def main():
                        "gather": {"none": None, "cf": "cf_gather_topk (C ABI: decode on the context's %s stream, ONE ncclAllGather per step on the rank's one gather stream / one communicator; slot header validated on the device)" % ("decode" if len(engs) < 3 else "main"),
                                   "torch": "torch.distributed.all_gather_into_tensor"}[gather],
                        "gather_fallback": fallback},
-            "windows": {"n": len(wins), "steps_each": args.steps, "median_ms": round(1e3 * med, 3),
-                        "min_ms": round(1e3 * min(wins), 3), "max_ms": round(1e3 * max(wins), 3),
+            "windows": {"n": len(wins), "steps_each": args.steps, "median_ms": round(1e3 * med, 5),
+                        "min_ms": round(1e3 * min(wins), 5), "max_ms": round(1e3 * max(wins), 5),
                         "value_min": round(world * B * args.steps / max(wins), 1), "value_max": round(world * B * args.steps / min(wins), 1)},
             "roofline": roofline,
         }

@@ -206,6 +206,15 @@ int cf_comm_create(cf_ctx* ctx, int rank, int world, const void* id, cf_comm** o
 /* Single process / single thread that owns one context per GPU: the n ncclCommInitRank calls inside one
  * ncclGroupStart/End (un-grouped, the first call would block forever waiting for the others).  out[i] = rank i = ctxs[i]. */
 int cf_comm_create_all(cf_ctx** ctxs, int n, cf_comm** out);
+/* Dry run of a `world`-rank gather on ONE GPU, without RCCL: the process plays the ranks in turn.  cf_comm_loopback_rank(comm, r)
+ * names the rank whose cf_gather_topk comes next; that call decodes the context's last forward (rank r's shard), writes the slot
+ * header and copies the slot into rank r's place of the landing area (the stand-in for the all-gather).  The call of the LAST rank
+ * of a step (every rank exactly once, any order) runs the header check + unpack and fills `records` [world * B, K, 16]; the calls
+ * before it write nothing.  Everything else -- slot sizes, shard agreement, header protocol, step numbers, the rank-major unpack
+ * arithmetic, the mismatch latch -- is the code of the real gather: a deployment checks its shard math for 2 / 4 / 8 ranks on one
+ * GPU (tests/test_multigpu.py asserts the 8-rank result equals the unsharded order bit for bit). */
+int cf_comm_create_loopback(cf_ctx* ctx, int world, cf_comm** out);
+int cf_comm_loopback_rank(cf_comm* comm, int rank);
 int cf_comm_destroy(cf_comm* comm);
 /* Give up on a communicator whose collective does not complete (ncclCommAbort: in-flight RCCL kernels exit), then release
  * it.  cf_comm_query: 0 = everything enqueued on the gather stream (shard agreement, gathers) has completed, 1 = still
@@ -216,7 +225,7 @@ int cf_comm_abort(cf_comm* comm);
 int cf_comm_query(cf_comm* comm);
 int cf_comm_synchronize(cf_comm* comm);
 const char* cf_comm_last_error(cf_comm* comm);
-/* Declare the shard every rank gathers: B images x K records (= the fixed slot size of every later gather).  Collective by
+/* Declare the largest shard every rank gathers: B images x K records (= the fixed slot size of every later gather).  Collective by
  * contract: every rank calls it with the same values at the same point of its call sequence (the first cf_gather_topk of a
  * communicator calls it implicitly; call it again on every rank to change the geometry).  It enqueues the ONLY extra
  * collective of the gather path -- a 2-int all-gather of each rank's (B, K) plus a device-side compare that latches a
@@ -230,11 +239,14 @@ int cf_comm_debug(cf_comm* comm, int what, int value);
 void* cf_comm_stream(cf_comm* comm);                    /* the gather stream (hipStream_t) */
 /* D3 decode of the last forward (as cf_decode_topk) followed by the all-gather: records [world * B, K, 16] =
  * x1,y1,x2,y2,score,cls,lm0..lm9 per detection, rank-major = exactly the batch order of the unsharded run.  Every rank
- * must pass the same B and K (cf_comm_set_shard).  ONE collective per call: each rank sends a fixed-size slot = a 64-byte
- * header {magic, B, K, step number} + its B x K x 16 records; behind the all-gather a device kernel checks every rank's
- * header against the agreed shard and this rank's step count and strips the headers into `records`.  A rank whose shard
- * differs from the agreed one still sends a full-size slot (carrying its real B, K) and returns CF_EINVAL: the counts and
- * the collective sequence stay identical on all ranks, every rank latches the mismatch, nobody hangs.  A latched mismatch
+ * must pass the same B and K.  ONE collective per call: each rank sends a fixed-size slot = a 64-byte header {magic, B, K,
+ * step number} + its B x K x 16 records; behind the all-gather a device kernel checks every rank's header against THIS
+ * rank's (B, K) and step count and strips the headers into `records`.  The slot agreed by cf_comm_set_shard is a CAPACITY:
+ * any (B, K) with B x K no larger than the agreed product -- the ragged last batch of a run, a smaller K -- is gathered in
+ * the same slot without another agreement, as long as it is the same on every rank.  A rank whose shard does not fit
+ * still sends a full-size slot (carrying its real B, K) and returns CF_EINVAL; a rank whose (B, K) differs from the
+ * others' is found by every rank's header check: the counts and the collective sequence stay identical on all ranks,
+ * every rank latches the mismatch, nobody hangs.  A latched mismatch
  * is reported by the blocking form itself, and by cf_comm_query / cf_comm_synchronize / the next cf_gather_topk for the
  * asynchronous form.  The decode runs on the context's decode stream, the all-gather on the communicator's stream behind
  * it, both underneath the next forward.  out_on_device = 1: `records` is a device buffer, the call never waits on the host

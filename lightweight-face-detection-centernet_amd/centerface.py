@@ -702,10 +702,21 @@ def _unregister(addr):
         pass
 
 
+def _owner(arr):
+    """The ndarray at the end of ``arr``'s .base chain: the object whose lifetime bounds the memory ``arr`` views."""
+    o = arr
+    while isinstance(o.base, np.ndarray):
+        o = o.base
+    return o
+
+
 def pin(arr):
     """Page-lock the memory of a C-contiguous numpy array in place (``cf_host_register``) and return it: batches taken from
     it reach the GPU by asynchronous DMA with no staging copy (``Engine.forward_images_enqueue``, ``CenterFaceBuckets``).
-    Worth it for buffers that are REUSED (a decoder's frame pool): registering costs ~0.1 ms per MB.  ``unpin`` releases."""
+    Worth it for buffers that are REUSED (a decoder's frame pool): registering costs ~0.1 ms per MB.  ``unpin`` releases it;
+    so does the garbage collection of the array that owns the memory (a finalizer on the owner unregisters the range BEFORE
+    numpy frees it -- a registration that outlived its memory would make ``is_pinned`` true for whatever array lands on that
+    address next, and ``hipMemcpyAsync`` would then DMA from pages HIP only believes to be locked)."""
     if not isinstance(arr, np.ndarray) or not arr.flags["C_CONTIGUOUS"] or arr.nbytes == 0:
         raise ValueError("pin needs a non-empty C-contiguous numpy array")
     addr = arr.ctypes.data
@@ -714,10 +725,17 @@ def pin(arr):
             if _pin_sizes[addr] >= arr.nbytes:
                 return arr
             raise ValueError("a shorter range at the same address is already pinned")
+        k = bisect.bisect_right(_pin_bases, addr) - 1
+        lo_clash = k >= 0 and _pin_bases[k] + _pin_sizes[_pin_bases[k]] > addr
+        hi_clash = k + 1 < len(_pin_bases) and _pin_bases[k + 1] < addr + arr.nbytes
+        if lo_clash or hi_clash:
+            raise ValueError("the array overlaps a range that is already pinned (pin the enclosing array once)")
+    owner = _owner(arr)
     _lib.check(_lib.lib().cf_host_register(C.c_void_p(addr), arr.nbytes), op=True)
     with _pin_lock:
         bisect.insort(_pin_bases, addr)
         _pin_sizes[addr] = arr.nbytes
+    weakref.finalize(owner, _unregister, addr)                     # (a no-op after unpin: _unregister forgets the address first)
     _remember(arr)
     return arr
 
@@ -749,8 +767,7 @@ def pinned_empty(shape, dtype=np.uint8):
     raw = np.empty(max(n, 1) + 4096, np.uint8)
     off = (-raw.ctypes.data) % 4096
     body = raw[off:off + max(n, 1)]
-    pin(body)
-    weakref.finalize(raw, _unregister, body.ctypes.data)           # views keep ``raw`` alive through .base
+    pin(body)                                                      # (its finalizer sits on ``raw``, which views keep alive through .base)
     out = body[:n].view(dtype).reshape(shape)
     _remember(out)
     return out

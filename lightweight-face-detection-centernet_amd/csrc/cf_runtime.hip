@@ -2009,6 +2009,11 @@ struct cf_comm {
     int* h_flag = nullptr; int* d_flag = nullptr;       // pinned + mapped: {verdict, peer rank, peer B, peer K, my B, my K, peer step, my step} (sticky)
     hipEvent_t ev_chk = nullptr;                        // behind the compare kernel of the agreement
     int debug_skew = 0;                                 // cf_comm_debug(1, v): the next gather's header carries B + v (tests of the mismatch path)
+    // cf_comm_create_loopback: no RCCL communicator -- this process plays every rank of a `world`-rank job in turn on ONE GPU
+    // (cf_comm_loopback_rank), the all-gather is the device copy of each rank's slot into its place of the landing area, and the
+    // header check + unpack run when the last rank has deposited: slot sizes, header protocol and the rank-major unpack arithmetic
+    // of an N-rank gather are exercised without N GPUs
+    bool loopback = false; unsigned deposited = 0;      // bit r: rank r's slot of the current step is in `recv`
     std::string err;
 };
 
@@ -2128,6 +2133,25 @@ int cf_comm_create_all(cf_ctx** ctxs, int n, cf_comm** out) {
     return CF_OK;
 }
 
+// Dry run of a `world`-rank gather on one GPU: no RCCL, this process plays the ranks one after the other.
+int cf_comm_create_loopback(cf_ctx* c, int world, cf_comm** out) {
+    if (!c || !out || world < 1 || world > 32) return CF_EINVAL;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    cf_comm* m = new cf_comm();
+    m->rank = 0; m->world = world; m->device = c->device; m->loopback = true;
+    int rr = comm_resources(c, m);
+    if (rr) { cf_comm_destroy(m); return rr; }
+    *out = m;
+    return CF_OK;
+}
+// the rank whose cf_gather_topk comes next (any order; every rank exactly once per step)
+int cf_comm_loopback_rank(cf_comm* m, int rank) {
+    if (!m || !m->loopback || rank < 0 || rank >= m->world) return CF_EINVAL;
+    m->rank = rank;
+    return CF_OK;
+}
+
 int cf_comm_destroy(cf_comm* m) {
     if (!m) return CF_OK;
     hipSetDevice(m->device);
@@ -2219,7 +2243,7 @@ void* cf_comm_stream(cf_comm* m) { return m ? (void*)m->stream : nullptr; }
 // (waiting for it if the host did not) BEFORE it enqueues a record gather: unequal counts never reach ncclAllGather.
 int cf_comm_set_shard(cf_comm* m, int B, int K) {
     if (!m || B < 1 || K < 1) return CF_EINVAL;
-    if (!m->comm) { m->err = "communicator was aborted"; return CF_ESTATE; }
+    if (!m->comm && !m->loopback) { m->err = "communicator was aborted"; return CF_ESTATE; }
     if (hipSetDevice(m->device) != hipSuccess) { m->err = "hipSetDevice failed"; return CF_EHIP; }
     { int mm = comm_mismatch(m); if (mm) return mm; }
     const size_t slot = (size_t)B * K * 16 + kSlotHeader;
@@ -2243,8 +2267,14 @@ int cf_comm_set_shard(cf_comm* m, int B, int K) {
     int* mine = m->d_chk + 2 * m->world;
     hipLaunchKernelGGL(cf_comm_publish_kernel, dim3(1), dim3(1), 0, m->stream, mine, B, K);
     hipError_t le = hipGetLastError(); if (le != hipSuccess) return hipfail(le, "cf_comm_publish_kernel");
-    ncclResult_t e = rccl()->AllGather(mine, m->d_chk, 2, ncclInt32, m->comm, m->stream);
-    if (e != ncclSuccess) { m->err = std::string("ncclAllGather (shard agreement): ") + rccl()->GetErrorString(e); return CF_EHIP; }
+    if (m->loopback) {                                   // one caller speaks for every rank: its pair in all `world` places
+        for (int r = 0; r < m->world; ++r)
+            if ((le = hipMemcpyAsync(m->d_chk + 2 * r, mine, 2 * sizeof(int), hipMemcpyDeviceToDevice, m->stream)) != hipSuccess) return hipfail(le, "hipMemcpyAsync (loopback agreement)");
+        m->deposited = 0;
+    } else {
+        ncclResult_t e = rccl()->AllGather(mine, m->d_chk, 2, ncclInt32, m->comm, m->stream);
+        if (e != ncclSuccess) { m->err = std::string("ncclAllGather (shard agreement): ") + rccl()->GetErrorString(e); return CF_EHIP; }
+    }
     hipLaunchKernelGGL(cf_comm_compare_kernel, dim3(1), dim3(64), 0, m->stream, (const int*)m->d_chk, m->world, B, K, m->d_flag);
     if ((le = hipGetLastError()) != hipSuccess) return hipfail(le, "cf_comm_compare_kernel");
     if ((le = hipEventRecord(m->ev_chk, m->stream)) != hipSuccess) return hipfail(le, "hipEventRecord");
@@ -2254,18 +2284,23 @@ int cf_comm_set_shard(cf_comm* m, int B, int K) {
 int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, int out_on_device) {
     if (!c || !m || !records) return CF_EINVAL;
     if (c->last_B < 1) return c->fail(CF_ESTATE, "cf_gather_topk before cf_forward");
-    if (!m->comm) return c->fail(CF_ESTATE, "communicator was aborted");
+    if (!m->comm && !m->loopback) return c->fail(CF_ESTATE, "communicator was aborted");
     if (m->device != c->device) return c->fail(CF_EINVAL, "communicator was created for device %d, context runs on %d", m->device, c->device);
     const int B = c->last_B, HW = (c->H / 4) * (c->W / 4);
     if (K < 1 || K > HW) return c->fail(CF_EINVAL, "K=%d must be in [1, %d]", K, HW);
     HIPCHK(c, hipSetDevice(c->device));
-    int r = ensure_topk_ws(c, K); if (r) return r;
+    int r = CF_OK;
     if (!c->ev_gather) HIPCHK(c, hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
     { int mm = comm_mismatch(m); if (mm) return c->fail(CF_EINVAL, "%s", m->err.c_str()); }
     // ncclAllGather takes ONE count for all ranks.  The count of every gather is the slot agreed by cf_comm_set_shard (implicitly
     // here on the first gather): its verdict is read -- waited for by polling if the host has not done so through
     // cf_comm_query -- before the first record gather of the geometry is enqueued.
     if (!m->slot_B) { r = cf_comm_set_shard(m, B, K); if (r) return c->fail(r, "%s", m->err.c_str()); }
+    // the all-gather reads a whole agreed slot from this context's record buffer, whatever this step's K is: size it for both
+    {
+        const size_t slot_rows = ((size_t)m->slot_B * m->slot_K + c->max_batch - 1) / c->max_batch;
+        r = ensure_topk_ws(c, (int)std::max<size_t>((size_t)K, slot_rows)); if (r) return r;
+    }
     if (!m->slot_verified) {
         for (unsigned spins = 0;; ++spins) {
             hipError_t q = hipEventQuery(m->ev_chk);
@@ -2277,12 +2312,19 @@ int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, in
         int mm = comm_mismatch(m); if (mm) return c->fail(CF_EINVAL, "%s", m->err.c_str());
         m->slot_verified = true;
     }
-    // A shard that differs from the agreed one is a rank-LOCAL fact: this rank still enqueues its full-size slot (from the spare
-    // buffer, the header carrying its real (B, K)), so the collective sequence and every count stay identical on all ranks, every
-    // rank's header check latches the mismatch, and the call returns CF_EINVAL here.
-    const bool local_ok = (B == m->slot_B && K == m->slot_K);
-    const size_t n = (size_t)m->slot_B * m->slot_K * 16;
-    const unsigned step = m->step++;
+    // The agreed slot is a CAPACITY (round 6): a step whose B x K records fit into it -- the ragged last batch of a run, a
+    // smaller K -- travels in the same fixed-size slot with its real (B, K) in the header, and the header check behind the all-gather
+    // requires every rank's header to equal THIS rank's (B, K, step): a geometry that is identical on every rank needs no second
+    // agreement and no second collective, one that differs between ranks latches the mismatch on every rank.  A shard that does NOT
+    // fit is a rank-LOCAL fact: this rank still enqueues a full-size slot (from the spare buffer, the header carrying its real
+    // (B, K)), so the collective sequence and every count stay identical on all ranks, every other rank's header check latches,
+    // and the call returns CF_EINVAL here (a larger geometry needs cf_comm_set_shard on every rank).
+    const size_t n = (size_t)B * K * 16;
+    const bool local_ok = n <= (size_t)m->slot_B * m->slot_K * 16;
+    // (loopback: the ranks of one step deposit one after the other and share its number; the step ends with the last of them)
+    const bool last_rank = !m->loopback || (m->deposited | (1u << m->rank)) == (m->world >= 32 ? ~0u : (1u << m->world) - 1u);
+    if (m->loopback && (m->deposited >> m->rank & 1u)) return c->fail(CF_ESTATE, "cf_gather_topk (loopback): rank %d has deposited its slot of this step already", m->rank);
+    const unsigned step = last_rank ? m->step++ : m->step;
     float* src = c->d_slot;
     if (local_ok) {
         // decode stream of the context: [wait forward] [wait the previous gather: it reads d_slot] decode -> records -> event
@@ -2307,11 +2349,22 @@ int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, in
     hipLaunchKernelGGL(cf_comm_header_kernel, dim3(1), dim3(1), 0, m->stream, src, B + m->debug_skew, K, step);
     m->debug_skew = 0;
     HIPCHK(c, hipGetLastError());
-    ncclResult_t e = rccl()->AllGather(src, m->recv, m->slot_floats, ncclFloat, m->comm, m->stream);
-    if (e != ncclSuccess) return c->fail(CF_EHIP, "ncclAllGather: %s", rccl()->GetErrorString(e));
+    if (m->loopback) {
+        HIPCHK(c, hipMemcpyAsync(m->recv + (size_t)m->rank * m->slot_floats, src, m->slot_floats * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+        m->deposited |= 1u << m->rank;
+        if (!last_rank) {                                // nothing to unpack yet; the next rank's decode must not overwrite d_slot under the copy
+            if (local_ok) { HIPCHK(c, hipEventRecord(c->ev_gather, m->stream)); c->gather_pending = true; }
+            if (!local_ok) return c->fail(CF_EINVAL, "cf_gather_topk (loopback): rank %d's shard (B=%d, K=%d) does not fit the agreed slot (B=%d, K=%d) -- the gather needs equal shards", m->rank, B, K, m->slot_B, m->slot_K);
+            return CF_OK;
+        }
+        m->deposited = 0;
+    } else {
+        ncclResult_t e = rccl()->AllGather(src, m->recv, m->slot_floats, ncclFloat, m->comm, m->stream);
+        if (e != ncclSuccess) return c->fail(CF_EHIP, "ncclAllGather: %s", rccl()->GetErrorString(e));
+    }
     float* dev_dst = (local_ok && out_on_device) ? records : nullptr;
     const int ublocks = dev_dst ? (int)std::min<size_t>(1024, (n / 4 * m->world + 255) / 256) : 1;
-    hipLaunchKernelGGL(cf_comm_unpack_kernel, dim3(ublocks), dim3(256), 0, m->stream, (const float*)m->recv, m->world, m->slot_floats, m->slot_B, m->slot_K, step, dev_dst, m->d_flag);
+    hipLaunchKernelGGL(cf_comm_unpack_kernel, dim3(ublocks), dim3(256), 0, m->stream, (const float*)m->recv, m->world, m->slot_floats, B, K, step, dev_dst, m->d_flag);
     HIPCHK(c, hipGetLastError());
     if (local_ok) {
         HIPCHK(c, hipEventRecord(c->ev_gather, m->stream));
@@ -2320,7 +2373,7 @@ int cf_gather_topk(cf_ctx* c, cf_comm* m, int K, int use_reg, float* records, in
     if (!local_ok) {
         volatile int* f = m->h_flag;                     // the device check will latch the same verdict; make it visible to the host now
         if (!f[0]) { f[1] = m->rank; f[2] = B; f[3] = K; f[4] = m->slot_B; f[5] = m->slot_K; f[0] = 1; }
-        return c->fail(CF_EINVAL, "cf_gather_topk: this rank's shard is (B=%d, K=%d), the communicator agreed on (B=%d, K=%d) -- the gather needs equal shards (pad the last one, or cf_comm_set_shard on every rank)",
+        return c->fail(CF_EINVAL, "cf_gather_topk: this rank's shard (B=%d, K=%d) does not fit the slot the communicator agreed on (B=%d, K=%d) -- the gather needs equal shards no larger than the agreed one (cf_comm_set_shard on every rank for a larger geometry)",
                        B, K, m->slot_B, m->slot_K);
     }
     if (!out_on_device) {

@@ -134,6 +134,24 @@ class Comm(object):
         _lib.check(_lib.lib().cf_comm_create_all(ctxs, n, outs), engines[0]._h)
         return [cls(e, i, n, None, _handle=C.c_void_p(outs[i])) for i, e in enumerate(engines)]
 
+    @classmethod
+    def loopback(cls, engine, world):
+        """Dry run of a ``world``-rank gather on ONE GPU (``cf_comm_create_loopback``): no RCCL, this process plays the ranks in
+        turn -- ``play(rank)`` before each ``gather_topk*``; the call of the step's last rank returns the gathered
+        [world * B, K, 16] records, the calls before it return None (host form) / write nothing (device form).  Slot sizes,
+        header protocol, step numbers and the rank-major unpack are those of the real gather."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().cf_comm_create_loopback(engine._h, int(world), C.byref(h)), engine._h)
+        m = cls(engine, 0, world, None, _handle=h)
+        m._loopback, m._played = True, set()
+        return m
+
+    def play(self, rank):
+        """Loopback only: the rank whose gather comes next (every rank exactly once per step, any order)."""
+        if _lib.lib().cf_comm_loopback_rank(self._h, int(rank)) != 0:
+            raise ValueError("play(%r): not a loopback communicator, or rank outside [0, %d)" % (rank, self.world))
+        self.rank = int(rank)
+
     def set_shard(self, B, K):
         """``cf_comm_set_shard``: declare the shard (B images x K records) every rank gathers.  Collective by contract (same
         values, same point of the call sequence on every rank); enqueues the one agreement collective of the gather path and
@@ -148,6 +166,11 @@ class Comm(object):
         eng = engine or self.engine
         out = np.empty((self.world * eng.last_B, int(K), REC), np.float32)
         _lib.check(_lib.lib().cf_gather_topk(eng._h, self._h, int(K), 1 if use_reg else 0, _lib.ptr(out), 0), eng._h)
+        if getattr(self, "_loopback", False):            # only the step's last rank holds the gathered records
+            self._played.add(self.rank)
+            if len(self._played) < self.world:
+                return None
+            self._played.clear()
         return out
 
     def gather_topk_device(self, K, records_ptr, use_reg=True, engine=None):

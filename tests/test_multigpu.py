@@ -235,10 +235,11 @@ def test_gather_is_asynchronous_and_latches_a_shard_mismatch():
 
 
 def test_gather_shard_change_is_rank_local_and_never_sends_unequal_counts():
-    """a rank whose shard differs from the agreed one (a short last batch) must not enqueue an all-gather with
-    another count.  It sends the agreed slot size with its real (B, K) in the header and gets CF_EINVAL at once; the header
-    check latches the mismatch (as it would on every other rank), and a new geometry needs cf_comm_set_shard on a fresh
-    communicator or before any mismatch.  Also: changing the geometry through set_shard, and K != the agreed K."""
+    """ADVICE r04 medium + r05 medium: no rank ever enqueues an all-gather with another count.  The agreed slot is a capacity: shards
+    that fit (ragged last batch, smaller K) are gathered in it as they are; a rank whose shard does NOT fit sends the agreed slot
+    size with its real (B, K) in the header and gets CF_EINVAL at once, the header check latches the mismatch (as it would on every
+    other rank), and a larger geometry needs cf_comm_set_shard on a fresh communicator or before any mismatch.  Also: changing the
+    geometry through set_shard, and K larger than the agreed K."""
     import torch
     S, B, K = 96, 4, 20
     imgs = np.random.default_rng(18).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
@@ -258,8 +259,19 @@ def test_gather_shard_change_is_rank_local_and_never_sends_unequal_counts():
     eng.forward_enqueue(imgs[:B - 1])
     comm.gather_topk_device(K + 5, out.data_ptr())
     assert comm.wait(30.0) and np.array_equal(out.cpu().numpy(), want2)
-    # a short shard without set_shard: rank-local CF_EINVAL, full-size slot sent, latched
+    # round 6: the agreed slot is a capacity -- a SHORTER shard (the ragged last batch, identical on every rank) and a smaller
+    # K travel in the same fixed-size slot with their real (B, K) in the header: no second agreement, no latch
     eng.forward_enqueue(imgs[:B - 2])
+    want3 = _records(eng, K + 5)
+    out3 = torch.zeros((B - 2, K + 5, 16), dtype=torch.float32, device="cuda:0")
+    comm.gather_topk_device(K + 5, out3.data_ptr())
+    assert comm.wait(30.0) and np.array_equal(out3.cpu().numpy(), want3)
+    got4 = comm.gather_topk(K - 3)
+    assert got4.shape == (B - 2, K - 3, 16) and np.array_equal(got4, _records(eng, K - 3))
+    eng.forward_enqueue(imgs[:B - 1])
+    assert np.array_equal(comm.gather_topk(K + 5), want2)          # and the full agreed shard again
+    # a shard that does NOT fit the agreed slot: rank-local CF_EINVAL, full-size slot sent, latched
+    eng.forward_enqueue(imgs)
     with pytest.raises((RuntimeError, ValueError), match="equal shards"):
         comm.gather_topk_device(K + 5, out.data_ptr())
     with pytest.raises(RuntimeError, match="equal shards"):
@@ -272,6 +284,70 @@ def test_gather_shard_change_is_rank_local_and_never_sends_unequal_counts():
         comm.gather_topk(K + 1)                          # another K than the agreed one
     comm.abort()
     eng.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gather_dry_run_n_ranks_equals_unsharded_order_bitwise(world):
+    """the N-rank gather without N GPUs.  A loopback communicator (cf_comm_create_loopback) plays the ranks of a
+    2 / 4 / 8-rank job in turn on one GPU -- shard_range() shards of one batch, each decoded, given its slot header and copied into its
+    rank's place of the landing area (the stand-in for ncclAllGather); the header check + rank-major unpack of the real gather then
+    run for `world` ranks.  The gathered records must equal the UNSHARDED decode of the whole batch bit for bit (host and device
+    destination, ranks playing out of order, two steps: the step number in the headers advances once per step), a ragged last step fits
+    the agreed slot, and a rank with another shard is found by the header check."""
+    import torch
+    S, K, per = 96, 20, 2
+    Btot = world * per
+    imgs = np.random.default_rng(100 + world).integers(0, 256, (Btot, S, S, 3), dtype=np.uint8)
+    full = cfa.Engine(S, S, max_batch=Btot, dtype="bf16")
+    full.forward_enqueue(imgs)
+    want = _records(full, K)
+    eng = cfa.Engine(S, S, max_batch=per, dtype="bf16")
+    comm = cfa.distributed.Comm.loopback(eng, world)
+    comm.set_shard(per, K)
+    assert comm.wait(30.0)
+    order = list(range(world))
+    for step in range(2):
+        got = None
+        for r in (order if step == 0 else order[::-1]):
+            lo, hi = cfa.distributed.shard_range(Btot, r, world)
+            assert hi - lo == per
+            eng.forward_enqueue(imgs[lo:hi])
+            comm.play(r)
+            out = comm.gather_topk(K)
+            got = out if out is not None else got
+        assert got.shape == (Btot, K, 16) and np.array_equal(got, want), step
+    # device destination
+    dev = torch.zeros((Btot, K, 16), dtype=torch.float32, device="cuda:0")
+    for r in order:
+        lo, hi = cfa.distributed.shard_range(Btot, r, world)
+        eng.forward_enqueue(imgs[lo:hi])
+        comm.play(r)
+        comm.gather_topk_device(K, dev.data_ptr())
+    assert comm.wait(30.0) and np.array_equal(dev.cpu().numpy(), want)
+    # a ragged last step (one image per rank, smaller K) travels in the agreed slot
+    full.forward_enqueue(imgs[::per])
+    want1 = _records(full, K - 5)
+    for r in order:
+        eng.forward_enqueue(imgs[r * per:r * per + 1])
+        comm.play(r)
+        got1 = comm.gather_topk(K - 5)
+    assert got1.shape == (world, K - 5, 16) and np.array_equal(got1, want1)
+    # the same rank twice in one step is a call-order error; a rank with another (B, K) is found by every rank's header check
+    eng.forward_enqueue(imgs[:per])
+    comm.play(0)
+    comm.gather_topk(K)
+    with pytest.raises(cfa._lib.CenterFaceError, match="deposited"):
+        comm.gather_topk(K)
+    for r in order[1:-1]:
+        eng.forward_enqueue(imgs[:per])
+        comm.play(r)
+        assert comm.gather_topk(K) is None
+    eng.forward_enqueue(imgs[:1])                                            # the last rank comes with a shorter shard than the others
+    comm.play(world - 1)
+    with pytest.raises((RuntimeError, ValueError), match="equal shards"):
+        comm.gather_topk(K)
+    comm.abort()
+    eng.close(); full.close()
 
 
 def test_engine_ring_matches_single_engine_bitwise():
