@@ -150,17 +150,20 @@ def _cpu_baseline_child(spec_path):
     def med(v):
         v = sorted(v)
         return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
-    # thread count: every candidate gets a warm-up and THREE timed runs at B = 1 (one of the two batch sizes that are reported);
-    # the median decides.  torch's intra-op pool oversubscribes badly on many-core hosts, so the candidates stop at the pinned cores.
+    # FIXED thread count (round 6): 16 threads on 16 pinned physical cores (fewer if the host has fewer).  Rounds 2-5
+    # searched the thread count and reported the better batch size; the winner changed from box to box (5 ... 34 img/s), so the
+    # rounds were not comparable.  The probe over other counts is still printed (B = 1, one warm-up + three runs each), it no
+    # longer decides anything.
     ncores = len(spec["cpus"])
-    cands = sorted({t for t in (8, 16, 32, 64, 128) if t <= ncores} | {min(ncores, 128)})
+    fixed = min(16, ncores)
+    cands = sorted({t for t in (8, 16, 32, 64) if t <= ncores} | {fixed})
     run1 = runner(1)
     probe = {}
     for th in cands:
         torch.set_num_threads(th)
         run1()
         probe[th] = med([run1() for _ in range(3)])
-    best = min(probe, key=lambda t: probe[t])
+    best = fixed
     torch.set_num_threads(best)
 
     def measure(bs, budget, min_runs):
@@ -184,6 +187,7 @@ def cpu_baseline(seconds, size, topk, imgs):
     import tempfile
     host_cores = os.cpu_count() or 1
     cpus, where = _host_core_set()
+    cpus = cpus[:16]                                          # the fixed configuration: 16 threads on 16 physical cores of one NUMA node
     with tempfile.TemporaryDirectory() as td:
         np.save(os.path.join(td, "imgs.npy"), np.ascontiguousarray(imgs[:16]))
         spec = {"cpus": cpus, "imgs": os.path.join(td, "imgs.npy"), "size": size, "topk": topk, "seconds": seconds}
@@ -196,16 +200,15 @@ def cpu_baseline(seconds, size, topk, imgs):
         raise RuntimeError("cpu baseline child failed: %s" % out.stderr[-2000:])
     r = json.loads(out.stdout.strip().splitlines()[-1])
     b16, b1 = r["b16"], r["b1"]
-    # the reported value is the better of the two batch sizes (oneDNN on a many-core host is often faster one image at a time)
-    best = b16 if b16["median"] >= b1["median"] else b1
-    return {"value": round(best["median"], 2), "unit": "images/s", "cores": r["threads"], "host_cores": host_cores,
+    # value = ALWAYS the B = 16 figure at the fixed thread count (comparable across rounds and boxes); B = 1 is reported beside it
+    return {"value": round(b16["median"], 2), "unit": "images/s", "cores": r["threads"], "host_cores": host_cores,
             "kind": "port", "value_b16": round(b16["median"], 2), "value_b1": round(b1["median"], 2),
             "spread": {"b16_min_max": [round(b16["min"], 2), round(b16["max"], 2)], "b16_runs": b16["runs"],
                        "b1_min_max": [round(b1["min"], 2), round(b1["max"], 2)], "b1_runs": b1["runs"]},
             "thread_probe_ms_per_image_b1": r["probe_ms_b1"],
             "pinned_to": "%d physical cores of %s (sched_setaffinity + OMP_PROC_BIND=close, OMP_PLACES=cores), fresh process" % (len(cpus), where),
             "sample": "B=16: %d images in %.1f s (%d runs); B=1: %d images in %.1f s (%d runs) (%dx%d, fp32 torch-CPU oracle forward + top-%d decode; "
-                      "%d threads = the fastest MEDIAN of three B=1 runs per candidate {8 ... %d}, %d host cores; value = median rate of the better batch size)"
+                      "FIXED %d threads on %d pinned physical cores, %d host cores; value = median B=16 rate, value_b1 = median B=1 rate)"
                       % (b16["images"], b16["seconds"], b16["runs"], b1["images"], b1["seconds"], b1["runs"], size, size, topk, r["threads"], len(cpus), host_cores)}
 
 

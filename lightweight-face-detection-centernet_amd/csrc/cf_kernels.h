@@ -122,7 +122,7 @@ void mb6_pack(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* w
               void* wexp_host, float* wdw_host, void* wproj_host);
 hipError_t mb6_launch(hipStream_t s, const MbParams& p);
 
-// cf_mbconv7.hip: as cf_mbconv6.hip, the depthwise feeding the project MFMAs directly (MbGeom::kind = 10; experiments switch CF_M7)
+// experiments/cf_mbconv7.hip (experiments build only): as cf_mbconv6.hip, the depthwise feeding the project MFMAs directly (MbGeom::kind = 10; experiments switch CF_M7)
 bool mb7_geometry(int dtype, MbGeom& g, int Cin, int hid, int Cout, int k, int s);
 void mb7_pack(const MbGeom& g, int Cin, int hid, int Cout, int k, const float* we, const float* wd, const float* wp,
               void* wexp_host, float* wdw_host, void* wproj_host);

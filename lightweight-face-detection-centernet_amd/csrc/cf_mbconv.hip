@@ -20,6 +20,7 @@
 //     phase 3  project: acc[out n-block] += Wp . D^T, accumulating over all hidden chunks.
 //   epilogue: + residual, 16 contiguous output channels per lane -> 16-byte stores.
 // The same two free permutations as cf_pw.hip are used (output channel <-> MFMA row, k <-> slot).
+#include "cf_exp.h"
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <type_traits>
@@ -48,7 +49,7 @@ void mb_pack_weights(int dtype, const MbGeom& g, int Cin, int hid, int Cout, int
     if (g.kind == 4) { mx_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 5) { mx_fused_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 6) { mx_fused2_pack_weights(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
-    if (g.kind == 10) { mb7_pack(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
+#include CF_EXP_INC(cf_mbconv_m7_pack)
     if (g.kind == 9) { mb6_pack(g, Cin, hid, Cout, k, we, wd, wp, wexp_host, wdw_host, wproj_host); return; }
     if (g.kind == 8) {                       // cf_mbconv5.hip: this file's expand fragments, taps as [chunk][group of 4 channels][tap][4]
         MbGeom g0 = g; g0.kind = 0; g0.NBO = 0; g0.HALF = 0; g0.wproj_bytes = 0;
@@ -440,10 +441,7 @@ static const MbEntry kMbTable[] = {
     MB_ENTRY(bf16_t, 1, 3, 1, 4, 32, 2, 1, 8, 16, 1, 4),   // 3.1  64 -> 384 -> 64 (+res)
     MB_ENTRY(bf16_t, 1, 5, 1, 4, 32, 3, 0, 8, 20, 0, 10),  // 4.0  64 -> 384 -> 96      8x20 tiles: a 40x40 map
     MB_ENTRY(bf16_t, 1, 5, 1, 6, 32, 3, 1, 8, 20, 0, 10),  // 4.1  96 -> 576 -> 96 (+res)   has no edge waste
-#ifdef CF_EXPERIMENTS   // never-default variants (CF_MB_VARIANT=n): A/B runs of an experiments build only
-    MB_VARIANT(1, bf16_t, 1, 3, 1, 4, 32, 2, 1, 8, 20, 0, 10),  // 3.1  8x20
-    MB_VARIANT(1, bf16_t, 1, 3, 2, 2, 32, 2, 0, 8, 20, 0, 5),   // 3.0  8x20
-#endif
+#include CF_EXP_INC(cf_mbconv_0)   // never-default variants (CF_MB_VARIANT=n): A/B runs of an experiments build only
     // fp32 storage (parity mode).  Round-3 A/B over hidden chunk / tile / k-groups (B = 64, 640x640, ms; previous entry in brackets):
     // what matters is the LDS footprint of the fp32 tile (1.0 at 8x16 / HC 32 = 87 KB = ONE four-wave workgroup per CU)
     MB_ENTRY(float, 0, 3, 2, 2, 32, 1, 0, 4, 16, 1, 4),    // 1.0  4x16 tile, two k-groups, 49 KB: 0.564 [8x16: 0.786; 8x16 HC 16: 0.635]
@@ -463,26 +461,7 @@ static const MbEntry kMbTable[] = {
     MB_ENTRY(sp32_t, 2, 3, 1, 8, 32, 2, 1, 8, 16, 1, 8),   // 3.1  two k-groups: 0.1275 -> 0.123
     MB_ENTRY(sp32_t, 2, 5, 1, 8, 32, 3, 0, 8, 16, 1, 8),   // 4.0
     MB_ENTRY(sp32_t, 2, 5, 1, 12, 32, 3, 1, 8, 16, 1, 4),  // 4.1
-#ifdef CF_EXPERIMENTS   // A/B sweep of the split mode (CF_MB_VARIANT=1..3)
-    MB_VARIANT(1, sp32_t, 2, 3, 2, 2, 48, 1, 0, 4, 16, 1, 4),    // 1.0 HC 48
-    MB_VARIANT(2, sp32_t, 2, 3, 2, 2, 96, 1, 0, 4, 16, 1, 4),    // 1.0 HC 96
-    MB_VARIANT(3, sp32_t, 2, 3, 2, 2, 32, 1, 0, 8, 16, 1, 8),    // 1.0 8x16
-    MB_VARIANT(1, sp32_t, 2, 5, 2, 3, 16, 1, 0, 4, 16, 1, 4),    // 2.0 4x16 HC 16
-    MB_VARIANT(2, sp32_t, 2, 5, 2, 3, 48, 1, 0, 4, 16, 1, 4),    // 2.0 4x16 HC 48
-    MB_VARIANT(3, sp32_t, 2, 5, 2, 3, 48, 1, 0, 8, 16, 1, 8),    // 2.0 8x16 HC 48
-    MB_VARIANT(1, sp32_t, 2, 3, 2, 4, 32, 2, 0, 4, 16, 1, 4),    // 3.0 4x16
-    MB_VARIANT(2, sp32_t, 2, 3, 2, 4, 64, 2, 0, 8, 16, 1, 8),    // 3.0 HC 64
-    MB_VARIANT(3, sp32_t, 2, 3, 2, 4, 32, 2, 0, 8, 16, 1, 4),    // 3.0 one k-group
-    MB_VARIANT(1, sp32_t, 2, 3, 1, 8, 64, 2, 1, 8, 16, 1, 8),    // 3.1 HC 64, 8 waves
-    MB_VARIANT(2, sp32_t, 2, 3, 1, 8, 32, 2, 1, 16, 16, 1, 8),   // 3.1 16x16
-    MB_VARIANT(3, sp32_t, 2, 3, 1, 8, 32, 2, 1, 8, 16, 1, 8),    // 3.1 two k-groups
-    MB_VARIANT(1, sp32_t, 2, 5, 1, 8, 64, 3, 0, 8, 16, 1, 8),    // 4.0 HC 64
-    MB_VARIANT(2, sp32_t, 2, 5, 1, 8, 32, 3, 0, 16, 16, 1, 8),   // 4.0 16x16
-    MB_VARIANT(3, sp32_t, 2, 5, 1, 8, 32, 3, 0, 8, 32, 1, 8),    // 4.0 8x32
-    MB_VARIANT(1, sp32_t, 2, 5, 1, 12, 32, 3, 1, 8, 16, 1, 8),   // 4.1 two k-groups
-    MB_VARIANT(2, sp32_t, 2, 5, 1, 12, 64, 3, 1, 8, 16, 1, 8),   // 4.1 HC 64
-    MB_VARIANT(3, sp32_t, 2, 5, 1, 12, 32, 3, 1, 8, 32, 1, 8),   // 4.1 8x32
-#endif
+#include CF_EXP_INC(cf_mbconv_1)   // A/B sweep of the split mode (CF_MB_VARIANT=1..3)
 };
 #undef MB_ENTRY
 
@@ -504,7 +483,7 @@ MbGeom mb_geometry(int dtype, int Cin, int hid, int Cout, int k, int s) {
     if (dtype == 1 && mx_fused_geometry(g, Cin, hid, Cout, k, s)) return g;      // stride 1: depthwise on the matrix cores
     if (dtype == 1 && mx_fused2_geometry(g, Cin, hid, Cout, k, s)) return g;     // stride 2
     if (dtype == 1 && mb2_geometry(g, Cin, hid, Cout, k, s)) return g;
-    if (dtype == 2 && mb7_geometry(dtype, g, Cin, hid, Cout, k, s)) return g;     // (experiments switch CF_M7=1)
+#include CF_EXP_INC(cf_mbconv_m7_geometry)
     if (dtype == 2 && mb6_geometry(dtype, g, Cin, hid, Cout, k, s)) return g;     // round 5: register-window depthwise (cf_mbconv6.hip)
     if (dtype != 1 && mb4_geometry(dtype, g, Cin, hid, Cout, k, s)) return g;
     g.JX = (Cin * sz / 16 + 1) / 2;
@@ -534,7 +513,7 @@ hipError_t launch_mbconv(hipStream_t s, int dtype, const MbParams& p) {
     if (p.kind == 7) return dtype != 1 ? mb4_launch(s, dtype, p) : hipErrorInvalidValue;
     if (p.kind == 8) return expdw_f32_launch(s, dtype, p);
     if (p.kind == 9) return dtype == 2 ? mb6_launch(s, p) : hipErrorInvalidValue;
-    if (p.kind == 10) return dtype == 2 ? mb7_launch(s, p) : hipErrorInvalidValue;
+#include CF_EXP_INC(cf_mbconv_m7_launch)
     const MbEntry* e = mb_find(dtype, p.k, p.s, p.JX, (p.Cout + 31) / 32, p.residual ? 1 : 0);
     if (!e || e->hc != p.HC) return hipErrorInvalidValue;
     return e->fn(s, p);

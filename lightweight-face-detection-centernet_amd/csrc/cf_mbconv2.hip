@@ -23,6 +23,7 @@
 //     weights (x -ln 2): x * sigmoid(x) costs exp2 + rcp + one packed add + one packed multiply.
 // fp16 has a narrower range than bf16: v_cvt_pkrtz saturates to +-65504 instead of overflowing, and
 // E is post-Swish (>= -0.28).  Everything outside the tile E stays bf16 (HBM tensors, project operand).
+#include "cf_exp.h"
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <cstdlib>
@@ -673,18 +674,7 @@ static const XdEntry kXdTable[] = {
     XD(0, 3, 1, 10, 32, 10, 20),    // 6.0  160 -> 960, 20x20
     XD(0, 5, 1, 4, 32, 10, 40),     // 4.0   64 -> 384, 40x40: full-width tiles (10x20 0.071, 20x20 0.067, 10x40 0.066, 20x40 0.083 ms)
     XD(0, 5, 1, 6, 32, 10, 40),     // 4.1   96 -> 576, 40x40   (0.106 / 0.098 / 0.096 / 0.129)
-#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
-    XD(1, 5, 1, 4, 32, 20, 20),
-    XD(1, 5, 1, 6, 32, 20, 20),
-    XD(2, 5, 1, 4, 32, 10, 20),
-    XD(2, 5, 1, 6, 32, 10, 20),
-    XD(1, 5, 2, 6, 32, 5, 20),
-    XD(1, 5, 1, 10, 64, 10, 20),
-    XD(1, 3, 1, 10, 64, 10, 20),
-    XD(2, 5, 2, 6, 64, 5, 20),
-    XD(2, 5, 1, 10, 32, 20, 20),
-    XD(2, 3, 1, 10, 32, 20, 20),
-#endif  // CF_EXPERIMENTS
+#include CF_EXP_INC(cf_mbconv2_0)   // never-default variants: A/B runs of an experiments build only
 };
 #undef XD
 static const XdEntry* xd_find(int k, int s, int jx) {
@@ -786,30 +776,7 @@ static const Mb2Entry kMb2Table[] = {
     MB2(0, 3, 1, 4, 64, 2, 1, 8, 16, 4),    // 3.1  64 -> 384 -> 64 (+res)
     MB2(0, 5, 1, 4, 64, 3, 0, 8, 16, 4),    // 4.0  64 -> 384 -> 96
     MB2(0, 5, 1, 6, 64, 3, 1, 8, 16, 4),    // 4.1  96 -> 576 -> 96 (+res)
-#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
-    // experimental variants (CF_MB2_VARIANT=n)
-    MB2(1, 3, 2, 1, 48, 1, 0, 8, 16, 6),    // 1.0 HC48 KG3
-    MB2(1, 3, 1, 2, 48, 1, 1, 8, 16, 6),    // 1.1 8x16 KG3
-    MB2(1, 5, 2, 2, 48, 1, 0, 8, 16, 6),    // 2.0 8x16 KG3
-    MB2(1, 5, 1, 2, 96, 1, 1, 8, 16, 4),    // 2.1 HC96
-    MB2(1, 3, 1, 4, 32, 2, 1, 8, 16, 4),    // 3.1 HC32
-    MB2(1, 5, 1, 4, 32, 3, 0, 8, 16, 4),    // 4.0 HC32
-    MB2(1, 5, 1, 6, 32, 3, 1, 8, 16, 4),    // 4.1 HC32
-    MB2(2, 3, 2, 1, 32, 1, 0, 4, 32, 4),    // 1.0 4x32
-    MB2(2, 3, 1, 2, 48, 1, 1, 8, 32, 4),    // 1.1 8x32 KG1
-    MB2(2, 5, 2, 2, 48, 1, 0, 4, 16, 3),    // 2.0 4x16 KG3
-    MB2(2, 5, 1, 2, 64, 1, 1, 16, 16, 8),   // 2.1 16x16 KG2
-    MB2(2, 3, 1, 4, 128, 2, 1, 8, 16, 4),   // 3.1 HC128
-    MB2(2, 5, 1, 4, 128, 3, 0, 8, 16, 4),   // 4.0 HC128
-    MB2(2, 5, 1, 6, 96, 3, 1, 8, 16, 4),    // 4.1 HC96
-    MB2(3, 3, 1, 2, 48, 1, 1, 16, 16, 12),  // 1.1 16x16 KG3
-    MB2(3, 5, 1, 2, 64, 1, 1, 8, 16, 8),    // 2.1 KG4
-    MB2(3, 3, 1, 4, 64, 2, 1, 8, 16, 8),    // 3.1 KG4
-    MB2(3, 5, 1, 4, 64, 3, 0, 8, 16, 8),    // 4.0 KG4
-    MB2(3, 5, 1, 6, 64, 3, 1, 8, 16, 8),    // 4.1 KG4
-    MB2(3, 5, 2, 2, 48, 1, 0, 8, 16, 2),    // 2.0 KG1 (2 waves)
-    MB2(3, 3, 2, 1, 96, 1, 0, 4, 16, 2),    // 1.0 4x16 HC96 KG... 
-#endif  // CF_EXPERIMENTS
+#include CF_EXP_INC(cf_mbconv2_1)   // never-default variants: A/B runs of an experiments build only
 };
 #undef MB2
 

@@ -27,6 +27,7 @@
 //
 // Numerics are those of cf_mbconv2.hip (same storage points: fp16 round-toward-zero tile, fp16 taps, fp32 accumulation,
 // pre-scaled Swish); only the fp32 summation order inside a row differs.  oracle/bf16_emulation.py is the checker.
+#include "cf_exp.h"
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include "cf_mx.h"
@@ -213,307 +214,7 @@ __global__ __launch_bounds__(NW * 64) void expdw_mx_kernel(MbParams p) {
     }
 }
 
-#ifdef CF_EXPERIMENTS   // rounds-persistent variant: measured slower (profiles/r03_mfma_depthwise.md), experiments build only
-// The same with the workgroup walking R rounds of its tile (grid.y = rounds / R): launch + first-DMA latency once per R rounds, the
-// next round's weights and operand table streaming into a second LDS stage under the current round's depthwise
-template <int KS, int JX, int TOH, int TOW, int NW, int R>
-__global__ __launch_bounds__(NW * 64) void expdw_mxr_kernel(MbParams p) {
-    constexpr bool ALDS = true;
-    typedef Mx<KS, JX, TOH, TOW, NW, true> G;
-    constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, CP = G::CP, NSET = G::NSET, WXB = G::WXB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* E = smem;
-    char* Wst = smem + G::EBYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pl = lane & 31, h = lane >> 5;
-    const int tiles_x = (p.Wout + TOW - 1) / TOW;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int ox0 = txi * TOW, oy0 = tyi * TOH, b = blockIdx.z;
-    const int grp = blockIdx.y;
-
-    // round r of this workgroup = hidden-channel round grp * R + r; expand weights and the operand table of round r + 1 are DMA'd
-    // into the other LDS stage while round r's depthwise runs
-    constexpr int STG = WXB + G::ATB;
-    auto stage = [&](int r) {
-        char* dst = Wst + (r & 1) * STG;
-        const char* srcx = (const char*)p.wexp + (size_t)(grp * R + r) * WXB;
-        for (int c = wave; c < WXB / 1024; c += NW)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
-        const char* srca = (const char*)p.wdw + (size_t)(grp * R + r) * G::ATB;
-        for (int c = wave; c < G::ATB / 1024; c += NW)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(dst + WXB + c * 1024), 16, 0, 0);
-        asm volatile("" ::: "memory");
-    };
-    stage(0);
-    asm volatile("" ::: "memory");
-    const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
-    const unsigned rowbytes = (unsigned)p.Cin * 2;
-    auto load_x = [&](int ib, u32x4* xf) -> bool {
-        const int ip = ib * 32 + pl;
-        const int ipc = ip < IPX ? ip : IPX - 1;
-        const int iy = ipc / IWP, ix = ipc - iy * IWP;
-        const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
-        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
-        if (p.xblock) {
-            const char* xb = (const char*)p.x + blk_off(((size_t)b * p.Hin + cy) * p.Win + cx, p.Cin / 8, h * JX);
-#pragma unroll
-            for (int j = 0; j < JX; ++j) xf[j] = ld16(xb + j * 512);
-        } else {
-            const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
-#pragma unroll
-            for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
-        }
-        return ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
-    };
-    auto mask_x = [&](u32x4* xf, bool valid) {
-#pragma unroll
-        for (int j = 0; j < JX; ++j) {
-            xf[j].x = valid ? xf[j].x : 0u; xf[j].y = valid ? xf[j].y : 0u; xf[j].z = valid ? xf[j].z : 0u; xf[j].w = valid ? xf[j].w : 0u;
-        }
-    };
-    const int abl = 0;
-    static constexpr SetMap<TOH, TOW, IWQ> kSets{};
-    const int kg = lane >> 4;
-#pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-    const char* Wr = Wst + (r & 1) * STG;
-    const char* Ats = Wr + WXB;
-    u32x4 xa[JX];
-    bool va = false;
-    if (wave < NIB) va = load_x(wave, xa);
-    static_assert(NIB >= NW, "every wave issues the X loads the wait below keeps in flight");
-    cf_sync_lds_dma_keep<JX>();      // previous round's depthwise done with E; this round's weights / table (DMA, issued earlier) landed
-    mask_x(xa, va);
-
-    // ---- phase 1: expand + Swish -> quad cells.  D rows (r & 3) + 8 (r >> 2) + 4 h: register quad t = halo quad ib*8 + 2t + h
-    for (int ib = wave; ib < NIB; ib += NW) {
-        u32x4 xn[JX];
-        const bool more = ib + NW < NIB;
-        bool vn = false;
-        if (more) { if (abl & 8) { for (int j = 0; j < JX; ++j) xn[j] = xa[j]; vn = va; } else vn = load_x(ib + NW, xn); }
-        f32x16 a;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = 0.0f;
-        const char* wb = Wr + lane * 16;
-#pragma unroll
-        for (int j = 0; j < JX; ++j) {
-            const u32x4 wv = ld16(wb + j * 1024);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xa[j]),
-                                                        __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
-        }
-        char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)CP + pl * 8;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x2 u0, u1; u0.x = a[4 * t]; u0.y = a[4 * t + 1]; u1.x = a[4 * t + 2]; u1.y = a[4 * t + 3];
-            f32x2 y0 = u0, y1 = u1;
-            if (!(abl & 4)) { y0 = swish2_pre(u0); y1 = swish2_pre(u1); }
-            u32x2 d;
-            d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
-            d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
-            *reinterpret_cast<u32x2*>(ecell + 2 * t * CP) = d;
-        }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < JX; ++j) xa[j] = xn[j];
-            mask_x(xa, vn);
-        }
-    }
-    __syncthreads();
-    if (r + 1 < R) stage(r + 1);
-
-    // ---- phase 2: depthwise on the matrix cores + Swish, 16 output quads x 32 channels per wave step
-    for (int set = wave; set < NSET; set += NW) {
-        const uint32_t e = kSets.v[set * 16 + (lane & 15)];
-        const int oy = (e >> 6) & 0x1ff, oxq = e & 63;
-        const bool live = (e & 0x8000u) == 0;
-        f32x4 acc[8];
-        const char* bb = E + (unsigned)(oy * IWQ + oxq) * (unsigned)CP + kg * 64;
-        if (abl & 1) {
-#pragma unroll
-            for (int g = 0; g < 8; ++g) acc[g] = f32x4{(float)oy, (float)oxq, (float)g, 1.0f};
-        } else {
-        mx_depthwise_lds<KS, IWQ, CP>(bb, Ats + lane * 8, acc);
-        }
-        // a = -log2(e) * depthwise output -> Swish, leftover factor out again (the project GEMM has plain weights)
-        if (!(abl & 2))
-#pragma unroll
-        for (int g = 0; g < 8; ++g)
-#pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
-                const f32x2 y = swish2_pre(u) * kNegLn23;
-                acc[g][i] = y.x; acc[g][i + 1] = y.y;
-            }
-        const int gy = oy0 + oy, gx0 = ox0 + 4 * oxq;
-        if (!live || gy >= p.Hout || ((abl & 16) && acc[0][0] != 123.0f)) continue;
-        const size_t opix0 = ((size_t)b * p.Hout + gy) * p.Wout + gx0;
-        const int chunk = (grp * R + r) * 4 + kg;                     // 8-channel chunk of the depthwise tensor
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (gx0 + i >= p.Wout) break;
-            u32x4 o;
-            o.x = packb(acc[0][i], acc[1][i]); o.y = packb(acc[2][i], acc[3][i]);
-            o.z = packb(acc[4][i], acc[5][i]); o.w = packb(acc[6][i], acc[7][i]);
-            const size_t opix = opix0 + i;
-            st16((char*)p.y + (p.yblock ? blk_off(opix, p.hid / 8, chunk) : (opix * p.hid + (size_t)chunk * 8) * 2), o);
-        }
-    }
-    }
-}
-
-// Tile-persistent variant: a workgroup walks T consecutive tile units (tile x image) of ITS round of 32 hidden
-// channels: expand weights and the Toeplitz table are DMA'd once, and the first X fragments of unit t + 1 are loaded into registers
-// while the depthwise of unit t runs (the plain kernel starts every tile with a weight DMA + an exposed X load).
-template <int KS, int JX, int TOH, int TOW, int NW, int T>
-__global__ __launch_bounds__(NW * 64) void expdw_mxt_kernel(MbParams p) {
-    typedef Mx<KS, JX, TOH, TOW, NW, true> G;
-    constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, CP = G::CP, NSET = G::NSET, WXB = G::WXB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* E = smem;
-    char* Wst = smem + G::EBYTES;
-    char* Ats = Wst + WXB;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pl = lane & 31, h = lane >> 5;
-    const int tiles_x = (p.Wout + TOW - 1) / TOW, tiles = tiles_x * ((p.Hout + TOH - 1) / TOH);
-    const int units = tiles * p.B;
-    const int grp = blockIdx.y;
-    const int unit0 = blockIdx.x * T;
-    {
-        const char* srcx = (const char*)p.wexp + (size_t)grp * WXB;
-        for (int c = wave; c < WXB / 1024; c += NW)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(Wst + c * 1024), 16, 0, 0);
-        const char* srca = (const char*)p.wdw + (size_t)grp * G::ATB;
-        for (int c = wave; c < G::ATB / 1024; c += NW)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(Ats + c * 1024), 16, 0, 0);
-    }
-    asm volatile("" ::: "memory");
-    auto load_x = [&](int b, int oy0, int ox0, int ib, u32x4* xf) -> bool {
-        const int ip = ib * 32 + pl;
-        const int ipc = ip < IPX ? ip : IPX - 1;
-        const int iy = ipc / IWP, ix = ipc - iy * IWP;
-        const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
-        const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
-        if (p.xblock) {
-            const char* xb = (const char*)p.x + blk_off(((size_t)b * p.Hin + cy) * p.Win + cx, p.Cin / 8, h * JX);
-#pragma unroll
-            for (int j = 0; j < JX; ++j) xf[j] = ld16(xb + j * 512);
-        } else {
-            const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
-            const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * ((unsigned)p.Cin * 2) + (unsigned)(h * JX * 16);
-#pragma unroll
-            for (int j = 0; j < JX; ++j) xf[j] = ld16(xbase + off + j * 16);
-        }
-        return ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
-    };
-    auto mask_x = [&](u32x4* xf, bool valid) {
-#pragma unroll
-        for (int j = 0; j < JX; ++j) {
-            xf[j].x = valid ? xf[j].x : 0u; xf[j].y = valid ? xf[j].y : 0u; xf[j].z = valid ? xf[j].z : 0u; xf[j].w = valid ? xf[j].w : 0u;
-        }
-    };
-    auto unit_origin = [&](int unit, int& b, int& oy0, int& ox0) {
-        b = unit / tiles;
-        const int tile = unit - b * tiles;
-        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-        oy0 = tyi * TOH; ox0 = txi * TOW;
-    };
-    static_assert(NIB >= NW, "every wave issues the X loads the wait below keeps in flight");
-    static constexpr SetMap<TOH, TOW, IWQ> kSets{};
-    const int kg = lane >> 4;
-
-    u32x4 xa[JX];
-    bool va = false;
-    int b, oy0, ox0;
-    if (unit0 >= units) return;
-    unit_origin(unit0, b, oy0, ox0);
-    va = load_x(b, oy0, ox0, wave, xa);
-    cf_sync_lds_dma_keep<JX>();              // weights / table landed for every wave
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {
-        const int unit = unit0 + t;
-        if (unit >= units) break;
-        mask_x(xa, va);
-        // ---- phase 1: expand + Swish -> quad cells
-        for (int ib = wave; ib < NIB; ib += NW) {
-            u32x4 xn[JX];
-            const bool more = ib + NW < NIB;
-            bool vn = false;
-            if (more) vn = load_x(b, oy0, ox0, ib + NW, xn);
-            f32x16 a;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
-            const char* wb = Wst + lane * 16;
-#pragma unroll
-            for (int j = 0; j < JX; ++j) {
-                const u32x4 wv = ld16(wb + j * 1024);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xa[j]),
-                                                            __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
-            }
-            char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)CP + pl * 8;
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                f32x2 u0, u1; u0.x = a[4 * tt]; u0.y = a[4 * tt + 1]; u1.x = a[4 * tt + 2]; u1.y = a[4 * tt + 3];
-                const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
-                u32x2 d;
-                d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
-                d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
-                *reinterpret_cast<u32x2*>(ecell + 2 * tt * CP) = d;
-            }
-            if (more) {
-#pragma unroll
-                for (int j = 0; j < JX; ++j) xa[j] = xn[j];
-                mask_x(xa, vn);
-            }
-        }
-        __syncthreads();
-        // the next unit's first X fragments travel while this unit's depthwise runs
-        const int bc = b, oyc = oy0, oxc = ox0;
-        if (t + 1 < T && unit + 1 < units) {
-            unit_origin(unit + 1, b, oy0, ox0);
-            va = load_x(b, oy0, ox0, wave, xa);
-        }
-        // ---- phase 2: depthwise on the matrix cores + Swish
-        for (int set = wave; set < NSET; set += NW) {
-            const uint32_t e = kSets.v[set * 16 + (lane & 15)];
-            const int oy = (e >> 6) & 0x1ff, oxq = e & 63;
-            const bool live = (e & 0x8000u) == 0;
-            f32x4 acc[8];
-            const char* bb = E + (unsigned)(oy * IWQ + oxq) * (unsigned)CP + kg * 64;
-            mx_depthwise_lds<KS, IWQ, CP>(bb, Ats + lane * 8, acc);
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; i += 2) {
-                    f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
-                    const f32x2 y = swish2_pre(u) * kNegLn23;
-                    acc[g][i] = y.x; acc[g][i + 1] = y.y;
-                }
-            const int gy = oyc + oy, gx0 = oxc + 4 * oxq;
-            if (!live || gy >= p.Hout) continue;
-            const size_t opix0 = ((size_t)bc * p.Hout + gy) * p.Wout + gx0;
-            const int chunk = grp * 4 + kg;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (gx0 + i >= p.Wout) break;
-                u32x4 o;
-                o.x = packb(acc[0][i], acc[1][i]); o.y = packb(acc[2][i], acc[3][i]);
-                o.z = packb(acc[4][i], acc[5][i]); o.w = packb(acc[6][i], acc[7][i]);
-                const size_t opix = opix0 + i;
-                st16((char*)p.y + (p.yblock ? blk_off(opix, p.hid / 8, chunk) : (opix * p.hid + (size_t)chunk * 8) * 2), o);
-            }
-        }
-        __syncthreads();                      // every wave is done reading E before the next unit's expand overwrites it
-    }
-}
-#endif  // CF_EXPERIMENTS
+#include CF_EXP_INC(cf_mbconv3_0)   // rounds-persistent variant: measured slower (profiles/r03_mfma_depthwise.md), experiments build only
 
 // ================================================================== fully fused block: expand -> depthwise -> project (+residual)
 // One workgroup per output tile; the hidden channels go through the tile in rounds of 32 (+ an optional last round of 16:
@@ -810,282 +511,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv_mx_kernel(MbParams p) {
     }
 }
 
-#ifdef CF_EXPERIMENTS   // role-specialised waves: measured slower, experiments build only
-// ================================================================== fused block with ROLE-SPECIALISED waves (stride 1)
-// mbconv_mx_kernel alternates a transcendental-bound phase (expand + Swish) and a matrix-pipe-bound one (depthwise) behind
-// barriers: a 4x4x4 MFMA costs ~13 cycles of SIMD time there instead of the ~4.5 it costs beside dense VALU work (ablation in
-// profiles/r03_mfma_depthwise.md).  Here a workgroup has eight waves in two roles on a DOUBLE-BUFFERED tile: waves 0-3 expand
-// round q + 1 into E[(q + 1) & 1] while waves 4-7 run depthwise + Swish + project of round q from E[q & 1]; every SIMD then
-// always holds one wave issuing transcendentals and one feeding the matrix pipe.  One barrier per round.  The roles share one
-// register array (X fragments / project accumulators) so that two workgroups fit a CU.
-// MEASURED SLOWER than mbconv_mx_kernel (layer1.1 0.204 vs 0.181 ms, layer2.1 0.084 vs 0.082; 0.286 / 0.112 with one workgroup per
-// CU): three independent workgroups per SIMD already interleave the two phases, and the pipeline's fill and drain steps idle one
-// role.  Kept as CF_FX_VARIANT=6 (parity green), not in the default table.
-template <int KS, int JX, int NMB, int TOH, int TOW, bool TAIL16>
-struct Fz {
-    static constexpr int NR = 4;                                    // waves per role
-    static constexpr int IH = TOH + KS - 1, IWQ = TOW / 4 + 1, IWP = IWQ * 4;
-    static constexpr int NQD = IH * IWQ, NIB = (NQD + 7) / 8, IPX = NQD * 4, MAXI = (NIB + NR - 1) / NR;
-    static constexpr int CP8 = 32 * 8 + 16, CP4 = 16 * 8 + 16;
-    static constexpr int EBYTES = NIB * 8 * CP8;
-    static constexpr int NOQ = TOH * (TOW / 4), NSET = (NOQ + 15) / 16;
-    static constexpr int WXB = JX * 1024, ATB = 2 * KS * 2 * 512;
-    static constexpr int LDS = 2 * EBYTES + 2 * WXB + 2 * ATB;
-    static_assert(NSET == NR && TOW % 4 == 0 && KS <= 5 && (NMB == 2 || NMB == 4), "one set per depthwise wave");
-    static_assert(!TAIL16 || JX <= 2, "16-channel round: one 16x16x32 expand MFMA, Cin <= 32");
-};
-
-template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, bool TAIL16>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void mbconv_mxs_kernel(MbParams p) {
-    typedef Fz<KS, JX, NMB, TOH, TOW, TAIL16> G;
-    constexpr int IWQ = G::IWQ, IWP = G::IWP, IPX = G::IPX, NIB = G::NIB, MAXI = G::MAXI, CP8 = G::CP8, CP4 = G::CP4;
-    constexpr int WXB = G::WXB, NR = G::NR;
-    typedef __attribute__((ext_vector_type(4))) __bf16 mfma_bf16x4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Wst = smem + 2 * G::EBYTES;
-    char* Ats = Wst + 2 * WXB;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = wave8 >> 2, wave = wave8 & 3;                  // role 0: expand, role 1: depthwise + project
-    const int pl = lane & 31, h = lane >> 5, kg = lane >> 4;
-    const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH, b = blockIdx.z;
-    const int nq = p.nq;
-    const int nrounds = nq + (TAIL16 ? 1 : 0);
-
-    const char* xbase = (const char*)p.x + (size_t)b * p.Hin * p.Win * p.Cin * 2;
-    const unsigned rowbytes = (unsigned)p.Cin * 2;
-
-    // ---- expand role state: X fragments of this wave's halo pixel blocks
-    static_assert(MAXI * JX <= 4 * NMB, "the two roles share one register array");
-    u32x4 st[4 * NMB];                                               // role 0: X fragments; role 1: project accumulators
-#define xf(t, j) st[(t) * JX + (j)]
-#define pacc(i, mb) (*reinterpret_cast<f32x4*>(&st[(i) * NMB + (mb)]))
-    if (role == 0) {
-#pragma unroll
-        for (int t = 0; t < MAXI; ++t) {
-            const int ib = wave + NR * t;
-            const int ip = ib * 32 + pl;
-            const int ipc = ip < IPX ? ip : IPX - 1;
-            const int iy = ipc / IWP, ix = ipc - iy * IWP;
-            const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
-            const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
-            const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
-            const unsigned off = ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(h * JX * 16);
-#pragma unroll
-            for (int j = 0; j < JX; ++j) {
-                const u32x4 v = ld16(xbase + off + j * 16);
-                xf(t, j).x = valid ? v.x : 0u; xf(t, j).y = valid ? v.y : 0u;
-                xf(t, j).z = valid ? v.z : 0u; xf(t, j).w = valid ? v.w : 0u;
-            }
-        }
-    }
-    auto stage_w = [&](int q) {                 // expand role: expand weights of round q -> stage q & 1
-        char* dst = Wst + (q & 1) * WXB;
-        const char* srcx = (const char*)p.wexp + (size_t)q * WXB;
-        for (int c = wave; c < WXB / 1024; c += NR)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx + c * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
-    };
-    auto stage_a = [&](int q) {                 // depthwise role: Toeplitz table of round q -> stage q & 1
-        char* dst = Ats + (q & 1) * G::ATB;
-        const char* srca = (const char*)p.wdw + (size_t)q * G::ATB;
-        for (int c = wave; c < G::ATB / 1024; c += NR)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srca + c * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
-    };
-    auto expand_round = [&](int q) {            // full round q (32 channels) -> E[q & 1]
-        char* E = smem + (q & 1) * G::EBYTES;
-        const char* wx = Wst + (q & 1) * WXB;
-#pragma unroll
-        for (int t = 0; t < MAXI; ++t) {
-            const int ib = wave + NR * t;
-            if (ib >= NIB) break;
-            f32x16 a;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
-#pragma unroll
-            for (int j = 0; j < JX; ++j) {
-                const u32x4 wv = ld16(wx + (j * 64 + lane) * 16);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, xf(t, j)),
-                                                            __builtin_bit_cast(mfma_bf16x8, wv), a, 0, 0, 0);
-            }
-            char* ecell = E + (unsigned)(ib * 8 + h) * (unsigned)CP8 + pl * 8;
-#pragma unroll
-            for (int tq = 0; tq < 4; ++tq) {
-                f32x2 u0, u1; u0.x = a[4 * tq]; u0.y = a[4 * tq + 1]; u1.x = a[4 * tq + 2]; u1.y = a[4 * tq + 3];
-                const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
-                u32x2 d;
-                d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
-                d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
-                *reinterpret_cast<u32x2*>(ecell + 2 * tq * CP8) = d;
-            }
-        }
-    };
-    auto expand_tail = [&]() {                  // last round: 16 channels on 16x16x32 MFMAs -> E[nq & 1], cell row 144 B
-        char* E = smem + (nq & 1) * G::EBYTES;
-        const u32x4 wv = ld16((const char*)p.wexp + (size_t)nq * WXB + lane * 16);
-        for (int sb = wave; sb < NIB * 2; sb += NR) {
-            const int ip = sb * 16 + (lane & 15), kc = lane >> 4;
-            const int ipc = ip < IPX ? ip : IPX - 1;
-            const int iy = ipc / IWP, ix = ipc - iy * IWP;
-            const int gy = oy0 - p.pad_lo + iy, gx = ox0 - p.pad_lo + ix;
-            const bool valid = ip < IPX && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win && kc * 8 < p.Cin;
-            const int cy = min(max(gy, 0), p.Hin - 1), cx = min(max(gx, 0), p.Win - 1);
-            u32x4 xv = ld16(xbase + ((unsigned)cy * (unsigned)p.Win + (unsigned)cx) * rowbytes + (unsigned)(min(kc * 8, p.Cin - 8) * 2));
-            xv.x = valid ? xv.x : 0u; xv.y = valid ? xv.y : 0u; xv.z = valid ? xv.z : 0u; xv.w = valid ? xv.w : 0u;
-            f32x4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, xv), __builtin_bit_cast(mfma_bf16x8, wv), a4, 0, 0, 0);
-            f32x2 u0, u1; u0.x = a4[0]; u0.y = a4[1]; u1.x = a4[2]; u1.y = a4[3];
-            const f32x2 y0 = swish2_pre(u0), y1 = swish2_pre(u1);
-            u32x2 d;
-            d.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y0.x, y0.y));
-            d.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y1.x, y1.y));
-            *reinterpret_cast<u32x2*>(E + (unsigned)(sb * 4 + kc) * (unsigned)CP4 + (lane & 15) * 8) = d;
-        }
-    };
-
-    // ---- depthwise role state: this wave's output quads (one set) and its project accumulators
-    static constexpr SetMap<TOH, TOW, IWQ> kSets{};
-    const uint32_t se = kSets.v[wave * 16 + (lane & 15)];
-    const unsigned qcell = ((se >> 6) & 0x1ff) * IWQ + (se & 63);
-    if (role == 1) {
-#pragma unroll
-        for (int i = 0; i < 4 * NMB; ++i) st[i] = u32x4{0u, 0u, 0u, 0u};
-    }
-    u32x4 wpc[NMB];
-    auto load_wp = [&](int q) {
-#pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) wpc[mb] = ld16((const char*)p.wproj + (((size_t)q * NMB + mb) * 64 + lane) * 16);
-    };
-    auto dw_round = [&](int q) {                // depthwise + Swish + project of full round q from E[q & 1]
-        const char* E = smem + (q & 1) * G::EBYTES;
-        f32x4 acc[8];
-        mx_depthwise_lds1<KS, IWQ, CP8>(E + qcell * (unsigned)CP8 + kg * 64, Ats + (q & 1) * G::ATB + lane * 8, acc);
-#pragma unroll
-        for (int g = 0; g < 8; ++g)
-#pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
-                const f32x2 y = swish2_pre(u);
-                acc[g][i] = y.x; acc[g][i + 1] = y.y;
-            }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x4 d;
-            d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
-            d.z = packb(acc[4][i], acc[5][i]); d.w = packb(acc[6][i], acc[7][i]);
-#pragma unroll
-            for (int mb = 0; mb < NMB; ++mb)
-                st[i * NMB + mb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wpc[mb]), __builtin_bit_cast(mfma_bf16x8, d),
-                                                                                         __builtin_bit_cast(f32x4, st[i * NMB + mb]), 0, 0, 0));
-        }
-    };
-    auto dw_tail = [&]() {                      // the 16-channel round from E[nq & 1] (cell row 144 B)
-        const char* E = smem + (nq & 1) * G::EBYTES;
-        u32x2 A4[KS][2];
-        {
-            const u32x2* at = reinterpret_cast<const u32x2*>(p.wdw) + (size_t)nq * (2 * KS * 2) * 64 + lane;
-#pragma unroll
-            for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) A4[ky][ks] = at[(ky * 2 + ks) * 64];
-        }
-        u32x2 wp4[NMB];
-#pragma unroll
-        for (int mb = 0; mb < NMB; ++mb)
-            wp4[mb] = *reinterpret_cast<const u32x2*>((const char*)p.wproj + (size_t)nq * NMB * 1024 + ((size_t)mb * 64 + lane) * 8);
-        const char* bb = E + qcell * (unsigned)CP4 + kg * 32;
-        f32x4 acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int st = 0; st < KS * 2; ++st) {
-            const char* bs = bb + ((st >> 1) * IWQ + (st & 1)) * CP4;
-            const u32x4 b0 = ld16(bs), b1 = ld16(bs + 16);
-            const mfma_f16x4 av = __builtin_bit_cast(mfma_f16x4, A4[st >> 1][st & 1]);
-            u32x2 t0, t1, t2, t3; t0.x = b0.x; t0.y = b0.y; t1.x = b0.z; t1.y = b0.w; t2.x = b1.x; t2.y = b1.y; t3.x = b1.z; t3.y = b1.w;
-            CF_MX_MFMA(acc[0], av, __builtin_bit_cast(mfma_f16x4, t0), 0);
-            CF_MX_MFMA(acc[1], av, __builtin_bit_cast(mfma_f16x4, t1), 1);
-            CF_MX_MFMA(acc[2], av, __builtin_bit_cast(mfma_f16x4, t2), 2);
-            CF_MX_MFMA(acc[3], av, __builtin_bit_cast(mfma_f16x4, t3), 3);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                f32x2 u; u.x = acc[g][i]; u.y = acc[g][i + 1];
-                const f32x2 y = swish2_pre(u);
-                acc[g][i] = y.x; acc[g][i + 1] = y.y;
-            }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x2 d; d.x = packb(acc[0][i], acc[1][i]); d.y = packb(acc[2][i], acc[3][i]);
-#pragma unroll
-            for (int mb = 0; mb < NMB; ++mb)
-                st[i * NMB + mb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mfma_bf16x4, wp4[mb]), __builtin_bit_cast(mfma_bf16x4, d),
-                                                                                           __builtin_bit_cast(f32x4, st[i * NMB + mb]), 0, 0, 0));
-        }
-    };
-
-    // ---- pipeline: round r is expanded during step r - 1 (step -1 = the prologue) and consumed during step r
-    if (role == 0) stage_w(0); else { stage_a(0); load_wp(0); }
-    cf_sync_lds_dma();                                               // W(0), A(0) landed
-    if (role == 0) {
-        expand_round(0);                                             // nq >= 1 always
-        if (nq > 1) stage_w(1);
-    }
-    cf_sync_lds_dma();                                               // E[0] complete, W(1) landed
-    for (int r = 0; r < nrounds; ++r) {
-        if (role == 0) {
-            if (r + 1 < nq) {
-                expand_round(r + 1);
-                if (r + 2 < nq) stage_w(r + 2);                      // stage (r + 2) & 1 = r & 1: last read by expand_round(r), one step ago
-            } else if (TAIL16 && r + 1 == nq) {
-                expand_tail();
-            }
-        } else {
-            if (r < nq) {
-                if (r + 1 < nq) stage_a(r + 1);                      // stage (r + 1) & 1: last read by dw_round(r - 1), one step ago
-                dw_round(r);
-                if (r + 1 < nq) load_wp(r + 1);
-            } else {
-                dw_tail();
-            }
-        }
-        if (r + 1 < nrounds) cf_sync_lds_dma();                      // E[(r + 1) & 1] complete and E[r & 1] free; DMAs landed
-    }
-    if (role == 0) return;
-
-    // ---- epilogue (depthwise role): lane (kq = lane >> 4, quad slot): channels 8 kq .. + 7 (+ 32) of the four pixels of its quad
-    const int oy = (se >> 6) & 0x1ff, oxq = se & 63;
-    const int gy = oy0 + oy, gx0 = ox0 + 4 * oxq;
-    if ((se & 0x8000u) || gy >= p.Hout) return;
-    const size_t opix0 = ((size_t)b * p.Hout + gy) * p.Wout + gx0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (gx0 + i >= p.Wout) break;
-        const size_t opix = opix0 + i;
-#pragma unroll
-        for (int mp = 0; mp < NMB / 2; ++mp) {
-            const int ch = mp * 32 + kg * 8;
-            if (ch >= p.Cout) break;
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = __builtin_bit_cast(f32x4, st[i * NMB + 2 * mp])[r]; v[4 + r] = __builtin_bit_cast(f32x4, st[i * NMB + 2 * mp + 1])[r]; }
-            if constexpr (RESID) {
-                float rr[8];
-                unpack16<bf16_t>(ld16((const char*)p.x + (opix * p.Cin + ch) * 2), rr);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = rr[r] + v[r];
-            }
-            st16((char*)p.y + (p.yblock ? blk_off(opix, p.Cout / 8, ch / 8) : (opix * p.Cout + ch) * 2), pack16b(v));
-        }
-    }
-}
-#undef xf
-#undef pacc
-#endif  // CF_EXPERIMENTS
+#include CF_EXP_INC(cf_mbconv3_1)   // role-specialised waves: measured slower, experiments build only
 
 // ================================================================== fully fused block, stride 2 (layer1.0, layer2.0)
 // The input halo of a stride-2 tile is four times the output tile, so the LDS budget allows 32 output quads = two sets per
@@ -1384,47 +810,8 @@ static hipError_t xmx_launch_t(hipStream_t s, const MbParams& p) {
     hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, q);
     return hipGetLastError();
 }
-#ifdef CF_EXPERIMENTS
-template <int KS, int JX, int TOH, int TOW, int NW, int R>
-static hipError_t xmxr_launch_t(hipStream_t s, const MbParams& p) {
-    typedef Mx<KS, JX, TOH, TOW, NW, true> G;
-    constexpr int LDS = G::EBYTES + 2 * (G::WXB + G::ATB);
-    auto kfn = expdw_mxr_kernel<KS, JX, TOH, TOW, NW, R>;
-    static thread_local bool configured_dev[32] = {};
-    int dev = 0; (void)hipGetDevice(&dev);
-    bool& configured = configured_dev[dev & 31];
-    if (LDS > 64 * 1024 && !configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    if ((p.hid / 32) % R) return hipErrorInvalidValue;
-    dim3 grid(((p.Wout + TOW - 1) / TOW) * ((p.Hout + TOH - 1) / TOH), p.hid / 32 / R, p.B), blk(NW * 64);
-    set_kernel_tag("void cf::expdw_mxr_kernel<%d, %d, %d, %d, %d, %d>(cf::MbParams)", KS, JX, TOH, TOW, NW, R);
-    hipLaunchKernelGGL(kfn, grid, blk, LDS, s, p);
-    return hipGetLastError();
-}
-#endif
-#ifdef CF_EXPERIMENTS
-template <int KS, int JX, int TOH, int TOW, int NW, int T>
-static hipError_t xmxt_launch_t(hipStream_t s, const MbParams& p) {
-    typedef Mx<KS, JX, TOH, TOW, NW, true> G;
-    auto kfn = expdw_mxt_kernel<KS, JX, TOH, TOW, NW, T>;
-    static thread_local bool configured_dev[32] = {};
-    int dev = 0; (void)hipGetDevice(&dev);
-    bool& configured = configured_dev[dev & 31];
-    if (G::LDS > 64 * 1024 && !configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    const int units = ((p.Wout + TOW - 1) / TOW) * ((p.Hout + TOH - 1) / TOH) * p.B;
-    dim3 grid((units + T - 1) / T, p.hid / 32, 1), blk(NW * 64);
-    set_kernel_tag("void cf::expdw_mxt_kernel<%d, %d, %d, %d, %d, %d>(cf::MbParams)", KS, JX, TOH, TOW, NW, T);
-    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
-    return hipGetLastError();
-}
-#endif
+#include CF_EXP_INC(cf_mbconv3_2)
+#include CF_EXP_INC(cf_mbconv3_3)
 #define XMT(V, KS, JX, TOH, TOW, NW, T) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, true>::LDS, &xmxt_launch_t<KS, JX, TOH, TOW, NW, T>}
 #define XMR(V, KS, JX, TOH, TOW, NW, R) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, true>::EBYTES + 2 * (Mx<KS, JX, TOH, TOW, NW, true>::WXB + Mx<KS, JX, TOH, TOW, NW, true>::ATB), &xmxr_launch_t<KS, JX, TOH, TOW, NW, R>}
 #define XMX(V, KS, JX, TOH, TOW, NW, AL) {KS, JX, TOH, TOW, NW, V, Mx<KS, JX, TOH, TOW, NW, (AL != 0)>::LDS, &xmx_launch_t<KS, JX, TOH, TOW, NW, (AL != 0)>}
@@ -1434,41 +821,7 @@ static const MxEntry kXmxTable[] = {
     XMX(0, 5, 6, 10, 40, 8, 1),      // 4.1   96 -> 576, 40x40: 0.083 ms [0.101]
     XMX(0, 5, 10, 20, 20, 4, 0),     // 5.1  160 -> 960, 20x20: 0.047 ms [0.057]
     XMX(0, 3, 10, 10, 20, 4, 1),     // 6.0  160 -> 960, 20x20: 0.042 ms [0.044]
-#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
-    // variants for A/B runs (CF_MX_VARIANT=n): all within +-8 % of the above
-    XMX(1, 5, 4, 8, 40, 5, 1),
-    XMX(1, 5, 6, 8, 40, 5, 1),
-    XMX(1, 5, 10, 20, 20, 7, 1),
-    XMX(1, 3, 10, 20, 20, 7, 1),
-    XMX(2, 5, 4, 20, 40, 4, 0),
-    XMX(2, 5, 6, 20, 40, 4, 0),
-    XMX(2, 5, 10, 20, 20, 4, 1),
-    XMX(2, 3, 10, 20, 20, 4, 1),
-    XMX(3, 5, 4, 10, 40, 4, 0),
-    XMX(3, 5, 6, 10, 40, 4, 0),
-    XMX(3, 5, 10, 10, 20, 4, 1),
-    XMX(3, 3, 10, 20, 20, 4, 0),
-    XMX(4, 5, 4, 20, 40, 7, 0),
-    XMX(4, 5, 6, 20, 40, 7, 0),
-    // rounds-persistent workgroups (expdw_mxr_kernel)
-    XMR(5, 5, 4, 10, 40, 8, 6),      // 4.0: 12 rounds -> 2 per tile
-    XMR(5, 5, 6, 10, 40, 8, 9),      // 4.1: 18 rounds -> 2 per tile
-    XMR(5, 5, 10, 10, 20, 4, 5),     // 5.1: 30 rounds
-    XMR(5, 3, 10, 10, 20, 4, 5),     // 6.0
-    XMR(6, 5, 4, 10, 40, 8, 3),
-    XMR(6, 5, 6, 10, 40, 8, 3),
-    XMR(6, 5, 10, 20, 20, 4, 3),
-    XMR(6, 3, 10, 20, 20, 4, 3),
-    XMR(7, 5, 4, 10, 40, 4, 4),
-    XMR(7, 5, 6, 10, 40, 4, 6),
-    XMR(7, 5, 10, 20, 20, 4, 6),
-    XMR(7, 3, 10, 20, 20, 4, 6),
-    // tile-persistent workgroups (expdw_mxt_kernel): T consecutive tile units per workgroup
-    XMT(8, 5, 4, 10, 40, 8, 2), XMT(8, 5, 6, 10, 40, 8, 2), XMT(8, 5, 10, 20, 20, 4, 2), XMT(8, 3, 10, 10, 20, 4, 2),
-    XMT(9, 5, 4, 10, 40, 8, 4), XMT(9, 5, 6, 10, 40, 8, 4), XMT(9, 5, 10, 20, 20, 4, 4), XMT(9, 3, 10, 10, 20, 4, 4),
-    XMT(10, 5, 4, 10, 40, 8, 8), XMT(10, 5, 6, 10, 40, 8, 8), XMT(10, 5, 10, 20, 20, 4, 8), XMT(10, 3, 10, 10, 20, 4, 8),
-    XMT(11, 5, 4, 10, 40, 8, 16), XMT(11, 5, 6, 10, 40, 8, 16), XMT(11, 5, 10, 20, 20, 4, 16), XMT(11, 3, 10, 10, 20, 4, 16),
-#endif  // CF_EXPERIMENTS
+#include CF_EXP_INC(cf_mbconv3_4)   // never-default variants: A/B runs of an experiments build only
 };
 #undef XMT
 #undef XMX
@@ -1590,26 +943,7 @@ CF_FX_ILP_INSTANCES(CF_X)
 #endif
 
 #ifndef CF_ILP_TU
-#ifdef CF_EXPERIMENTS
-template <int KS, int JX, int NMB, bool RESID, int TOH, int TOW, bool TAIL16>
-static hipError_t fz_launch_t(hipStream_t s, const MbParams& p) {
-    typedef Fz<KS, JX, NMB, TOH, TOW, TAIL16> G;
-    auto kfn = mbconv_mxs_kernel<KS, JX, NMB, RESID, TOH, TOW, TAIL16>;
-    static thread_local bool configured_dev[32] = {};
-    int dev = 0; (void)hipGetDevice(&dev);
-    bool& configured = configured_dev[dev & 31];
-    if (G::LDS > 64 * 1024 && !configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    dim3 grid((p.Wout + TOW - 1) / TOW, (p.Hout + TOH - 1) / TOH, p.B), blk(512);
-    set_kernel_tag("void cf::mbconv_mxs_kernel<%d, %d, %d, %s, %d, %d, %s>(cf::MbParams)", KS, JX, NMB, RESID ? "true" : "false", TOH, TOW,
-                   TAIL16 ? "true" : "false");
-    hipLaunchKernelGGL(kfn, grid, blk, G::LDS, s, p);
-    return hipGetLastError();
-}
-#endif
+#include CF_EXP_INC(cf_mbconv3_5)
 #define FXE(V, KS, JX, NMB, RES, TAIL, TOH, TOW, NW, XR, AL) \
     {KS, JX, NMB, RES, TAIL, TOH, TOW, NW, V, Fx<KS, JX, NMB, TOH, TOW, NW, (TAIL != 0), (AL != 0)>::LDS, \
      &fx_launch_t<KS, JX, NMB, (RES != 0), TOH, TOW, NW, (TAIL != 0), (XR != 0), (AL != 0)>}
@@ -1619,24 +953,7 @@ static const FxEntry kFxTable[] = {
     FXE(0, 3, 2, 2, 1, 1, 16, 16, 4, 0, 1),     // 1.1  24 -> 144 -> 24 (+res), 160x160, four rounds of 32 + one of 16: 0.175 ms [0.205]
     // variants for A/B runs (CF_FX_VARIANT=n); 3.1 (64 -> 384 -> 64, 40x40) stays on cf_mbconv2.hip: 0.097-0.106 ms here against 0.063,
     // and the Cout = 96 blocks (4.0 / 4.1) stay split (fused here: 0.115 / 0.210 ms against 0.082 / 0.120 for the two launches)
-#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
-    FXE(1, 5, 2, 2, 1, 0, 16, 16, 4, 1, 1),
-    FXE(2, 5, 2, 2, 1, 0, 16, 16, 4, 0, 0),
-    FXE(3, 5, 2, 2, 1, 0, 16, 20, 5, 0, 1),
-    FXE(1, 3, 2, 2, 1, 1, 16, 16, 4, 1, 1),
-    FXE(2, 3, 2, 2, 1, 1, 16, 20, 5, 0, 1),
-    FXE(3, 3, 2, 2, 1, 1, 32, 16, 4, 1, 1),
-    FXE(1, 3, 4, 4, 1, 0, 16, 16, 4, 1, 1),
-    FXE(2, 3, 4, 4, 1, 0, 8, 40, 5, 1, 1),
-    // wide tiles, eight waves, single-buffered operand reads (<= 128 VGPRs: four waves per SIMD)
-    {3, 2, 2, 1, 1, 16, 32, 8, 4, Fx<3, 2, 2, 16, 32, 8, true, true>::LDS, &fx_launch_t<3, 2, 2, true, 16, 32, 8, true, true, true, true>},
-    {5, 2, 2, 1, 0, 16, 32, 8, 4, Fx<5, 2, 2, 16, 32, 8, false, true>::LDS, &fx_launch_t<5, 2, 2, true, 16, 32, 8, false, true, true, true>},
-    {3, 2, 2, 1, 1, 16, 16, 4, 5, Fx<3, 2, 2, 16, 16, 4, true, true>::LDS, &fx_launch_t<3, 2, 2, true, 16, 16, 4, true, true, true, true>},
-    {5, 2, 2, 1, 0, 16, 16, 4, 5, Fx<5, 2, 2, 16, 16, 4, false, true>::LDS, &fx_launch_t<5, 2, 2, true, 16, 16, 4, false, true, true, true>},
-    // role-specialised waves on a double-buffered tile (mbconv_mxs_kernel)
-    {3, 2, 2, 1, 1, 16, 16, 8, 6, Fz<3, 2, 2, 16, 16, true>::LDS, &fz_launch_t<3, 2, 2, true, 16, 16, true>},
-    {5, 2, 2, 1, 0, 16, 16, 8, 6, Fz<5, 2, 2, 16, 16, false>::LDS, &fz_launch_t<5, 2, 2, true, 16, 16, false>},
-#endif  // CF_EXPERIMENTS
+#include CF_EXP_INC(cf_mbconv3_6)   // never-default variants: A/B runs of an experiments build only
 };
 #undef FXE
 static const FxEntry* fx_find(int k, int jx, int nmb, int res, int tail) {
@@ -1762,12 +1079,7 @@ static const FsEntry kFsTable[] = {
     FSE(0, 5, 2, 2, 1, 8, 16, 0, 0),      // 2.0  24 -> 144 -> 32, 160x160 -> 80x80, four rounds of 32 + one of 16: 0.150 ms [0.177]
     // layer1.0 (16 -> 96 -> 24, 3x3, 320x320 -> 160x160) stays on cf_mbconv2.hip: its depthwise is 4 % of the block's work and
     // 12 800 small workgroups pay the operand-table fetch three times each: 0.264 ms here (0.327 with the table in LDS) vs 0.246
-#ifdef CF_EXPERIMENTS   // never-default variants: A/B runs of an experiments build only
-    FSE(1, 3, 1, 2, 0, 8, 16, 0, 0),
-    FSE(1, 5, 2, 2, 1, 8, 16, 0, 1),
-    FSE(2, 3, 1, 2, 0, 8, 16, 0, 1),
-    FSE(2, 5, 2, 2, 1, 8, 16, 1, 0),
-#endif  // CF_EXPERIMENTS
+#include CF_EXP_INC(cf_mbconv3_7)   // never-default variants: A/B runs of an experiments build only
 };
 #undef FSE
 static const FsEntry* fs_find(int k, int jx, int nmb, int tail) {

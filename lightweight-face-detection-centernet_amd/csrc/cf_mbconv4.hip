@@ -15,6 +15,7 @@
 //     consecutive rows of the tile (one 16-byte bank slot apart) instead of every second one (two-way conflict).
 // Exact mode: no weight folding and the same swish2() as the other fp32 kernels (its arithmetic is what the goldens pin);
 // split mode (SP): Swish factors folded into the expand / project weights like cf_mbconv.hip (swish2_sel<true>).
+#include "cf_exp.h"
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <cstdlib>
@@ -387,40 +388,7 @@ static const F4Entry kF4Table[] = {
     F4E(1, 3, 1, 8, 32, 2, 1, 8, 16, 4),     // 3.1  64 -> 384 -> 64
     F4E(1, 5, 1, 8, 32, 3, 0, 8, 16, 4),     // 4.0  64 -> 384 -> 96
     F4E(1, 5, 1, 12, 32, 3, 1, 8, 16, 4),    // 4.1  96 -> 576 -> 96
-#ifdef CF_EXPERIMENTS   // A/B sweep of the split mode (CF_F4_VARIANT=3..6): small stride-2 tiles, X fragments resident for wide Cin
-    F4X(3, 3, 2, 2, 32, 1, 0, 4, 16, 2, 0),    // 1.0 4x16, KG 2
-    F4X(4, 3, 2, 2, 32, 1, 0, 4, 16, 4, 0),    // 1.0 4x16, KG 4
-    F4X(5, 3, 2, 2, 96, 1, 0, 4, 16, 4, 0),    // 1.0 4x16, HC 96
-    F4X(6, 3, 2, 2, 48, 1, 0, 4, 16, 2, 0),    // 1.0 4x16, HC 48 (KG 2: 3 pairs each)
-    F4X(3, 5, 2, 3, 48, 1, 0, 4, 16, 2, 0),    // 2.0 4x16 HC 48 KG 2
-    F4X(4, 5, 2, 3, 48, 1, 0, 4, 16, 3, 0),    // 2.0 4x16 HC 48 KG 3
-    F4X(5, 5, 2, 3, 16, 1, 0, 4, 16, 2, 0),    // 2.0 4x16 HC 16 KG 2
-    F4X(6, 5, 2, 3, 16, 1, 0, 8, 16, 4, 0),    // 2.0 8x16 HC 16 KG 2
-    F4X(3, 3, 2, 4, 32, 2, 0, 4, 16, 2, 0),    // 3.0 4x16 KG 2
-    F4X(4, 3, 2, 4, 32, 2, 0, 4, 16, 4, 0),    // 3.0 4x16 KG 4
-    F4X(5, 3, 2, 4, 64, 2, 0, 4, 16, 4, 0),    // 3.0 4x16 HC 64
-    F4X(6, 3, 2, 4, 32, 2, 0, 8, 16, 8, 0),    // 3.0 8x16 KG 4
-    F4X(3, 3, 1, 8, 32, 2, 1, 8, 16, 4, 0),    // 3.1 X resident, 4 waves
-    F4X(4, 3, 1, 8, 32, 2, 1, 8, 16, 8, 0),    // 3.1 X resident, 8 waves (KG 4)
-    F4X(5, 3, 1, 8, 64, 2, 1, 8, 16, 8, 0),    // 3.1 HC 64, 8 waves
-    F4X(6, 3, 1, 8, 64, 2, 1, 8, 16, 4, 0),    // 3.1 HC 64, 4 waves
-    F4X(3, 5, 1, 8, 32, 3, 0, 8, 16, 4, 0),    // 4.0 X resident, 4 waves
-    F4X(4, 5, 1, 8, 32, 3, 0, 8, 16, 8, 0),    // 4.0 X resident, 8 waves
-    F4X(5, 5, 1, 8, 64, 3, 0, 8, 16, 8, 0),    // 4.0 HC 64
-    F4X(6, 5, 1, 8, 32, 3, 0, 8, 16, 8, 1),    // 4.0 X reload, 8 waves
-    F4X(3, 5, 1, 12, 32, 3, 1, 8, 16, 4, 0),   // 4.1 X resident, 4 waves
-    F4X(4, 5, 1, 12, 32, 3, 1, 8, 16, 8, 0),   // 4.1 X resident, 8 waves
-    F4X(5, 5, 1, 12, 64, 3, 1, 8, 16, 8, 0),   // 4.1 HC 64
-    F4X(6, 5, 1, 12, 32, 3, 1, 8, 16, 8, 1),   // 4.1 X reload, 8 waves
-    F4X(3, 3, 1, 3, 48, 1, 1, 8, 16, 2, 0),    // 1.1 2 waves
-    F4X(4, 3, 1, 3, 48, 1, 1, 8, 16, 6, 0),    // 1.1 KG 3
-    F4X(5, 3, 1, 3, 144, 1, 1, 8, 16, 4, 0),   // 1.1 HC 144 (one round)
-    F4X(6, 3, 1, 3, 48, 1, 1, 16, 16, 4, 0),   // 1.1 16x16
-    F4X(3, 5, 1, 4, 32, 1, 1, 8, 16, 8, 0),    // 2.1 KG 4
-    F4X(4, 5, 1, 4, 64, 1, 1, 8, 16, 4, 0),    // 2.1 HC 64
-    F4X(5, 5, 1, 4, 64, 1, 1, 8, 16, 8, 0),    // 2.1 HC 64 KG 4
-    F4X(6, 5, 1, 4, 32, 1, 1, 16, 16, 4, 0),   // 2.1 16x16
-#endif
+#include CF_EXP_INC(cf_mbconv4_0)   // A/B sweep of the split mode (CF_F4_VARIANT=3..6): small stride-2 tiles, X fragments resident for wide Cin
 };
 #undef F4E
 #undef F4X
@@ -430,9 +398,8 @@ static const F4Entry* f4_find(int dtype, int k, int s, int jx, int nbo, int res)
     // build only (var 2 = the split mode's own defaults: never selectable for the exact mode, whose goldens pin the arithmetic)
     static const int want = [] {
         const int v = cf_env_int("CF_F4_VARIANT", 0);
-#ifdef CF_EXPERIMENTS
-        return v == 2 ? 0 : v;
-#else
+#include CF_EXP_INC(cf_mbconv4_1)
+#if !CF_EXP_ON
         return v == 1 ? 1 : 0;
 #endif
     }();

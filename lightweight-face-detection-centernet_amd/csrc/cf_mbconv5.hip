@@ -22,6 +22,7 @@
 // The depthwise output leaves in PIXEL-BLOCK order [m / 32][hid / 4][m % 32][4 channels] (PwParams::xblock: the project GEMM's
 // B operand is then one 512-byte run per wave half and k-step) or NHWC.  Split mode (SP): Swish factors as cf_mbconv.hip
 // (-log2 e folded into the expand weights, the leftover -ln 2 multiplied in here, before the store).
+#include "cf_exp.h"
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <cstdlib>
@@ -394,50 +395,7 @@ static const X5Entry kX5Table[] = {
     X5E(0, 5, 2, 12, 32, 5, 20, 8, 0, 1, 18),     // 5.0   96 -> 576, 40x40 -> 20x20
     X5M(0, 5, 1, 20, 32, 10, 20, 12, 0, 1, 3, 10), // 5.1  160 -> 960, 20x20: twelve waves = one halo block each, its 80 fragment registers resident (0.134 -> 0.119)
     X5E(0, 3, 1, 20, 32, 10, 20, 8, 1, 1, 10),    // 6.0  160 -> 960, 20x20
-#ifdef CF_EXPERIMENTS
-    X5E(8, 5, 1, 20, 32, 10, 20, 8, 0, 0, 10),      // 8: layer5.1 with eight waves, X re-read (the first table row); 6.0 on twelve waves
-    X5M(8, 3, 1, 20, 32, 10, 20, 12, 1, 1, 3, 10),
-    X5M(9, 5, 1, 20, 32, 10, 20, 12, 0, 1, 3, 30),  // 9: ... every chunk in one workgroup
-    X5M(9, 3, 1, 20, 32, 10, 20, 12, 1, 1, 3, 30),
-    X5E(7, 5, 1, 8, 32, 10, 20, 8, 0, 0, 4),      // 7: two workgroups per CU, 10x20 tiles, X re-read (the first table row above)
-    X5E(7, 5, 1, 12, 32, 10, 20, 8, 0, 0, 6),
-    X5E(7, 5, 2, 12, 16, 5, 20, 8, 0, 0, 12),
-    X5E(7, 3, 1, 20, 32, 10, 20, 8, 1, 0, 10),
-    // resident, pre-split X fragments, one workgroup per CU; the same on 10x40 tiles (40x40 maps) and with every chunk in one workgroup
-    X5E(1, 5, 1, 8, 32, 10, 20, 8, 1, 1, 4),
-    X5E(1, 5, 1, 12, 32, 10, 20, 8, 1, 1, 6),
-    X5E(1, 5, 2, 12, 16, 5, 20, 8, 1, 1, 12),
-    X5E(1, 5, 1, 20, 32, 10, 20, 8, 1, 1, 10),
-    X5E(1, 3, 1, 20, 32, 10, 20, 8, 1, 1, 10),
-    X5E(2, 5, 1, 8, 32, 10, 40, 8, 1, 1, 12),
-    X5E(2, 5, 1, 12, 32, 10, 40, 8, 1, 1, 18),
-    X5E(2, 5, 2, 12, 32, 5, 20, 8, 1, 1, 18),
-    X5E(2, 5, 1, 20, 32, 20, 20, 8, 1, 1, 30),
-    X5E(2, 3, 1, 20, 32, 20, 20, 8, 1, 1, 30),
-    X5E(3, 5, 1, 8, 32, 10, 20, 8, 1, 1, 12),
-    X5E(3, 5, 1, 12, 32, 10, 20, 8, 1, 1, 18),
-    X5E(3, 5, 2, 12, 16, 5, 20, 8, 1, 1, 36),
-    X5E(3, 5, 1, 20, 32, 10, 20, 8, 1, 1, 30),
-    X5E(3, 3, 1, 20, 32, 10, 20, 8, 1, 1, 30),
-    // hidden chunks of 64 (the X load / split of a block serves two MFMA blocks), re-read X, 256-register budget, row pipeline
-    X5M(4, 5, 1, 8, 64, 10, 20, 8, 1, 0, 2, 6),
-    X5M(4, 5, 1, 12, 64, 10, 20, 8, 1, 0, 2, 9),
-    X5M(4, 5, 2, 12, 32, 5, 20, 8, 1, 0, 2, 18),
-    X5M(4, 5, 1, 20, 64, 10, 20, 8, 1, 0, 2, 15),
-    X5M(4, 3, 1, 20, 64, 10, 20, 8, 1, 0, 2, 15),
-    // big tiles, chunks of 32, re-read X, 256-register budget, row pipeline
-    X5M(5, 5, 1, 8, 32, 10, 40, 8, 1, 0, 2, 12),
-    X5M(5, 5, 1, 12, 32, 10, 40, 8, 1, 0, 2, 18),
-    X5M(5, 5, 2, 12, 32, 5, 20, 8, 1, 0, 2, 9),
-    X5M(5, 5, 1, 20, 32, 20, 20, 8, 1, 0, 2, 30),
-    X5M(5, 3, 1, 20, 32, 20, 20, 8, 1, 0, 2, 30),
-    // the same with fewer chunks per workgroup (more workgroups)
-    X5M(6, 5, 1, 8, 32, 10, 40, 8, 1, 0, 2, 4),
-    X5M(6, 5, 1, 12, 32, 10, 40, 8, 1, 0, 2, 6),
-    X5M(6, 5, 2, 12, 32, 5, 20, 8, 1, 0, 2, 6),
-    X5M(6, 5, 1, 20, 32, 20, 20, 8, 1, 0, 2, 10),
-    X5M(6, 3, 1, 20, 32, 20, 20, 8, 1, 0, 2, 10),
-#endif
+#include CF_EXP_INC(cf_mbconv5_0)
 };
 #undef X5E
 #undef X5M

@@ -16,6 +16,7 @@
 // their B fragments (lane = pixel, 16 bytes per k-step); the project accumulators stay in registers across the hidden chunks
 // (one 32-channel block: Cout <= 32).  X fragments are loaded and SPLIT into bf16 (hi, lo) once per workgroup and stay in
 // registers for all chunks.  Two barriers per chunk: [expand -> E] B1 [depthwise E -> D] B2 [project D -> acc].
+#include "cf_exp.h"
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <cstdlib>
@@ -324,23 +325,7 @@ static const M6Entry kM6Table[] = {
     // columns (20 instead of 18): it pays only where the depthwise dominates the block -- 5x5 stride 1.  Only layer2.1 runs here.
     // var KS S JX HC res tile   waves regs-for-waves/SIMD
     M6E(0, 5, 1, 4, 32, 1, 8, 16, 8, 4),     // 2.1  32 -> 192 -> 32: eight waves (two k-groups), two workgroups per CU
-#ifdef CF_EXPERIMENTS   // the sweep (CF_M6_VARIANT=1..4)
-    M6E(1, 3, 1, 4, 48, 1, 8, 16, 8, 4),     // 1.1  24 -> 144 -> 24 (JX: Cin = 24 -> 3 chunks per half, padded to 4)
-    M6E(1, 3, 2, 2, 16, 0, 8, 16, 8, 4),     // 1.0  16 ->  96 -> 24
-    M6E(1, 5, 2, 4, 16, 0, 8, 16, 8, 4),     // 2.0  24 -> 144 -> 32
-    M6E(2, 3, 1, 4, 48, 1, 16, 16, 8, 2),    // 16x16 tiles, one workgroup per CU
-    M6E(2, 5, 1, 4, 32, 1, 16, 16, 8, 2),
-    M6E(2, 3, 2, 2, 16, 0, 8, 16, 4, 2),     // stride 2: four waves
-    M6E(2, 5, 2, 4, 16, 0, 8, 16, 8, 2),
-    M6E(3, 3, 1, 4, 16, 1, 8, 16, 4, 2),     // chunks of 16 (E + D = 24 KB: more workgroups per CU)
-    M6E(3, 5, 1, 4, 16, 1, 8, 16, 4, 2),
-    M6E(3, 3, 2, 2, 32, 0, 4, 16, 4, 2),     // stride 2: 4x16 tiles
-    M6E(3, 5, 2, 4, 16, 0, 4, 16, 4, 2),
-    M6E(4, 3, 1, 4, 48, 1, 8, 16, 4, 2),     // four waves, one k-group
-    M6E(4, 5, 1, 4, 32, 1, 8, 16, 4, 2),
-    M6E(4, 3, 2, 2, 32, 0, 8, 16, 8, 2),
-    M6E(4, 5, 2, 4, 16, 0, 8, 16, 4, 2),
-#endif
+#include CF_EXP_INC(cf_mbconv6_0)   // the sweep (CF_M6_VARIANT=1..4)
 };
 #undef M6E
 

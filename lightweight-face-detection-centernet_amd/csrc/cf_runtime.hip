@@ -8,6 +8,7 @@
 // versus ~140 ATen ops in the reference.  Activations are NHWC in a handful of
 // reused HBM buffers (ping/pong + expanded + depthwise) so the working set of a batch stays small
 // and L2 / Infinity-Cache resident between producer and consumer where it fits.
+#include "cf_exp.h"
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -24,9 +25,7 @@
 #include <vector>
 
 #include "centerface_hip.h"
-#ifdef CF_EXPERIMENTS
-#include "cf_experiments.h"
-#endif
+#include CF_EXP_INC(cf_runtime_0)
 #include "cf_common.h"
 #include "cf_kernels.h"
 
@@ -1104,9 +1103,8 @@ int launch_all_ops(cf_ctx* c, const void* net_in, int in_format, int B) {
 
 extern "C" {
 
-#ifdef CF_EXPERIMENTS
-#define CF_FLUSH_LANE(c) do { if ((c)->lane_pending) { int rl_ = cf_forward_lanes_flush(c); if (rl_) return rl_; } } while (0)
-#else
+#include CF_EXP_INC(cf_runtime_1)
+#if !CF_EXP_ON
 #define CF_FLUSH_LANE(c) do { } while (0)
 #endif
 
@@ -1149,90 +1147,7 @@ int cf_forward(cf_ctx* c, const void* in, int in_format, int in_on_device, int B
     return CF_OK;
 }
 
-#ifdef CF_EXPERIMENTS   // measured 2-8 % slower than the free-running pair of contexts: not in the release library
-// ---- two-lane schedule (experimental): the forward is cut into three segments -- front A (stem .. the
-// op before cut 1), front B (cut 1 .. the op before cut 2) and the back half (cut 2 .. heads).  With two contexts alternating
-// batches, cf_forward_lanes(cur, prev, ...) enqueues
-//   1. front A of the new batch on cur's stream, after prev's front B           (front A runs ALONE: it is VALU-bound)
-//   2. the back half of prev's batch on prev's stream, after cur's front A      (HBM- / latency-bound, small grids)
-//   3. front B of the new batch on cur's stream                                 (runs UNDERNEATH 2: the mid-size kernels)
-// so which kernels share the chip is fixed by events instead of by how two free-running chains happen to line up.  prev's
-// results are complete after this call's work (decode it now); cf_forward_lanes_flush(c) launches a back half that has no
-// successor (end of stream, fences).  Eager launches (no graph): the segments are tens of microseconds each at any batch.
-static int lane_cuts(cf_ctx* c) {
-    if (c->lane_cut1 >= 0) return CF_OK;
-    const char* n1 = getenv("CF_LANE_CUT1") ? getenv("CF_LANE_CUT1") : "layer2.0";      // (experiments build only: this whole section)
-    const char* n2 = getenv("CF_LANE_CUT2") ? getenv("CF_LANE_CUT2") : "layer4.0";
-    int c1 = -1, c2 = -1;
-    for (size_t i = 0; i < c->ops.size(); ++i) {
-        if (c->ops[i].fused_away) continue;
-        if (c1 < 0 && c->ops[i].name.rfind(n1, 0) == 0) c1 = (int)i;
-        if (c2 < 0 && c->ops[i].name.rfind(n2, 0) == 0) c2 = (int)i;
-    }
-    if (c1 < 0 || c2 < 0 || c1 > c2) return c->fail(CF_EINVAL, "cf_forward_lanes: cut points %s / %s not found in the plan", n1, n2);
-    c->lane_cut1 = c1; c->lane_cut2 = c2;
-    if (!c->ev_seg1) HIPCHK(c, hipEventCreateWithFlags(&c->ev_seg1, hipEventDisableTiming));
-    if (!c->ev_seg2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_seg2, hipEventDisableTiming));
-    return CF_OK;
-}
-static int launch_range(cf_ctx* c, int lo, int hi, const void* net_in, int in_format, int B) {
-    for (int i = lo; i < hi; ++i) {
-        const Op& op = c->ops[i];
-        if (op.fused_away) continue;
-        if (op.kind == OP_HEAD && c->dec_pending) {       // the overlapped decode of the batch before still reads heads / hm_plane
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dec, 0));
-            c->dec_pending = false;
-        }
-        HIPCHK(c, launch_op(c, op, net_in, in_format, B));
-    }
-    return CF_OK;
-}
-static int lane_back_half(cf_ctx* p) {
-    int r = launch_range(p, p->lane_cut2, (int)p->ops.size(), p->lane_in, p->lane_fmt, p->lane_B);
-    if (r) return r;
-    HIPCHK(p, hipEventRecord(p->ev_fwd, p->stream));
-    p->lane_pending = false;
-    p->last_B = p->lane_B;
-    return CF_OK;
-}
-
-int cf_forward_lanes(cf_ctx* cur, cf_ctx* prev, const void* in, int in_format, int in_on_device, int B) {
-    if (!cur || cur == prev) return CF_EINVAL;
-    if (prev && prev->device != cur->device) return cur->fail(CF_EINVAL, "cf_forward_lanes: both contexts must live on one device");
-    int r = lane_cuts(cur); if (r) return r;
-    if (cur->lane_pending) { r = lane_back_half(cur); if (r) return r; }       // its own earlier batch never got a successor
-    const void* net_in = nullptr;
-    r = stage_input(cur, in, in_format, in_on_device, B, &net_in);
-    if (r) return r;
-    static const bool alone = cf_ab_int("CF_LANE_ALONE", 1) != 0;        // A/B: front A may overlap prev's front B
-    if (alone && prev && prev->seg2_recorded) HIPCHK(cur, hipStreamWaitEvent(cur->stream, prev->ev_seg2, 0));
-    r = launch_range(cur, 0, cur->lane_cut1, net_in, in_format, B); if (r) return r;
-    HIPCHK(cur, hipEventRecord(cur->ev_seg1, cur->stream));
-    if (cur->in_slot_used >= 0) {                       // the stem has read the host-input staging slot
-        HIPCHK(cur, hipEventRecord(cur->ev_slot_free[cur->in_slot_used], cur->stream));
-        cur->slot_busy[cur->in_slot_used] = true;
-        cur->in_slot_used = -1;
-    }
-    if (prev && prev->lane_pending) {
-        HIPCHK(prev, hipSetDevice(prev->device));
-        HIPCHK(prev, hipStreamWaitEvent(prev->stream, cur->ev_seg1, 0));
-        r = lane_back_half(prev); if (r) return r;
-    }
-    r = launch_range(cur, cur->lane_cut1, cur->lane_cut2, net_in, in_format, B); if (r) return r;
-    HIPCHK(cur, hipEventRecord(cur->ev_seg2, cur->stream));
-    cur->seg2_recorded = true;
-    cur->lane_pending = true; cur->lane_in = net_in; cur->lane_fmt = in_format; cur->lane_B = B;
-    cur->last_B = 0;                                    // no decodable result on cur until its back half has been launched
-    return CF_OK;
-}
-
-int cf_forward_lanes_flush(cf_ctx* c) {
-    if (!c) return CF_EINVAL;
-    if (!c->lane_pending) return CF_OK;
-    HIPCHK(c, hipSetDevice(c->device));
-    return lane_back_half(c);
-}
-#endif  // CF_EXPERIMENTS
+#include CF_EXP_INC(cf_runtime_2)   // measured 2-8 % slower than the free-running pair of contexts: not in the release library
 
 int cf_forward_resized(cf_ctx* c, const void* imgs, int in_on_device, int B, int h, int w) {
     if (!c || !imgs || h < 1 || w < 1) return CF_EINVAL;

@@ -10,6 +10,7 @@
 // reads its 3 x 72 contiguous elements per output pixel from there.  Same arithmetic, same operation
 // order as cf_pw.hip (IDAUp epilogue) followed by cf_head.hip (collapsed), so results are bit-identical
 // to the two-kernel path.
+#include "cf_exp.h"
 #include "cf_common.h"
 #include "cf_kernels.h"
 #include <cstdlib>
@@ -192,29 +193,7 @@ hipError_t launch_uphead(hipStream_t s, int dtype, const UpHeadParams& p) {
     if (p.B <= 0) return hipSuccess;
     static const bool xcd_on = cf_ab_int("CF_UH_XCD", 0) >= 1;      // A/B only: 0.090 -> 0.094 ms with it
     UpHeadParams q = p; q.xcd = xcd_on ? 1 : 0;
-#ifdef CF_EXPERIMENTS
-    static const int var = cf_ab_int("CF_UH_VARIANT", 0);           // A/B sweep of tile height / waves / non-temporal record stores
-    if (dtype == 1) {
-        if (cf_ab_int("CF_UH_COALESCE", 1) == 0) return uphead_launch_t<bf16_t, false, 8, 4, false>(s, q);
-        switch (var) {
-            case 1: return uphead_launch_t<bf16_t, true, 8, 4, true>(s, q);
-            case 2: return uphead_launch_t<bf16_t, true, 16, 8, false>(s, q);
-            case 3: return uphead_launch_t<bf16_t, true, 8, 4, false>(s, q);       // the round-3 geometry
-            case 4: return uphead_launch_t<bf16_t, true, 16, 4, true>(s, q);
-            case 5: return uphead_launch_t<bf16_t, true, 32, 8, true>(s, q);
-            case 6: return uphead_launch_t<bf16_t, true, 8, 8, true>(s, q);
-            default: break;
-        }
-    } else if (dtype == 2) {
-        switch (var) {
-            case 1: return uphead_launch_t<sp32_t, true, 8, 4, true>(s, q);
-            case 2: return uphead_launch_t<sp32_t, true, 16, 8, true>(s, q);
-            case 3: return uphead_launch_t<sp32_t, true, 4, 4, true>(s, q);
-            case 4: return uphead_launch_t<sp32_t, true, 16, 16, true>(s, q);
-            default: break;
-        }
-    }
-#endif
+#include CF_EXP_INC(cf_uphead_0)
     // bf16: 16 x 32 tiles on eight waves, non-temporal record stores: halo rows 2 / 8 -> 2 / 16 of the skip / low fetch (B = 64, 640x640,
     // HIP events, same box: 8x32 / 4 waves 79.0 us, + non-temporal 78.1, 16x32 / 8 waves 73.2, + non-temporal 72.3; 16x32 / 4 waves 84.9,
     // 32x32 / 8 waves 86.4, 8x32 / 8 waves 91.4); every variant is bit-identical to the two-kernel path (test_fused_up3_heads_...)

@@ -15,9 +15,8 @@
 // the per-workgroup fixed costs (fragment load + split, the k-group reduction with eight barriers, the epilogue) outweigh the
 // chunk loop, and the k = 8 MFMA form runs the matrix pipe at half efficiency.  Experiments build only (CF_M7=1); the release
 // library contains none of it.
-#include "cf_common.h"
-#include "cf_kernels.h"
-#ifdef CF_EXPERIMENTS
+#include "../cf_common.h"
+#include "../cf_kernels.h"
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -329,7 +328,7 @@ static const M7Entry kM7Table[] = {
     M7E(0, 3, 1, 4, 48, 1, 8, 16, 6, 3),     // 1.1  24 -> 144 -> 24: six waves (JX: Cin = 24 -> 3 chunks per half, padded to 4)
     M7E(0, 3, 2, 2, 32, 0, 8, 16, 4, 2),     // 1.0  16 ->  96 -> 24
     M7E(0, 5, 2, 4, 16, 0, 8, 16, 2, 2),     // 2.0  24 -> 144 -> 32
-#ifdef CF_EXPERIMENTS   // CF_M7_VARIANT=1..3
+    // CF_M7_VARIANT=1..3
     M7E(1, 5, 1, 4, 32, 1, 8, 16, 2, 2),     // two waves, two steps each
     M7E(1, 3, 1, 4, 48, 1, 8, 16, 3, 2),     // three waves, two steps each
     M7E(1, 3, 2, 2, 32, 0, 8, 16, 2, 2),
@@ -339,7 +338,6 @@ static const M7Entry kM7Table[] = {
     M7E(3, 5, 1, 4, 32, 1, 16, 16, 8, 2),    // 16x16 tiles
     M7E(3, 3, 1, 4, 48, 1, 16, 16, 6, 2),
     M7E(3, 3, 2, 2, 16, 0, 8, 16, 2, 2),     // stride 2, chunks of 16
-#endif
 };
 #undef M7E
 
@@ -404,10 +402,3 @@ hipError_t mb7_launch(hipStream_t s, const MbParams& p) {
 }
 
 }  // namespace cf
-#else
-namespace cf {
-bool mb7_geometry(int, MbGeom&, int, int, int, int, int) { return false; }
-void mb7_pack(const MbGeom&, int, int, int, int, const float*, const float*, const float*, void*, float*, void*) {}
-hipError_t mb7_launch(hipStream_t, const MbParams&) { return hipErrorInvalidValue; }
-}  // namespace cf
-#endif

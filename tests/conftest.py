@@ -12,7 +12,7 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
-def pytest_configure(config):
+def _markers(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "isolated: stresses the runtime (churn, hazards, threads, placement): runs in a child interpreter, after the parity tests")
 
@@ -62,7 +62,7 @@ PROGRESS = os.environ.get("CF_TEST_PROGRESS") or os.path.join(tempfile.gettempdi
 _fault_lib = None
 
 
-def _install_native_fault_handler():
+def _install_native_fault_handler(config):
     global _fault_lib
     import ctypes
     import faulthandler
@@ -74,20 +74,33 @@ def _install_native_fault_handler():
             subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", so, src], check=True, capture_output=True, timeout=120)
         lib = ctypes.CDLL(so)
         lib.cf_fault_note.argtypes = [ctypes.c_char_p]
+        lib.cf_fault_install.argtypes = [ctypes.c_int]
+        # pytest redirects fd 2 into a capture file while a test runs: both handlers must write to the REAL stderr, i.e. to the
+        # duplicate pytest's own faulthandler plugin made before capturing started (or to our own, made now, with capture suspended)
+        fd = None
+        try:
+            from _pytest.faulthandler import fault_handler_stderr_fd_key
+            fd = config.stash.get(fault_handler_stderr_fd_key, None)
+        except Exception:                            # noqa: BLE001
+            pass
+        if fd is None:
+            fd = os.dup(2)
         was_on = faulthandler.is_enabled()
         if was_on:
             faulthandler.disable()
-        lib.cf_fault_install()                       # first in, last to run: faulthandler chains to the handler it replaced
+        lib.cf_fault_install(fd)                     # first in, last to run: faulthandler chains to the handler it replaced
         if was_on:
-            faulthandler.enable(file=sys.__stderr__, all_threads=True)
+            faulthandler.enable(file=fd, all_threads=True)
         _fault_lib = lib
     except Exception as e:                           # noqa: BLE001  (diagnostics only: never a reason to fail a run)
         sys.__stderr__.write("conftest: native fault handler not installed (%s)\n" % e)
 
 
-def pytest_sessionstart(session):
+@pytest.hookimpl(trylast=True)
+def pytest_configure(config):
+    _markers(config)
     if not os.environ.get("CF_NO_FAULT_HANDLER"):
-        _install_native_fault_handler()
+        _install_native_fault_handler(config)
 
 
 def pytest_runtest_logstart(nodeid, location):

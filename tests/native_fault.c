@@ -16,6 +16,7 @@
 #include <sys/syscall.h>
 
 static char g_note[512] = "(no test id recorded)";
+static int g_fd = 2;          /* where to write: the conftest passes a dup of the REAL stderr (pytest redirects fd 2 while a test runs) */
 
 void cf_fault_note(const char* s) {
     if (!s) return;
@@ -29,16 +30,17 @@ static void handler(int sig, siginfo_t* si, void* uc) {
     char head[800];
     int n = snprintf(head, sizeof head, "\n=== native fault: signal %d in thread %ld of pid %d (si_addr %p) while running: %s ===\n", sig,
                      (long)syscall(SYS_gettid), (int)getpid(), si ? si->si_addr : (void*)0, g_note);
-    if (n > 0 && write(2, head, (size_t)n) < 0) { }
+    if (n > 0 && write(g_fd, head, (size_t)n) < 0) { }
     int k = backtrace(frames, 96);
-    backtrace_symbols_fd(frames, k, 2);
+    backtrace_symbols_fd(frames, k, g_fd);
     n = snprintf(head, sizeof head, "=== native fault: end (test: %s) ===\n", g_note);
-    if (n > 0 && write(2, head, (size_t)n) < 0) { }
+    if (n > 0 && write(g_fd, head, (size_t)n) < 0) { }
     signal(sig, SIG_DFL);
     raise(sig);
 }
 
-void cf_fault_install(void) {
+void cf_fault_install(int fd) {
+    if (fd >= 0) g_fd = fd;
     void* warm[4];
     backtrace(warm, 4);                      /* loads libgcc now, not inside the handler */
     struct sigaction sa;
@@ -51,5 +53,5 @@ void cf_fault_install(void) {
 }
 
 __attribute__((constructor)) static void on_load(void) {
-    if (getenv("CF_FAULT_PRELOAD")) cf_fault_install();      /* LD_PRELOAD use: install at load time */
+    if (getenv("CF_FAULT_PRELOAD")) cf_fault_install(2);      /* LD_PRELOAD use: install at load time */
 }
