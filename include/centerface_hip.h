@@ -320,8 +320,18 @@ int cf_graph_stats(cf_ctx* ctx, int* n_graphs, int* n_uncapturable);
  * (cf_forward from pageable memory stages through the driver and blocks the caller for the copy) */
 int cf_host_alloc(cf_ctx* ctx, uint64_t bytes, void** hptr);
 int cf_host_free(cf_ctx* ctx, void* hptr);
+/* The same without a context (any device may DMA from it; hipHostMalloc, portable): for a host's frame pool. */
+int cf_pinned_alloc(uint64_t bytes, void** hptr);
+int cf_pinned_free(void* hptr);
 /* Page-lock / release memory the caller owns (no context needed; any device may then DMA from it).  For buffers that are reused:
- * registering costs a page-table walk (~0.1 ms per MB).  Errors: cf_op_last_error(). */
+ * registering costs a page-table walk (~0.1 ms per MB).  Errors: cf_op_last_error().
+ * CONTRACT (round 6): `hptr` is page-aligned (4096), `bytes` a multiple of the page size, and the range is a mapping OF ITS OWN
+ * (mmap, shm, a device driver's buffer) -- NOT memory from malloc / new / numpy.  Registration works on pages and on the kernel's
+ * view of the mapping; the C library grows, trims and reuses its heap (brk) underneath live registrations, and the GPU then faults on
+ * a page it was told is locked ("Memory access fault by GPU ... Reason: Unknown", SIGABRT from the HSA runtime's event thread).
+ * Measured on MI355X / ROCm 7 (tools/diag/pin_churn_probe.py, 45 s of allocation churn per run): heap memory 6 faults in 22 runs,
+ * whole pages inside a heap array 1 in 6, mmap regions 0 in 6, cf_pinned_alloc memory 0 in 6.  An unaligned pointer or size is
+ * CF_EINVAL; whose mapping it is cannot be checked here (cfa.pin refuses the [heap] segment).  Prefer cf_pinned_alloc. */
 int cf_host_register(void* hptr, uint64_t bytes);
 int cf_host_unregister(void* hptr);
 /* device memory helpers so a host language without a GPU allocator can keep inputs resident */

@@ -22,7 +22,7 @@ EXPORTS = (
     "cf_version", "cf_strerror", "cf_last_error", "cf_device_count", "cf_create", "cf_destroy",
     "cf_load_weights", "cf_forward", "cf_forward_resized", "cf_forward_images", "cf_upload_images", "cf_forward_uploaded", "cf_get_resized_input", "cf_get_heads", "cf_decode_topk", "cf_decode_topk_post", "cf_affine_from_center_scale", "cf_decode_threshold", "cf_decode_threshold_ex", "cf_decode_threshold_sized", "cf_decode_threshold_enqueue", "cf_set_rescale",
     "cf_detect_topk", "cf_synchronize", "cf_event_record", "cf_event_elapsed_ms",
-    "cf_profile_forward", "cf_plan_size", "cf_plan_op", "cf_forward_trace", "cf_graph_stats", "cf_get_streams", "cf_streams_share_queue", "cf_streams_share_queue_ex", "cf_spread_streams", "cf_reroll_streams", "cf_ctdet_loss", "cf_comm_unique_id", "cf_comm_create", "cf_comm_create_all", "cf_comm_create_loopback", "cf_comm_loopback_rank", "cf_comm_destroy", "cf_comm_abort", "cf_comm_query", "cf_comm_synchronize", "cf_comm_last_error", "cf_comm_debug", "cf_comm_set_shard", "cf_comm_stream", "cf_gather_topk", "cf_host_alloc", "cf_host_free", "cf_host_register", "cf_host_unregister", "cf_device_alloc", "cf_device_free", "cf_memcpy_h2d", "cf_memcpy_d2h",
+    "cf_profile_forward", "cf_plan_size", "cf_plan_op", "cf_forward_trace", "cf_graph_stats", "cf_get_streams", "cf_streams_share_queue", "cf_streams_share_queue_ex", "cf_spread_streams", "cf_reroll_streams", "cf_ctdet_loss", "cf_comm_unique_id", "cf_comm_create", "cf_comm_create_all", "cf_comm_create_loopback", "cf_comm_loopback_rank", "cf_comm_destroy", "cf_comm_abort", "cf_comm_query", "cf_comm_synchronize", "cf_comm_last_error", "cf_comm_debug", "cf_comm_set_shard", "cf_comm_stream", "cf_gather_topk", "cf_host_alloc", "cf_host_free", "cf_pinned_alloc", "cf_pinned_free", "cf_host_register", "cf_host_unregister", "cf_device_alloc", "cf_device_free", "cf_memcpy_h2d", "cf_memcpy_d2h",
     "cf_op_last_error", "cf_op_shufflev2", "cf_op_mbconv", "cf_op_expand_dw", "cf_op_ctdet_loss", "cf_op_encode_targets", "cf_op_dwconv", "cf_op_pwconv", "cf_op_stem", "cf_op_idaup", "cf_op_heads",
     "cf_op_ctdet_decode", "cf_op_ctdet_post_process", "cf_op_decode_threshold", "cf_op_decode_threshold_ex", "cf_op_nms", "cf_op_box_match",
 )
@@ -129,6 +129,8 @@ def lib():
         L.cf_reroll_streams.argtypes = [C.c_void_p]
         L.cf_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.cf_host_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.cf_pinned_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+        L.cf_pinned_free.argtypes = [C.c_void_p]
         L.cf_host_register.argtypes = [C.c_void_p, C.c_uint64]
         L.cf_host_unregister.argtypes = [C.c_void_p]
         L.cf_forward_images.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]

@@ -686,16 +686,37 @@ class CenterFace(object):
 
 
 # ---- page-locked caller memory ------------------------------------------------------------------------------------------
+# Round 6.  Round 5 page-locked numpy HEAP memory in place (hipHostRegister on `im.copy()`, and on an aligned window of an np.empty
+# array for pinned_empty).  That is what killed the driver's GPU run of round 5: the C library grows, trims and reuses its heap
+# underneath a live registration, the registration's pages stop being the ones the GPU was given, and a later DMA from the array
+# faults ("Memory access fault by GPU ... on address <heap address>": SIGABRT from the HSA runtime's event thread, no Python
+# exception possible).  tools/diag/pin_churn_probe.py reproduces it in under a minute of allocation churn: 6 faults in 22 runs from heap
+# memory, 1 in 6 even from whole pages inside a heap array, none from mmap regions or hipHostMalloc memory.  Hence:
+#   * pinned_empty / pinned_copy hand out hipHostMalloc memory (cf_pinned_alloc) -- the library never registers numpy's heap;
+#   * pin() only accepts whole pages of a mapping of its own (np.memmap / mmap / shared memory: a frame pool) and refuses the heap.
 _pin_lock = threading.Lock()
-_pin_bases, _pin_sizes = [], {}          # sorted base addresses / base -> bytes, of everything pin() registered
+_pin_bases, _pin_sizes = [], {}          # sorted base addresses / base -> bytes, of every page-locked range handed out or registered
 _pin_ids = {}                            # id(array object handed out by pin / pinned_empty) -> its address (the per-image fast path)
+_PAGE = 4096
+
+
+def _track(addr, nbytes):
+    with _pin_lock:
+        bisect.insort(_pin_bases, addr)
+        _pin_sizes[addr] = nbytes
+
+
+def _untrack(addr):
+    with _pin_lock:
+        if _pin_sizes.pop(addr, None) is None:
+            return False
+        _pin_bases.remove(addr)
+        return True
 
 
 def _unregister(addr):
-    with _pin_lock:
-        if _pin_sizes.pop(addr, None) is None:
-            return
-        _pin_bases.remove(addr)
+    if not _untrack(addr):
+        return
     try:
         _lib.lib().cf_host_unregister(C.c_void_p(addr))
     except Exception:                                              # noqa: BLE001  (interpreter shutdown)
@@ -710,31 +731,51 @@ def _owner(arr):
     return o
 
 
+def _heap_range():
+    """[lo, hi) of the C library's main heap (the ``[heap]`` line of /proc/self/maps), or None."""
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                if ln.rstrip().endswith("[heap]"):
+                    lo, hi = ln.split()[0].split("-")
+                    return int(lo, 16), int(hi, 16)
+    except OSError:
+        pass
+    return None
+
+
 def pin(arr):
-    """Page-lock the memory of a C-contiguous numpy array in place (``cf_host_register``) and return it: batches taken from
-    it reach the GPU by asynchronous DMA with no staging copy (``Engine.forward_images_enqueue``, ``CenterFaceBuckets``).
-    Worth it for buffers that are REUSED (a decoder's frame pool): registering costs ~0.1 ms per MB.  ``unpin`` releases it;
-    so does the garbage collection of the array that owns the memory (a finalizer on the owner unregisters the range BEFORE
-    numpy frees it -- a registration that outlived its memory would make ``is_pinned`` true for whatever array lands on that
-    address next, and ``hipMemcpyAsync`` would then DMA from pages HIP only believes to be locked)."""
+    """Page-lock the memory of a C-contiguous numpy array IN PLACE (``cf_host_register``) and return it: batches taken from it
+    reach the GPU by asynchronous DMA with no staging copy (``Engine.forward_images_enqueue``, ``CenterFaceBuckets``).  Only for
+    memory that is a mapping of its own -- ``np.memmap``, ``mmap.mmap``, a shared-memory segment: a decoder's frame pool -- in whole
+    pages: the address a multiple of 4096, the size too.  Arrays from ``np.empty`` / ``.copy()`` / ``cv2.imread`` live on the C
+    library's heap and are REFUSED (ValueError): registering heap memory faults the GPU once the heap has been trimmed and regrown
+    (the abort of GPUTEST_r05; see the comment above) -- copy such images into ``pinned_empty`` / ``pinned_copy`` buffers instead.
+    ``unpin`` releases the registration; so does the garbage collection of the array that owns the memory (a finalizer on the
+    owner unregisters the range before the mapping can go away)."""
     if not isinstance(arr, np.ndarray) or not arr.flags["C_CONTIGUOUS"] or arr.nbytes == 0:
         raise ValueError("pin needs a non-empty C-contiguous numpy array")
-    addr = arr.ctypes.data
+    addr, nbytes = arr.ctypes.data, arr.nbytes
+    if addr % _PAGE or nbytes % _PAGE:
+        raise ValueError("pin needs whole pages of a mapping of its own (address and size multiples of %d; got 0x%x, %d bytes): "
+                         "numpy heap arrays cannot be page-locked in place -- use pinned_empty / pinned_copy" % (_PAGE, addr, nbytes))
+    heap = _heap_range()
+    if heap is not None and addr < heap[1] and addr + nbytes > heap[0]:
+        raise ValueError("pin: the array lives on the C library's heap; page-locking heap memory in place faults the GPU when the heap "
+                         "is trimmed and regrown -- use pinned_empty / pinned_copy")
     with _pin_lock:
         if addr in _pin_sizes:
-            if _pin_sizes[addr] >= arr.nbytes:
+            if _pin_sizes[addr] >= nbytes:
                 return arr
             raise ValueError("a shorter range at the same address is already pinned")
         k = bisect.bisect_right(_pin_bases, addr) - 1
         lo_clash = k >= 0 and _pin_bases[k] + _pin_sizes[_pin_bases[k]] > addr
-        hi_clash = k + 1 < len(_pin_bases) and _pin_bases[k + 1] < addr + arr.nbytes
+        hi_clash = k + 1 < len(_pin_bases) and _pin_bases[k + 1] < addr + nbytes
         if lo_clash or hi_clash:
             raise ValueError("the array overlaps a range that is already pinned (pin the enclosing array once)")
     owner = _owner(arr)
-    _lib.check(_lib.lib().cf_host_register(C.c_void_p(addr), arr.nbytes), op=True)
-    with _pin_lock:
-        bisect.insort(_pin_bases, addr)
-        _pin_sizes[addr] = arr.nbytes
+    _lib.check(_lib.lib().cf_host_register(C.c_void_p(addr), nbytes), op=True)
+    _track(addr, nbytes)
     weakref.finalize(owner, _unregister, addr)                     # (a no-op after unpin: _unregister forgets the address first)
     _remember(arr)
     return arr
@@ -757,24 +798,53 @@ def _direct_addr(im):
 
 
 def unpin(arr):
+    """Release a ``pin`` registration (``pinned_empty`` memory is released with its last view instead)."""
     _pin_ids.pop(id(arr), None)
     _unregister(arr.ctypes.data)
 
 
+class _PinnedBlock(object):
+    """One hipHostMalloc allocation (``cf_pinned_alloc``) exposed through the array interface; freed when the last numpy view of it
+    is gone (numpy keeps this object as the .base of every view)."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _lib.check(_lib.lib().cf_pinned_alloc(int(nbytes), C.byref(p)), op=True)
+        self.addr, self.nbytes = p.value, int(nbytes)
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.addr, False), "version": 3}
+        _track(self.addr, self.nbytes)
+
+    def __del__(self):
+        addr, self.addr = getattr(self, "addr", None), None
+        if addr:
+            _untrack(addr)
+            try:
+                _lib.lib().cf_pinned_free(C.c_void_p(addr))
+            except Exception:                                      # noqa: BLE001  (interpreter shutdown)
+                pass
+
+
 def pinned_empty(shape, dtype=np.uint8):
-    """``np.empty`` in page-locked memory (page-aligned; released when the array and its views are gone)."""
+    """``np.empty`` in page-locked host memory (hipHostMalloc through ``cf_pinned_alloc``; released when the array and its views are
+    gone): images written here reach the GPU by asynchronous DMA with no staging copy."""
     n = int(np.prod(shape)) * np.dtype(dtype).itemsize
-    raw = np.empty(max(n, 1) + 4096, np.uint8)
-    off = (-raw.ctypes.data) % 4096
-    body = raw[off:off + max(n, 1)]
-    pin(body)                                                      # (its finalizer sits on ``raw``, which views keep alive through .base)
-    out = body[:n].view(dtype).reshape(shape)
+    block = _PinnedBlock(max(n, 1))
+    out = np.asarray(block)[:n].view(dtype).reshape(shape)
     _remember(out)
     return out
 
 
+def pinned_copy(arr):
+    """A copy of ``arr`` in page-locked memory (``pinned_empty`` + one host copy): for images that arrive in pageable memory
+    (``cv2.imread``, a decoder) and are used more than once."""
+    arr = np.asarray(arr)
+    out = pinned_empty(arr.shape, arr.dtype)
+    np.copyto(out, arr)
+    return out
+
+
 def is_pinned(arr):
-    """True when the array's bytes lie inside a range registered by ``pin`` / ``pinned_empty``."""
+    """True when the array's bytes lie inside a range registered by ``pin`` or handed out by ``pinned_empty``."""
     if not isinstance(arr, np.ndarray) or not arr.flags["C_CONTIGUOUS"]:
         return False
     addr = arr.ctypes.data

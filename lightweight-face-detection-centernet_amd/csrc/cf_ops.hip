@@ -99,11 +99,41 @@ extern "C" {
 
 const char* cf_op_last_error(void) { return g_op_error.c_str(); }
 
-// Page-lock memory the caller already owns (a numpy array, cv2.imread's result, a decoder's output buffer) so that cf_forward /
-// cf_forward_resized / cf_forward_images read it by asynchronous DMA, without the staging copy into cf_host_alloc memory.  Costs a
-// page-table walk per call (~0.1 ms per MB): for buffers that are reused, not for one-shot images.
+// Page-locked host memory without a context (hipHostMalloc, portable: every device may DMA from it): what cfa.pinned_empty hands out.
+int cf_pinned_alloc(uint64_t bytes, void** hptr) {
+    if (!hptr || bytes == 0) { g_op_error = "cf_pinned_alloc: null pointer or zero size"; return CF_EINVAL; }
+    *hptr = nullptr;
+    const hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *hptr = nullptr;
+        g_op_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? CF_ENOMEM : CF_EHIP;
+    }
+    return CF_OK;
+}
+int cf_pinned_free(void* hptr) {
+    if (!hptr) return CF_OK;
+    const hipError_t e = hipHostFree(hptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g_op_error = std::string("hipHostFree: ") + hipGetErrorString(e);
+        return CF_EHIP;
+    }
+    return CF_OK;
+}
+
+// Page-lock memory the caller already owns (a mapped frame pool, a shared-memory segment) so that cf_forward / cf_forward_resized /
+// cf_forward_images read it by asynchronous DMA, without the staging copy into cf_host_alloc memory.  Costs a page-table walk per call
+// (~0.1 ms per MB): for buffers that are reused, not for one-shot images.  Whole pages of a mapping of its own only (the header's
+// contract): round 5 registered numpy heap arrays, and the GPU faulted on them once the C library had trimmed and regrown its heap
+// underneath (the SIGABRT of GPUTEST_r05).
 int cf_host_register(void* hptr, uint64_t bytes) {
     if (!hptr || bytes == 0) { g_op_error = "cf_host_register: null pointer or zero size"; return CF_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(hptr) & 4095u) || (bytes & 4095u)) {
+        g_op_error = "cf_host_register: the range must be whole pages (pointer and size multiples of 4096) of a mapping of its own -- not malloc / numpy heap memory; use cf_pinned_alloc";
+        return CF_EINVAL;
+    }
     const hipError_t e = hipHostRegister(hptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
     if (e != hipSuccess) {
         (void)hipGetLastError();

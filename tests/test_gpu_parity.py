@@ -913,6 +913,7 @@ def test_variable_size_buckets_match_per_shape_detectors(dtype):
     pool.close()
 
 
+@pytest.mark.isolated
 def test_variable_size_buckets_product_configuration_128_images():
     """The configs[3] PRODUCT configuration: 128 images of five VGA shapes through CenterFaceBuckets(bf16, max_batch=32)
     -- chunks of 32, page-locked staging reused across chunks and shapes (one grow-only buffer per context), resized
@@ -968,19 +969,79 @@ def test_device_rescale_equals_numpy_floor_divide():
     assert total > 0
 
 
+def _mapped_pinned_copy(im):
+    """A frame-pool style buffer: an anonymous mmap region of whole pages (a mapping of its own -- the only kind of caller memory
+    cfa.pin accepts), page-locked in place; returns (image view, the registered base array)."""
+    import mmap
+    n = im.nbytes
+    base = np.frombuffer(mmap.mmap(-1, (n + 4095) // 4096 * 4096), np.uint8)
+    cfa.pin(base)
+    view = base[:n].reshape(im.shape)
+    view[...] = im
+    return view, base
+
+
+@pytest.mark.isolated
+def test_pin_refuses_heap_memory_and_partial_pages():
+    """Round 6 (the abort of GPUTEST_r05): numpy heap arrays are never page-locked in place.  cfa.pin accepts whole pages of a mapping of
+    its own and refuses everything else with a ValueError; cf_host_register (C ABI) refuses unaligned ranges; pinned_empty /
+    pinned_copy hand out hipHostMalloc memory that is released with its last view."""
+    import ctypes as C
+    import gc
+    import mmap
+    L = cfa._lib.lib()
+    small = np.zeros(9 * 4096, np.uint8)                             # 36 KB: from the brk heap; a page-aligned window of whole pages in it
+    small = small[(-small.ctypes.data) % 4096:][:8 * 4096]
+    for arr in (np.zeros((480, 640, 3), np.uint8), np.zeros(4096 * 4 + 16, np.uint8)[16:], np.zeros(100, np.uint8), small):
+        with pytest.raises(ValueError, match="pinned_empty"):
+            cfa.pin(arr)
+        assert not cfa.is_pinned(arr)
+    with pytest.raises(ValueError):
+        cfa.pin(np.zeros((4, 4), np.uint8)[:, ::2])                 # not C-contiguous
+    buf = np.zeros(3 * 4096, np.uint8)
+    al = (-buf.ctypes.data) % 4096
+    assert L.cf_host_register(C.c_void_p(buf.ctypes.data + al + 8), 4096) == -1 and b"whole pages" in L.cf_op_last_error()
+    assert L.cf_host_register(C.c_void_p(buf.ctypes.data + al), 4000) == -1
+    assert L.cf_host_register(None, 4096) == -1 and L.cf_host_unregister(None) == -1
+    assert L.cf_host_register(C.c_void_p(buf.ctypes.data + al), 0) == -1
+    base = np.frombuffer(mmap.mmap(-1, 8 * 4096), np.uint8)
+    assert cfa.pin(base) is base and cfa.is_pinned(base[100:200]) and cfa.pin(base) is base      # idempotent
+    with pytest.raises(ValueError, match="overlaps"):
+        cfa.pin(base[4096:8192])
+    cfa.unpin(base)
+    assert not cfa.is_pinned(base)
+    a = cfa.pinned_empty((37, 53, 3))
+    b = cfa.pinned_copy(np.arange(24, dtype=np.float32).reshape(2, 3, 4))
+    assert a.shape == (37, 53, 3) and a.dtype == np.uint8 and cfa.is_pinned(a) and cfa.is_pinned(a[3])
+    assert b.dtype == np.float32 and np.array_equal(b, np.arange(24, dtype=np.float32).reshape(2, 3, 4)) and cfa.is_pinned(b)
+    addr = a.ctypes.data
+    row = a[5]
+    del a
+    gc.collect()
+    assert cfa.is_pinned(row)                                       # a view keeps the block alive
+    del row
+    gc.collect()
+    with cfa.centerface._pin_lock:
+        assert addr not in cfa.centerface._pin_sizes                # released with the last view
+    p = C.c_void_p()
+    assert L.cf_pinned_alloc(0, C.byref(p)) == -1 and L.cf_pinned_free(None) == 0
+
+
+@pytest.mark.isolated
 def test_pinned_images_reach_the_gpu_without_staging_and_match():
-    """Page-locked caller images (cfa.pinned_empty / cfa.pin) go through cf_forward_images -- one DMA per image, no staging copy --
-    in CenterFaceBuckets and CenterFace.detect_batch, with the results of the staged path; pageable images keep the staged path."""
+    """Page-locked caller images (cfa.pinned_empty, or cfa.pin on a mapped frame pool) go through cf_forward_images -- one DMA per image, no
+    staging copy -- in CenterFaceBuckets and CenterFace.detect_batch, with the results of the staged path; pageable images keep the staged path."""
     rng = np.random.default_rng(5)
     shapes = [(480, 640), (640, 480), (640, 640), (470, 730)]
     pageable = [rng.integers(0, 256, shapes[i % 4] + (3,), dtype=np.uint8) for i in range(22)]
-    pinned = []
+    pinned, bases = [], []
     for k, im in enumerate(pageable):
         if k % 2:
             a = cfa.pinned_empty(im.shape)
             a[...] = im
         else:
-            a = cfa.pin(im.copy())
+            a, base = _mapped_pinned_copy(im)                        # a caller's own mapping, page-locked in place
+            bases.append(base)
         assert cfa.is_pinned(a) and cfa.is_pinned(a[10:20]) and not cfa.is_pinned(im)
         pinned.append(a)
     calls = {"direct": 0, "staged": 0}
@@ -1020,17 +1081,17 @@ def test_pinned_images_reach_the_gpu_without_staging_and_match():
     for (d1, l1), (d2, l2), i in zip(a, b, sel):
         assert np.array_equal(d1, d2) and np.array_equal(l1, l2)
         assert np.array_equal(d1, want[i][0]) and np.array_equal(l1, want[i][1])
-    for k, arr in enumerate(pinned):
-        if k % 2 == 0:
-            cfa.unpin(arr)
-            assert not cfa.is_pinned(arr)
+    for base in bases:
+        cfa.unpin(base)
+        assert not cfa.is_pinned(base)
 
 
+@pytest.mark.isolated
 def test_upload_forward_split_and_its_error_paths():
     """cf_upload_images / cf_forward_uploaded / cf_forward_images through the C ABI: the split call equals the block call bit for bit
     (network-sized and resized, page-locked and pageable pointers, images adjacent in memory = one DMA run, a batch large enough for
     the shared copy streams); a forward without an upload is CF_ESTATE, an upload replaced by another forward is gone, null images and
-    oversized batches are CF_EINVAL; cf_host_register rejects null / empty ranges."""
+    oversized batches are CF_EINVAL."""
     import ctypes as C
     L = cfa._lib.lib()
     rng = np.random.default_rng(17)
@@ -1039,7 +1100,8 @@ def test_upload_forward_split_and_its_error_paths():
         block = cfa.pinned_empty((B, h, w, 3))                      # adjacent images: cf_upload_images coalesces them into one copy
         block[...] = rng.integers(0, 256, block.shape, dtype=np.uint8)
         loose = [block[b].copy() for b in range(B)]                 # pageable, separately allocated
-        pinned = [cfa.pin(block[b].copy()) for b in range(B)]       # page-locked, separately allocated
+        mapped = [_mapped_pinned_copy(block[b]) for b in range(B)]   # page-locked in place, separately mapped (a caller's frame pool)
+        pinned = [m[0] for m in mapped]
         if (h, w) == (H, W):
             eng.forward_enqueue(block)
         else:
@@ -1066,14 +1128,10 @@ def test_upload_forward_split_and_its_error_paths():
         ptrs[B - 1] = None
         assert L.cf_upload_images(eng._h, ptrs, B, h, w) == -1 and b"null pointer" in L.cf_last_error(eng._h)
         assert L.cf_forward_uploaded(None) == -1 and L.cf_upload_images(None, ptrs, B, h, w) == -1
-        for a in pinned:
-            cfa.unpin(a)
+        eng.synchronize()
+        for m in mapped:
+            cfa.unpin(m[1])
         eng.close()
-    assert L.cf_host_register(None, 16) == -1 and L.cf_host_unregister(None) == -1
-    buf = np.zeros(4096, np.uint8)
-    assert L.cf_host_register(C.c_void_p(buf.ctypes.data), 0) == -1
-    with pytest.raises(ValueError):
-        cfa.pin(np.zeros((4, 4), np.uint8)[:, ::2])                 # not C-contiguous
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32_split"])
@@ -1261,6 +1319,7 @@ def test_ctdet_loss_on_engine_heads_matches_explicit_maps():
     eng.close()
 
 
+@pytest.mark.isolated
 def test_graph_cache_eviction_and_context_churn():
     """More (batch size) keys than the 16-entry hipGraph cache holds: evicted graphs are rebuilt, results stay
     bit-identical to eager launches; then 12 create/destroy cycles of contexts of different shapes (no leaked
@@ -1307,6 +1366,7 @@ def test_bf16_forward_is_bit_reproducible():
 
 
 # ----------------------------------------------------------------------------- round-2 hardening
+@pytest.mark.isolated
 def test_threshold_decode_takes_any_candidate_count_and_reports_truncation():
     """The reference's decode handles any number of cells above the threshold (centerface.py:78-79).  An early-training
     heat map (hm bias -1.79 -> sigmoid 0.143) with a low threshold puts most of a 160x160 map above it: the candidate
@@ -1333,6 +1393,7 @@ def test_threshold_decode_takes_any_candidate_count_and_reports_truncation():
     assert np.array_equal(dets[0], np.asarray(O.decode_d2(hm[0], wh[0], reg[0], (640, 640), threshold=0.1), np.float32)[:100])
 
 
+@pytest.mark.isolated
 def test_threshold_decode_enqueue_then_collect():
     """cf_decode_threshold_enqueue: the decode kernels go into the stream right behind the forward; the collecting call with the
     same parameters returns exactly what a plain decode returns, other parameters or a newer forward make it launch its own."""
@@ -1361,6 +1422,7 @@ def test_threshold_decode_enqueue_then_collect():
     eng.close()
 
 
+@pytest.mark.isolated
 def test_stream_and_buffer_hazards_between_entry_points():
     """(1) forward_resized followed by a host-input forward WITHOUT a sync in between: the resize writes a dedicated
     buffer, so the second call's H2D copy cannot overwrite what the first forward's stem still reads.  (2) A
@@ -1397,6 +1459,7 @@ def test_stream_and_buffer_hazards_between_entry_points():
     eng.close(); ref_eng.close()
 
 
+@pytest.mark.isolated
 def test_two_contexts_driven_from_two_threads():
     """include/centerface_hip.h: "different ctxs may be driven from different threads".  Two threads, each with its own
     Engine (different shapes and modes), run forwards, both decoders and a weight reload concurrently; every result must

@@ -91,6 +91,7 @@ def test_bench_step_configs4_shard_two_contexts_one_communicator():
         e.close()
 
 
+@pytest.mark.isolated
 def test_two_contexts_in_flight_are_deterministic():
     """Two contexts running concurrently on one GPU (the benchmarked schedule) return, step after step, exactly what one context
     returns alone.  Regression test for the LDS-DMA publication race (a wave passing the barrier before another wave's
@@ -117,6 +118,7 @@ def test_two_contexts_in_flight_are_deterministic():
         e.close()
 
 
+@pytest.mark.isolated
 def test_comm_create_all_grouped_and_abort():
     """cf_comm_create_all (the single-process host: n ncclCommInitRank calls inside one ncclGroupStart/End) at n = 1, its
     gather, and cf_comm_abort on a live communicator; two contexts on one device are refused (one rank per GPU)."""
@@ -397,6 +399,7 @@ def test_engine_ring_matches_single_engine_bitwise():
     one.close()
 
 
+@pytest.mark.isolated
 def test_spread_streams_places_contexts_and_keeps_results():
     """cf_spread_streams / cf_streams_share_queue_ex: three contexts' main streams (and one context's decode stream) are re-placed -- all pairwise
     (window 0) and neighbours only (window 2); captured graphs and results stay valid, the probe answers for every selector, bad arguments are
