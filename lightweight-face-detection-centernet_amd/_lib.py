@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 CF_OK = 0
 CF_F32, CF_BF16, CF_F32_SPLIT = 0, 1, 2
 CF_IN_U8_HWC_BGR, CF_IN_F32_NCHW = 0, 1
-CF_FLAG_COLLAPSE_HEADS, CF_FLAG_NO_GRAPH, CF_FLAG_NO_FUSE, CF_FLAG_NO_UPHEAD, CF_FLAG_NO_NECK, CF_FLAG_NO_DECODE_STREAM = 1, 2, 4, 8, 16, 32
+CF_FLAG_COLLAPSE_HEADS, CF_FLAG_NO_GRAPH, CF_FLAG_NO_FUSE, CF_FLAG_NO_UPHEAD, CF_FLAG_NO_NECK, CF_FLAG_NO_DECODE_STREAM, CF_FLAG_STREAM_HIGH = 1, 2, 4, 8, 16, 32, 64
 CF_EOVERFLOW = -6
 
 # every symbol include/centerface_hip.h declares (checked by tests/test_abi.py)

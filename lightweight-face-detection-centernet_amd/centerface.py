@@ -33,7 +33,7 @@ class Engine(object):
     """One cf_ctx: one GPU, one stream, fixed (H, W), batch up to ``max_batch``."""
 
     def __init__(self, height, width, max_batch=1, dtype="fp32", device=0, weights=None,
-                 collapse_heads=None, fuse=True, graph=True, uphead=True, neck=True, decode_stream=True):
+                 collapse_heads=None, fuse=True, graph=True, uphead=True, neck=True, decode_stream=True, high_priority_streams=False):
         L = _lib.lib()
         if dtype not in _DTYPES:
             raise ValueError("dtype must be one of %s" % sorted(_DTYPES))
@@ -47,7 +47,8 @@ class Engine(object):
             collapse_heads = True
         flags = ((_lib.CF_FLAG_COLLAPSE_HEADS if collapse_heads else 0) | (0 if fuse else _lib.CF_FLAG_NO_FUSE)
                  | (0 if graph else _lib.CF_FLAG_NO_GRAPH) | (0 if uphead else _lib.CF_FLAG_NO_UPHEAD)
-                 | (0 if neck else _lib.CF_FLAG_NO_NECK) | (0 if decode_stream else _lib.CF_FLAG_NO_DECODE_STREAM))
+                 | (0 if neck else _lib.CF_FLAG_NO_NECK) | (0 if decode_stream else _lib.CF_FLAG_NO_DECODE_STREAM)
+                 | (_lib.CF_FLAG_STREAM_HIGH if high_priority_streams else 0))
         handle = C.c_void_p()
         _lib.check(L.cf_create(self.device, self.max_batch, self.H, self.W, _DTYPES[dtype], flags, C.byref(handle)))
         self._h = handle
@@ -404,33 +405,42 @@ class EngineRing(object):
         dets, lms, inds = ring.collect(t0)          # waits for batch0 only
     """
 
-    def __init__(self, height, width, depth=2, **engine_kwargs):
+    def __init__(self, height, width, depth=2, placement=None, **engine_kwargs):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         # three or more contexts (small batches: BASELINE configs[4] shards of four 1280x1280 images): six streams on HIP's four hardware
         # queues serialise more than they overlap -- the decodes stay on the main streams (CF_FLAG_NO_DECODE_STREAM): 9.5 -> 12.2 k img/s at depth 3
         engine_kwargs.setdefault("decode_stream", depth < 3)
+        # Where the ring's streams land decides whether its contexts overlap at all.  HIP folds a process's streams onto four hardware queues
+        # PER PRIORITY CLASS and gives a new stream the least-used queue of its class; two main streams on one queue (or on two queues of one
+        # dispatch pipe) run their forwards strictly one after the other (48.2 k img/s instead of 54.4 k at 64 x 640x640, and which of the two a
+        # ring got depended on every stream the process had created before).
+        #   placement="priority" (default since round 6): the ring's streams are created in the HIGHEST priority class (CF_FLAG_STREAM_HIGH),
+        #     which nothing else uses -- up to four streams always get queues of their own, whatever the process did before: 54.3-54.5 k
+        #     from five different histories (tools/queue_order_probe.py), no probe kernels, nothing undocumented relied upon.
+        #   placement="probe": round 5's mechanism -- default-priority streams, pairs tested with spin kernels (cf_streams_share_queue_ex),
+        #     cf_spread_streams re-places them all when two clash (54.5 k; kept for A/B runs and for pools of more than four streams).
+        #   placement="none": streams as the runtime creates them.
+        placement = placement or os.environ.get("CF_RING_PLACEMENT", "priority")
+        if os.environ.get("CF_RING_PLACE", "1") == "0":        # (round-5 switch: streams as created)
+            placement = "none"
+        if placement not in ("priority", "probe", "none"):
+            raise ValueError("placement must be 'priority', 'probe' or 'none'")
+        if placement == "priority":
+            engine_kwargs.setdefault("high_priority_streams", True)
+        self.placement = placement
         self.engines = [Engine(height, width, **engine_kwargs) for _ in range(int(depth))]
-        # HIP folds a process's streams onto four hardware queues; which queue a new stream gets depends on every stream the
-        # process created before.  When the MAIN streams of two contexts land on one queue their forwards run strictly one
-        # after the other (42.0k img/s instead of 45.8k at 64 x 640x640, 4 of 5 start-up arrangements tried): test the pairs
-        # and re-create the streams of the later context until no two main streams share a queue (profiles/r02_ablation.md).
-        # Round 5: the decode streams count too (a decode stream on the other context's main queue takes the overlap away just the same), and
-        # a ring created after other contexts of the process (bench.py's tolerance-mode ring) could not be fixed by re-rolling: it ran at its
-        # one-context rate.  If any two of the ring's streams share a queue, cf_spread_streams places them all afresh (candidates probed one by
-        # one, misplaced ones kept as ballast).  A ring whose streams are fine as created is left alone: the placement the runtime gives the
-        # first contexts of a process is also the fastest one measured (54.1 k against 51.9 k img/s after a spread, no queue shared in either).
         self.queue_rerolls = 0
-        which = (0, 1) if engine_kwargs["decode_stream"] else (0,)
-        streams = [(e, w) for e in self.engines for w in which]
-        # (+ 16: the dispatch-pipe probe; two DECODE streams on one pipe are harmless and sometimes all the process's queues allow)
-        clash = os.environ.get("CF_RING_PLACE", "1") != "0" and any(      # (CF_RING_PLACE=0: streams as created, for A/B runs)
-            a[0].queue_shared(a[1] + 16, b[0], b[1]) for k, a in enumerate(streams) for b in streams[:k] if not (a[1] == 1 and b[1] == 1))
-        if clash:
-            hs = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
-            nd = C.c_int(0)
-            self.engines[0]._chk(self.engines[0]._L.cf_spread_streams(hs, len(self.engines), 0, C.byref(nd)))
-            self.queue_rerolls = 1
+        if placement == "probe":
+            which = (0, 1) if engine_kwargs["decode_stream"] else (0,)
+            streams = [(e, w) for e in self.engines for w in which]
+            # (+ 16: the dispatch-pipe probe; two DECODE streams on one pipe are harmless and sometimes all the process's queues allow)
+            clash = any(a[0].queue_shared(a[1] + 16, b[0], b[1]) for k, a in enumerate(streams) for b in streams[:k] if not (a[1] == 1 and b[1] == 1))
+            if clash:
+                hs = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+                nd = C.c_int(0)
+                self.engines[0]._chk(self.engines[0]._L.cf_spread_streams(hs, len(self.engines), 0, C.byref(nd)))
+                self.queue_rerolls = 1
         self.depth = int(depth)
         self._n = 0
         self._out = [None] * self.depth               # per slot: (K, dets_ptr, lms_ptr, inds_ptr, B)
@@ -613,13 +623,17 @@ class CenterFace(object):
         def enqueue(e, chunk):
             chunk = [np.asarray(im, dtype=np.uint8) for im in chunk]
             e.set_rescale(self.scale_h, self.scale_w)
-            if all(is_pinned(im) for im in chunk):
-                return e.forward_images_enqueue(chunk)
-            batch = np.stack(chunk)
-            if batch.shape[1:3] == (self.img_h_new, self.img_w_new):
-                e.forward_enqueue(batch)
-            else:
-                e.forward_resized_enqueue(batch)
+            try:
+                if all(is_pinned(im) for im in chunk):
+                    return e.forward_images_enqueue(chunk)
+                batch = np.stack(chunk)
+                if batch.shape[1:3] == (self.img_h_new, self.img_w_new):
+                    e.forward_enqueue(batch)
+                else:
+                    e.forward_resized_enqueue(batch)
+            except BaseException:
+                e.set_rescale(0.0, 0.0)                  # the rescale is per-context state: a failed enqueue must not leave it behind
+                raise
 
         def finish(e):
             try:
@@ -1014,6 +1028,11 @@ class CenterFaceBuckets(object):
                 e2, hw2, idx2 = order[up_next]
                 if not direct[up_next] or id(e2) in uploaded:
                     return
+                # calls on ONE context are serialised by the caller (include/centerface_hip.h): the collector thread may still be inside
+                # this context's decode of its previous chunk -- no upload ahead into it until that chunk has been collected
+                busy = last.get(id(e2))
+                if busy is not None and not busy.done():
+                    return
                 e2._upload_addrs([addrs[i] for i in idx2], hw2[0], hw2[1], [imgs[i] for i in idx2])
                 uploaded[id(e2)] = up_next
                 up_next += 1
@@ -1053,6 +1072,12 @@ class CenterFaceBuckets(object):
                 f.result()
             except Exception as exc:                               # noqa: BLE001
                 err = err or exc
+        if main_exc is not None or err is not None:
+            for eng, _ in work:                                    # the rescale is per-context state: never left behind by a failed chunk
+                try:
+                    eng.set_rescale(0.0, 0.0)
+                except Exception:                                  # noqa: BLE001
+                    pass
         if main_exc is not None:
             if err is not None and err is not main_exc:
                 raise main_exc from err

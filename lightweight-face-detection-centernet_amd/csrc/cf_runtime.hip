@@ -112,6 +112,7 @@ struct cf_ctx {
     uint8_t* h_thr = nullptr; bool t_host = false; hipEvent_t ev_thr = nullptr;
     // cf_decode_threshold_enqueue: the decode kernels of the last forward are already in the stream with these parameters
     bool thr_pending = false; int thr_mode = 0, thr_h = 0, thr_w = 0, thr_maxout = 0, thr_B = 0; float thr_score = 0.f, thr_nms = 0.f, thr_rs_h = 0.f, thr_rs_w = 0.f;
+    int prio = 0;                      // stream priority class of the context's main / decode streams: -1 lowest, 0 normal, +1 highest
     float rs_h = 0.f, rs_w = 0.f;      // cf_set_rescale: the threshold decode floor-divides x by rs_w and y by rs_h (0 = off)
     // hipGraph replay of the backbone + neck launches, one executable graph per (input pointer,
     // input format, batch): the second forward with a key captures it, later ones replay it
@@ -471,10 +472,17 @@ CopyStream g_copy[64];
 static hipError_t make_copy_stream(hipStream_t* out) {
     int lo = 0, hi = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-    static const bool prio = cf_ab_int("CF_COPY_PRIO", 1) != 0;
+    static const bool prio = cf_ab_int("CF_COPY_PRIO", 1) != 0;       // (round 6, with the ring in the highest class too: lowest-class copy streams 50.1 k against 52.4 k)
     if (e == hipSuccess) e = hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio ? hi : lo);
     if (e != hipSuccess) *out = nullptr;
     return e;
+}
+hipError_t make_ctx_stream(cf_ctx* c, hipStream_t* out) {
+    if (c->prio == 0) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    int least = 0, greatest = 0;                       // (numerically the greatest priority is the smaller number)
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, c->prio > 0 ? greatest : least);
 }
 hipError_t acquire_copy_stream(int device, hipStream_t* out) {
     std::lock_guard<std::mutex> lk(g_copy_mu);
@@ -548,7 +556,8 @@ int cf_create(int device, int max_batch, int H, int W, int dtype, uint32_t flags
         cf_destroy(c);
         return code;
     };
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
+    c->prio = (flags & CF_FLAG_STREAM_HIGH) ? 1 : 0;
+    if ((e = make_ctx_stream(c, &c->stream)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fwd, hipEventDisableTiming)) != hipSuccess) return bail(CF_EHIP, "hipEventCreate", e);
     if ((e = acquire_copy_stream(c->device, &c->stream_in)) != hipSuccess) return bail(CF_EHIP, "hipStreamCreate", e);
     for (int i = 0; i < 2; ++i) {
@@ -813,7 +822,7 @@ hipError_t launch_plan_at(cf_ctx* c, size_t i, const void* net_in, int in_format
 int ensure_decode_stream(cf_ctx* c) {
     if (c->stream2) return CF_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(c, make_ctx_stream(c, &c->stream2));
     return CF_OK;
 }
 
@@ -1843,8 +1852,8 @@ int cf_reroll_streams(cf_ctx* c) {
     if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     HIPCHK(c, hipStreamSynchronize(c->stream_in));
     hipStream_t s1 = nullptr, s2 = nullptr;
-    HIPCHK(c, hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));     // new ones first: the old ones still hold their queues
-    if (c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    HIPCHK(c, make_ctx_stream(c, &s1));     // new ones first: the old ones still hold their queues
+    if (c->stream2) HIPCHK(c, make_ctx_stream(c, &s2));
     hipStreamDestroy(c->stream);
     if (c->stream2) hipStreamDestroy(c->stream2);
     c->stream = s1; c->stream2 = s2;

@@ -400,6 +400,38 @@ def test_engine_ring_matches_single_engine_bitwise():
 
 
 @pytest.mark.isolated
+@pytest.mark.parametrize("dummies", [0, 1, 2, 3])
+def test_engine_ring_priority_placement_needs_no_probe_and_no_luck(dummies):
+    """Round 6: EngineRing's default placement creates the ring's streams in the highest stream-priority class
+    (CF_FLAG_STREAM_HIGH), which nothing else in the process uses -- the two main streams get hardware queues (and dispatch pipes) of their
+    own whatever the process created before (0 ... 3 default-priority dummy streams first: exactly the histories that put both main streams
+    of round 2-5's rings on one queue), without a single probe kernel at creation (queue_rerolls == 0, placement == 'priority').  The
+    probes below are the test's own."""
+    import torch
+    keep = []
+    for _ in range(dummies):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            torch.zeros(1, device="cuda").add_(1)
+        keep.append(st)
+    torch.cuda.synchronize()
+    ring = cfa.EngineRing(160, 160, depth=2, max_batch=4, dtype="bf16")
+    assert ring.placement == "priority" and ring.queue_rerolls == 0
+    a, b = ring.engines
+    assert not a.queue_shared(0, b, 0)                  # main streams: different hardware queues ...
+    assert not a.queue_shared(16, b, 0)                 # ... and different dispatch pipes
+    x = np.random.default_rng(dummies).integers(0, 256, (4, 160, 160, 3), dtype=np.uint8)
+    t0, t1 = ring.submit(x, K=20), ring.submit(x, K=20)
+    r0, r1 = ring.collect(t0), ring.collect(t1)
+    for u, v in zip(r0, r1):
+        assert np.array_equal(u, v)
+    ring.close()
+    probe = cfa.EngineRing(160, 160, depth=2, max_batch=4, dtype="bf16", placement="probe")      # round 5's mechanism stays available
+    assert probe.placement == "probe" and not probe.engines[0].queue_shared(16, probe.engines[1], 0)
+    probe.close()
+
+
+@pytest.mark.isolated
 def test_spread_streams_places_contexts_and_keeps_results():
     """cf_spread_streams / cf_streams_share_queue_ex: three contexts' main streams (and one context's decode stream) are re-placed -- all pairwise
     (window 0) and neighbours only (window 2); captured graphs and results stay valid, the probe answers for every selector, bad arguments are
