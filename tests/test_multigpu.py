@@ -352,6 +352,42 @@ def test_gather_dry_run_n_ranks_equals_unsharded_order_bitwise(world):
     eng.close(); full.close()
 
 
+@pytest.mark.isolated
+@pytest.mark.parametrize("cfg", ["configs2", "configs4"])
+def test_baseline_multi_gpu_configs_dry_run_on_one_gpu(cfg):
+    """BASELINE configs[2] (B = 512 over 8 GPUs: 64 x 640x640 per rank, top-100) and configs[4] (1280x1280 dense crowd, top-1000, 8 GPUs: 4 per
+    rank) at their REAL per-rank shapes and slot sizes, every leg but the RCCL transport: one GPU plays the eight ranks through the loopback
+    communicator (two contexts per rank as bench.py drives them for configs[2], three without decode streams for configs[4]); the gathered
+    [8 x B, K, 16] records of a step equal the rank-major concatenation of each shard's own decode bit for bit."""
+    import torch
+    world = 8
+    S, B, K, depth = (640, 64, 100, 2) if cfg == "configs2" else (1280, 4, 1000, 3)
+    ring = cfa.EngineRing(S, S, depth=depth, max_batch=B, dtype="bf16")
+    comm = cfa.distributed.Comm.loopback(ring.engines[0], world)
+    comm.set_shard(B, K)
+    assert comm.wait(30.0)
+    rng = np.random.default_rng(42)
+    shards = [rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8) for _ in range(2)]          # two distinct shards, dealt to the ranks in turn
+    want = []
+    for r in range(world):
+        ring.engines[0].forward_enqueue(shards[r % 2])
+        want.append(_records(ring.engines[0], K))
+    want = np.concatenate(want)
+    dev = torch.zeros((world * B, K, 16), dtype=torch.float32, device="cuda:0")
+    for step in range(2):
+        for r in range(world):
+            eng = ring.engines[(step * world + r) % depth]                                  # the rank's contexts alternate, one communicator
+            eng.forward_enqueue(shards[r % 2])
+            comm.play(r)
+            comm.gather_topk_device(K, dev.data_ptr(), engine=eng)
+        assert comm.wait(60.0)
+        got = dev.cpu().numpy()
+        assert got.shape == (world * B, K, 16) and np.array_equal(got, want), (cfg, step)
+        dev.zero_()
+    comm.abort()
+    ring.close()
+
+
 def test_engine_ring_matches_single_engine_bitwise():
     """EngineRing: batches submitted back to back on alternating contexts, collected out of order, different batch sizes
     and K -- every result equals the single-engine result of the same batch."""
