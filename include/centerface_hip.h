@@ -64,11 +64,12 @@ extern "C" {
                                       * (configs[4] shard, B = 4: 3 contexts 9.5 k img/s with decode streams, 12.2 k without; 2 contexts 11.3 k) */
 #define CF_FLAG_STREAM_HIGH 64u       /* the context's main and decode streams are created in the HIGHEST stream-priority class.  The HIP runtime
                                       * keeps one pool of (four) hardware queues per priority class and gives a new stream the least-used queue of its
-                                      * class: the first four streams of a class that nothing else in the process uses always get queues of their own.
-                                      * For a host that keeps two or three batches in flight (cfa.EngineRing): the placement of its streams no longer
-                                      * depends on what the process created before, and needs no probing (round 6: 54.3-54.5 k img/s from five
-                                      * different process histories, against 48.2-54.4 k for default-priority streams as created and 54.5 k for the
-                                      * probed placement of cf_spread_streams; tools/queue_order_probe.py, profiles/r06_stream_priority.md) */
+                                      * class, so streams in a class of their own are placed independently of everything the process created in the
+                                      * default class: 54.3-54.5 k img/s for two contexts from five different process histories, against 48.2-54.4 k
+                                      * for default-class streams as created (round 6, tools/queue_order_probe.py).  The class is shared with the
+                                      * device's copy stream and with this library's earlier contexts: after contexts have been destroyed in it the
+                                      * map is no longer the same (45.7-47.8 k, tools/ring_sequence_probe.py) -- for a host that creates its contexts
+                                      * once; cf_streams_share_queue_ex / cf_spread_streams verify and repair a placement in any history. */
 
 typedef struct cf_ctx cf_ctx;
 

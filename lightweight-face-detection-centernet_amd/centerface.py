@@ -415,13 +415,19 @@ class EngineRing(object):
         # PER PRIORITY CLASS and gives a new stream the least-used queue of its class; two main streams on one queue (or on two queues of one
         # dispatch pipe) run their forwards strictly one after the other (48.2 k img/s instead of 54.4 k at 64 x 640x640, and which of the two a
         # ring got depended on every stream the process had created before).
-        #   placement="priority" (default since round 6): the ring's streams are created in the HIGHEST priority class (CF_FLAG_STREAM_HIGH),
-        #     which nothing else uses -- up to four streams always get queues of their own, whatever the process did before: 54.3-54.5 k
-        #     from five different histories (tools/queue_order_probe.py), no probe kernels, nothing undocumented relied upon.
-        #   placement="probe": round 5's mechanism -- default-priority streams, pairs tested with spin kernels (cf_streams_share_queue_ex),
-        #     cf_spread_streams re-places them all when two clash (54.5 k; kept for A/B runs and for pools of more than four streams).
+        #   placement="probe" (default): default-priority streams, every pair tested with spin kernels (cf_streams_share_queue_ex, + 16 = the
+        #     dispatch-pipe form), cf_spread_streams re-places them all when two clash: 51.0-54.5 k in EVERY process history measured
+        #     (tools/queue_order_probe.py, tools/ring_sequence_probe.py), ~15-30 ms at creation.
+        #   placement="priority" (round 6): the ring's streams are created in the HIGHEST priority class (CF_FLAG_STREAM_HIGH) and nothing is
+        #     probed.  A class of its own is proof against everything the process did in the DEFAULT class -- 54.3-54.5 k with an identical queue
+        #     map after 0 / 1 / 2 / 3 / 5 dummy streams or live plain contexts, where default-class streams as created give 48.2-54.4 k -- but not
+        #     against this library's own earlier use of the highest class: the device's copy stream lives there, five streams share four queues,
+        #     and which two share depends on what was created AND DESTROYED before (a ring created after two plain contexts were closed: 47.5 k;
+        #     after two single-context rings: 45.7-47.8 k; with the copy stream in the lowest class instead: 51.7 k always, 4 % under the best).
+        #     For a server that creates its ring first and keeps it: the same rate as "probe" with no probe kernel ever launched.
         #   placement="none": streams as the runtime creates them.
-        placement = placement or os.environ.get("CF_RING_PLACEMENT", "priority")
+        if placement is None:
+            placement = os.environ.get("CF_RING_PLACEMENT") or "probe"
         if os.environ.get("CF_RING_PLACE", "1") == "0":        # (round-5 switch: streams as created)
             placement = "none"
         if placement not in ("priority", "probe", "none"):

@@ -438,11 +438,12 @@ def test_engine_ring_matches_single_engine_bitwise():
 @pytest.mark.isolated
 @pytest.mark.parametrize("dummies", [0, 1, 2, 3])
 def test_engine_ring_priority_placement_needs_no_probe_and_no_luck(dummies):
-    """Round 6: EngineRing's default placement creates the ring's streams in the highest stream-priority class
-    (CF_FLAG_STREAM_HIGH), which nothing else in the process uses -- the two main streams get hardware queues (and dispatch pipes) of their
-    own whatever the process created before (0 ... 3 default-priority dummy streams first: exactly the histories that put both main streams
-    of round 2-5's rings on one queue), without a single probe kernel at creation (queue_rerolls == 0, placement == 'priority').  The
-    probes below are the test's own."""
+    """Round 6: EngineRing(placement="priority") creates the ring's streams in the highest stream-priority class
+    (CF_FLAG_STREAM_HIGH) -- in a process that has not used that class before (this test runs in a child interpreter of its own) the two main
+    streams get hardware queues and dispatch pipes of their own whatever the process created in the DEFAULT class (0 ... 3 dummy streams
+    first: exactly the histories that put both main streams of round 2-5's rings on one queue), without a single probe kernel at creation.
+    The probes below are the test's own.  The default stays placement="probe": the priority class is not proof against the library's own earlier
+    contexts in it (tools/ring_sequence_probe.py), probing is."""
     import torch
     keep = []
     for _ in range(dummies):
@@ -451,7 +452,7 @@ def test_engine_ring_priority_placement_needs_no_probe_and_no_luck(dummies):
             torch.zeros(1, device="cuda").add_(1)
         keep.append(st)
     torch.cuda.synchronize()
-    ring = cfa.EngineRing(160, 160, depth=2, max_batch=4, dtype="bf16")
+    ring = cfa.EngineRing(160, 160, depth=2, max_batch=4, dtype="bf16", placement="priority")
     assert ring.placement == "priority" and ring.queue_rerolls == 0
     a, b = ring.engines
     assert not a.queue_shared(0, b, 0)                  # main streams: different hardware queues ...
@@ -462,8 +463,11 @@ def test_engine_ring_priority_placement_needs_no_probe_and_no_luck(dummies):
     for u, v in zip(r0, r1):
         assert np.array_equal(u, v)
     ring.close()
-    probe = cfa.EngineRing(160, 160, depth=2, max_batch=4, dtype="bf16", placement="probe")      # round 5's mechanism stays available
+    probe = cfa.EngineRing(160, 160, depth=2, max_batch=4, dtype="bf16")      # the default: probed, repaired when needed
     assert probe.placement == "probe" and not probe.engines[0].queue_shared(16, probe.engines[1], 0)
+    t0 = probe.submit(x, K=20)
+    for u, v in zip(probe.collect(t0), r0):
+        assert np.array_equal(u, v)
     probe.close()
 
 

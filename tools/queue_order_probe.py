@@ -17,6 +17,16 @@ for _ in range(k):
     dummies.append(st)
 torch.cuda.synchronize()
 rng = np.random.default_rng(0)
+# PLAIN=k: k plain contexts (default-class streams; the first one brings the device's copy stream into being) created and used before the ring;
+# PLAIN_CLOSE=1 closes them again first
+plain = []
+for _ in range(int(os.environ.get("PLAIN", "0"))):
+    e = cfa.Engine(160, 160, max_batch=2, dtype="bf16")
+    e.forward_enqueue(rng.integers(0, 256, (2, 160, 160, 3), dtype=np.uint8)); e.decode_topk(10)
+    plain.append(e)
+if os.environ.get("PLAIN_CLOSE") == "1":
+    for e in plain:
+        e.close()
 ring = cfa.EngineRing(S, S, depth=2, max_batch=B, dtype=os.environ.get("DTYPE", "bf16"))
 e0 = ring.engines[0]
 xs = []
@@ -38,4 +48,4 @@ for _ in range(9):
 names = [(i, w) for i in range(2) for w in (0, 1)]
 lab = lambda i, w: ("main%d" % i, "dec%d" % i)[w]
 fat = {lab(i, w): [lab(j, v) for (j, v) in names if (j, v) != (i, w) and ring.engines[j].queue_shared(v, ring.engines[i], w + 16)] for (i, w) in names}
-print(json.dumps({"dummy_streams": k, "blocked_by_fat_kernel_on": fat, "prio": prio, "spread_called": ring.queue_rerolls, "images_per_s": round(float(np.median(rates)), 1)}))
+print(json.dumps({"plain_contexts": len(plain), "closed": os.environ.get("PLAIN_CLOSE") == "1", "placement": ring.placement, "dummy_streams": k, "blocked_by_fat_kernel_on": fat, "prio": prio, "spread_called": ring.queue_rerolls, "images_per_s": round(float(np.median(rates)), 1)}))
