@@ -98,6 +98,31 @@ int main(int argc, char** argv) {
         }
         free(rec);
     }
+    /* Dry run of an N-rank gather on ONE GPU (`./detect weights.bin H W batch dryrun N`): no RCCL -- a loopback communicator lets this
+     * process play the N ranks in turn.  The batch is dealt to the ranks image by image (shards of one image: B ranks at most); every
+     * rank decodes its shard, writes its slot header and deposits the slot; the call of the last rank runs the header check and the
+     * rank-major unpack of the real gather.  The gathered records must equal the unsharded decode above, image for image: what a
+     * deployment checks about its shard math before the multi-GPU node exists. */
+    if (argc > 6 && strcmp(argv[5], "dryrun") == 0) {
+        const int world = atoi(argv[6]);
+        if (world < 1 || world > B) { fprintf(stderr, "dryrun: world must be in [1, batch]\n"); return 2; }
+        cf_comm* comm = NULL;
+        float* rec = (float*)malloc((size_t)world * K * 16 * sizeof(float));
+        CHECK(ctx, cf_comm_create_loopback(ctx, world, &comm));
+        CHECK(ctx, cf_comm_set_shard(comm, 1, K));
+        for (int r = 0; r < world; ++r) {
+            CHECK(ctx, cf_forward(ctx, img + (size_t)r * H * W * 3, CF_IN_U8_HWC_BGR, 0, 1));       /* rank r's shard: image r */
+            if (cf_comm_loopback_rank(comm, r) != CF_OK) { fprintf(stderr, "cf_comm_loopback_rank failed\n"); return 1; }
+            CHECK(ctx, cf_gather_topk(ctx, comm, K, 1, rec, 0));                                    /* filled by the LAST rank's call */
+        }
+        for (int b = 0; b < world; ++b)
+            for (int k = 0; k < K; ++k)
+                for (int e = 0; e < 5; ++e)
+                    if (rec[((size_t)b * K + k) * 16 + e] != dets[((size_t)b * K + k) * 6 + e]) { fprintf(stderr, "dry run: record %d of image %d differs from the unsharded decode\n", k, b); return 1; }
+        printf("dry run: %d ranks x 1 image gathered in rank-major order = the unsharded decode\n", world);
+        CHECK(ctx, cf_comm_destroy(comm));
+        free(rec);
+    }
     CHECK(ctx, cf_destroy(ctx));
     return 0;
 }

@@ -40,6 +40,8 @@ def test_c_example_matches_python_host(tmp_path):
     out = subprocess.run([exe, wfile, str(H), str(W), str(B), "gather"], check=True, capture_output=True, text=True).stdout.strip().splitlines()
     assert out[-2].startswith("gathered %d x 10 records over RCCL" % B), out[-2]     # cf_comm_* / cf_gather_topk from plain C
     assert out[-1].startswith("grouped communicator: gathered %d x 10 records" % B), out[-1]      # cf_comm_create_all / cf_comm_abort
+    dry = subprocess.run([exe, wfile, str(H), str(W), "4", "dryrun", "4"], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert dry[-1].startswith("dry run: 4 ranks x 1 image gathered in rank-major order"), dry[-1]      # cf_comm_create_loopback from plain C: no RCCL
     out = [l for l in out if l.startswith("image ")]                                    # (librccl prints its version banner on stdout)
     assert len(out) == B
     # the same bytes as detect.c's LCG
