@@ -5,18 +5,19 @@
 // (model/blocks.py:26-29,37-39, symmetric pad k//2, no activation).
 //
 // The op is pure streaming (1.8 - 12.5 flop/B): the design goal is HBM bandwidth.
-//  * NHWC makes an image row one contiguous run of W*C elements; a thread owns VEC consecutive
-//    channels of one output column, so a wave's loads are back-to-back 16-byte pieces of that run
-//    (fully coalesced, whole 128-B lines).
-//  * A thread marches DOWN a strip of TH output rows: every input row of the strip is loaded once
-//    per thread (k horizontally shifted vectors; the shifts overlap the neighbouring lanes' loads
-//    and are served by the CU's L1/TA, not by HBM) and is folded into the <= ceil(k/s) output rows
-//    it contributes to while they are live in registers -- vertical reuse never leaves the VGPRs.
-//  * The k*k*VEC weights of the thread's channels sit in registers for the whole strip (fp32).
-//  * ZeroPad2d, Swish and the bf16 pack are fused: the op reads its unpadded input once and
-//    writes its output once.
+//  * the halo tile of one channel chunk is copied HBM -> LDS by the DMA path (global_load_lds_dwordx4), out-of-image chunks from a
+//    zero constant (= ZeroPad2d), the chunk's tap weights (fp32) next to it;
+//  * the compute phase works on strips of four output pixels per 16-byte channel group (dw_strip_kernel below: what it reads from LDS
+//    and how many VALU operations it spends per output element, against round 1's one-vector-per-item form);
+//  * ZeroPad2d, bias, Swish and the bf16 pack are fused: the op reads its unpadded input once and writes its output once.
+// Measured per layer of the 640x640 network at B = 64 (profiles/r06_dw_strip.md): 3x3 stride 2 5.57 TB/s = 70 % of the 8 TB/s spec
+// (layer1.0; round 1: 4.63), 3x3 stride 1 3.3-4.2 TB/s, 5x5 1.9-3.7 TB/s (round 1: 1.3-2.7; VALU-bound: 25 taps per output element).
+// The product path fuses this op into the MBConv kernels (the depthwise tensor never reaches HBM); it runs standalone in the
+// unfused path (CF_FLAG_NO_FUSE), in cf_op_dwconv and in the ShuffleV2 block.
+#include "cf_exp.h"
 #include "cf_common.h"
 #include "cf_kernels.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -27,283 +28,255 @@ void dw_pack_weights(const float* w, int C, int k, float* out_host) {
         for (int t = 0; t < k * k; ++t) out_host[(size_t)t * C + c] = w[(size_t)c * k * k + t];
 }
 
-template <typename T, int VEC> struct VecIO;
-template <> struct VecIO<bf16_t, 8> {
-    static __device__ __forceinline__ void load(const void* p, float* f) { unpack16<bf16_t>(ld16(p), f); }
-    static __device__ __forceinline__ void store(void* p, const float* f) { st16(p, pack16<bf16_t>(f)); }
-};
-template <> struct VecIO<bf16_t, 4> {
-    static __device__ __forceinline__ void load(const void* p, float* f) {
-        u32x2 c = *reinterpret_cast<const u32x2*>(p);
-        f[0] = bf16lo(c.x); f[1] = bf16hi(c.x); f[2] = bf16lo(c.y); f[3] = bf16hi(c.y);
-    }
-    static __device__ __forceinline__ void store(void* p, const float* f) {
-        u32x2 c; c.x = pack_bf16x2(f[0], f[1]); c.y = pack_bf16x2(f[2], f[3]);
-        *reinterpret_cast<u32x2*>(p) = c;
-    }
-};
-template <> struct VecIO<float, 4> {
-    static __device__ __forceinline__ void load(const void* p, float* f) { unpack16<float>(ld16(p), f); }
-    static __device__ __forceinline__ void store(void* p, const float* f) { st16(p, pack16<float>(f)); }
-};
-
-template <typename T, int KS, int S, int VEC, int TH, int ACT, bool BIAS>
-__global__ __launch_bounds__(256) void dw_kernel(DwParams p) {
-    const int CG = p.C / VEC;
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= p.Wo * CG) return;
-    const int xo = f / CG;
-    const int c0 = (f - xo * CG) * VEC;
-    const int y0 = blockIdx.y * TH;
-    const int b = blockIdx.z;
-
-    float wreg[KS * KS][VEC];
-#pragma unroll
-    for (int t = 0; t < KS * KS; ++t)
-#pragma unroll
-        for (int v4 = 0; v4 < VEC / 4; ++v4)           // 16-byte weight loads (c0 is a multiple of 4)
-            unpack16<float>(ld16(p.w + (size_t)t * p.C + c0 + 4 * v4), &wreg[t][4 * v4]);
-    float breg[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) breg[e] = BIAS ? p.bias[c0 + e] : 0.0f;
-
-    const int ix0 = xo * S - p.pad_lo;
-    bool xok[KS];
-#pragma unroll
-    for (int kx = 0; kx < KS; ++kx) xok[kx] = (unsigned)(ix0 + kx) < (unsigned)p.W;
-
-    const T* xin = (const T*)p.x + (size_t)b * p.H * p.W * p.C + c0;
-    T* yout = (T*)p.y + ((size_t)b * p.Ho * p.Wo + xo) * p.C + c0;
-
-    float acc[TH][VEC];
-#pragma unroll
-    for (int t = 0; t < TH; ++t)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[t][e] = 0.0f;
-
-    constexpr int ROWS = (TH - 1) * S + KS;       // input rows touched by the strip
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const int iy = y0 * S - p.pad_lo + r;
-        const bool yok = (unsigned)iy < (unsigned)p.H;
-        float v[KS][VEC];
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            if (yok && xok[kx]) {
-                VecIO<T, VEC>::load(xin + ((size_t)iy * p.W + (ix0 + kx)) * p.C, v[kx]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[kx][e] = 0.0f;
-            }
-        }
-#pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {
-            // output row t of the strip uses input row r when t*S + ky == r
-            if ((r - ky) >= 0 && (r - ky) % S == 0 && (r - ky) / S < TH) {
-                const int t = (r - ky) / S;
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        acc[t][e] = fmaf(v[kx][e], wreg[ky * KS + kx][e], acc[t][e]);
-            }
-        }
-        // output row t is complete after its last input row r = t*S + KS-1
-        if (r >= KS - 1 && (r - (KS - 1)) % S == 0) {
-            const int t = (r - (KS - 1)) / S;
-            const int yo = y0 + t;
-            if (yo < p.Ho) {
-                float o[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) o[e] = acc[t][e] + breg[e];
-                act_arr<ACT, VEC>(o);
-                VecIO<T, VEC>::store(yout + (size_t)yo * p.Wo * p.C, o);
-            }
-        }
-    }
-}
-
-template <typename T, int KS, int S, int VEC, int TH>
-static hipError_t dw_dispatch(hipStream_t s, const DwParams& p) {
-    dim3 blk(256);
-    dim3 grid((unsigned)((p.Wo * (p.C / VEC) + 255) / 256), (unsigned)((p.Ho + TH - 1) / TH), (unsigned)p.B);
-    const bool bias = p.bias != nullptr;
-    set_kernel_tag("void cf::dw_kernel<%s, %d, %d, %d, %d, %d, %s>(cf::DwParams)", type_tag<T>(), KS, S, VEC, TH, p.act, bias ? "true" : "false");
-    if (p.act == 1 && !bias) hipLaunchKernelGGL((dw_kernel<T, KS, S, VEC, TH, 1, false>), grid, blk, 0, s, p);
-    else if (p.act == 0 && bias) hipLaunchKernelGGL((dw_kernel<T, KS, S, VEC, TH, 0, true>), grid, blk, 0, s, p);
-    else if (p.act == 0 && !bias) hipLaunchKernelGGL((dw_kernel<T, KS, S, VEC, TH, 0, false>), grid, blk, 0, s, p);
-    else hipLaunchKernelGGL((dw_kernel<T, KS, S, VEC, TH, 1, true>), grid, blk, 0, s, p);
-    return hipGetLastError();
-}
+#include CF_EXP_INC(cf_dw_0)   // round 1's register-marching kernel (CF_DW_MARCH=1)
 
 // ================================================================== LDS-staged variant
 // The input tile (halo included) of one channel chunk is copied HBM -> LDS by the DMA path
 // (global_load_lds_dwordx4: no VGPR round trip, a wave keeps 1 KiB per instruction in flight with
 // almost no registers), out-of-image chunks are sourced from a 16-byte zero constant (= ZeroPad2d),
-// then every thread computes output vectors from LDS: k*k ds_read_b128 of the tile + the tap weights
-// (fp32, staged once per workgroup).  Consecutive lanes own consecutive 16-byte channel groups of a
+// then the workgroup computes from LDS.  Consecutive lanes own consecutive 16-byte channel groups of a
 // pixel, so LDS reads are conflict-free and global stores are whole pixels' worth of contiguous bytes.
 __device__ __attribute__((aligned(16))) const uint32_t g_dw_zero16[4] = {0u, 0u, 0u, 0u};
 
 struct DwLdsGeom { int Cc, nchunk, cpp, rc, nch, magic_rc, magic_cpp, nt; size_t lds_bytes; };
+static int magic_div(int d) { return (int)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }   // exact for n < 2^16, d >= 2 (d = 1 does not fit 32 bits: the kernels test for it)
 
-template <typename T, int KS, int S, int TH, int TW, int ACT, bool BIAS>
-__global__ __launch_bounds__(256) void dw_lds_kernel(DwParams p, DwLdsGeom g) {
-    constexpr int P = Elem<T>::PER16;
-    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+#include CF_EXP_INC(cf_dw_1)   // round 1's one-output-vector-per-item compute phase (CF_DW_STRIP=0)
+
+// ================================================================== LDS-staged, strip form (round 6)
+// Same staging as dw_lds_kernel (the halo tile of one channel chunk by LDS DMA, tap weights as fp32 next to it); the compute phase is
+// restructured around what bound the first form -- LDS traffic and unpack instructions, not HBM: there every output vector (8 channels
+// of one pixel) read k*k tile chunks AND k*k x 32 bytes of weights from LDS (54 B per output element at 3x3, 150 B at 5x5, against
+// ~128 B per cycle and CU) and unpacked every tile chunk once per tap.  Here a work item is a STRIP of SX = 4 output pixels of one row
+// for one 16-byte channel group: per kernel row it reads the (SX - 1) S + k tile chunks behind the strip once, unpacks them once, and
+// reads that row's k weight vectors once for all four outputs -- 18 B (3x3) / 45 B (5x5) of LDS traffic per output element, 13.5 / 35
+// VALU operations instead of 18 / 50, as v_pk_fma_f32 on channel pairs.  The taps of an output accumulate in the same order as before
+// (ky outer, kx inner, first tap a plain multiply): results are bit-identical to dw_lds_kernel.  Items are laid out channel group
+// fastest, so consecutive lanes read consecutive 16-byte chunks (conflict-free) and store whole pixels' worth of contiguous bytes.
+template <typename T, int KS, int S, int TH, int TW>
+__global__ __launch_bounds__(256) void dw_strip_kernel(DwParams p, DwLdsGeom g, int ntx, int nty, int ntiles) {
+    constexpr int P = Elem<T>::PER16, H2 = P / 2, SX = 4;
+    constexpr int IW = (TW - 1) * S + KS;
+    constexpr int WIN = (SX - 1) * S + KS, NSTRIP = TW / SX;
+    static_assert(TW % SX == 0, "strips of four output pixels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* tile = smem;                                            // [IH][IW][Cc] T, linear 16-byte chunks
-    float* wl = reinterpret_cast<float*>(smem + (((size_t)g.nch * 16 + 1023) / 1024) * 1024);   // [k*k][Cc]
+    // two buffers of [tile | tap weights]: the DMA of tile t + 1 runs underneath the arithmetic of tile t (persistent workgroups)
+    const size_t tile_bytes = (((size_t)g.nch * 16 + 1023) / 1024) * 1024;
+    const size_t buf_bytes = tile_bytes + (((size_t)KS * KS * g.Cc * 4 + 1023) / 1024) * 1024;       // (the weights arrive in whole 1 KiB DMA groups too)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int b = blockIdx.z / g.nchunk, c0 = (blockIdx.z - b * g.nchunk) * g.Cc;
-    const int iy0 = y0 * S - p.pad_lo, ix0 = x0 * S - p.pad_lo;
-    const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.C + c0) * sizeof(T);
-
-    // ---- DMA the tile: chunk q -> (row, pixel, part); LDS address = q * 16 (lane-linear per wave)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
     const int ngroups = (g.nch + 63) >> 6;
-    for (int grp = wave; grp < ngroups; grp += 4) {
-        const int q = grp * 64 + lane;
-        const int row = __umulhi((unsigned)q, (unsigned)g.magic_rc);
-        const int rem = q - row * g.rc;
-        const int px = __umulhi((unsigned)rem, (unsigned)g.magic_cpp);
-        const int part = rem - px * g.cpp;
-        const int gy = iy0 + row, gx = ix0 + px;
-        const bool ok = q < g.nch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        const char* src = ok ? xb + ((size_t)gy * p.W + gx) * p.C * sizeof(T) + part * 16
-                             : reinterpret_cast<const char*>(g_dw_zero16);
-        if (g.nt & 1)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tile + grp * 1024), 16, 0, 2);
-        else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tile + grp * 1024), 16, 0, 0);
-    }
-    for (int i = tid; i < KS * KS * (g.Cc / 4); i += 256) {       // tap weights of this channel chunk
-        const int t = i / (g.Cc / 4), c4 = i - t * (g.Cc / 4);
-        st16(wl + t * g.Cc + c4 * 4, ld16(p.w + (size_t)t * p.C + c0 + c4 * 4));
-    }
-    cf_sync_lds_dma();                                            // every wave drains its DMAs (vmcnt), then the barrier
 
-    // ---- compute: output vector v -> (pixel, channel group)
-    const int nvec = TH * TW * g.cpp;
-    for (int v = tid; v < nvec; v += 256) {
-        const int opx = __umulhi((unsigned)v, (unsigned)g.magic_cpp);
-        const int cg = v - opx * g.cpp;
-        const int oy = opx / TW, ox = opx % TW;
-        const int gy = y0 + oy, gx = x0 + ox;
-        if (gy >= p.Ho || gx >= p.Wo) continue;
-        const char* tb = tile + ((size_t)((oy * S) * IW + ox * S) * g.cpp + cg) * 16;
-        const float* wb = wl + cg * P;
-        float d[P];
+    // tile t -> (image, channel chunk, tile row, tile column); x fastest, so the tiles in flight at any moment are neighbours (shared halo lines in L2)
+    auto decode = [&](int t, int& b, int& c0, int& y0, int& x0) {
+        const int tx = t % ntx; t /= ntx;
+        const int ty = t % nty; t /= nty;
+        const int ck = t % g.nchunk; b = t / g.nchunk;
+        c0 = ck * g.Cc; y0 = ty * TH; x0 = tx * TW;
+    };
+    auto stage = [&](int t, char* buf) {
+        int b, c0, y0, x0; decode(t, b, c0, y0, x0);
+        const int iy0 = y0 * S - p.pad_lo, ix0 = x0 * S - p.pad_lo;
+        const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.C + c0) * sizeof(T);
+        for (int grp = wave; grp < ngroups; grp += nwave) {
+            const int q = grp * 64 + lane;
+            const int row = __umulhi((unsigned)q, (unsigned)g.magic_rc);
+            const int rem = q - row * g.rc;
+            const int px = (g.cpp == 1 ? rem : (int)__umulhi((unsigned)rem, (unsigned)g.magic_cpp));
+            const int part = rem - px * g.cpp;
+            const int gy = iy0 + row, gx = ix0 + px;
+            const bool ok = q < g.nch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const char* src = ok ? xb + ((size_t)gy * p.W + gx) * p.C * sizeof(T) + part * 16
+                                 : reinterpret_cast<const char*>(g_dw_zero16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(buf + grp * 1024), 16, 0, 0);
+        }
+        // tap weights of the tile's channel chunk: whole 1 KiB groups by DMA as well ([k*k][Cc] fp32 = k*k*Cc/4 chunks of 16 bytes)
+        char* wdst = buf + tile_bytes;
+        const int nwch = KS * KS * (g.Cc / 4), nwg = (nwch + 63) >> 6;
+        for (int grp = wave; grp < nwg; grp += nwave) {
+            const int i = grp * 64 + lane;
+            const int ic = i < nwch ? i : nwch - 1;
+            const int t2 = ic / (g.Cc / 4), c4 = ic - t2 * (g.Cc / 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.w + (size_t)t2 * p.C + c0 + c4 * 4),
+                                             (__attribute__((address_space(3))) void*)(wdst + grp * 1024), 16, 0, 0);
+        }
+    };
+    auto unpack2 = [](const u32x4& c, f32x2* f) {                 // one 16-byte chunk -> H2 channel pairs
+        if constexpr (P == 8) {
+            f[0].x = bf16lo(c.x); f[0].y = bf16hi(c.x); f[1].x = bf16lo(c.y); f[1].y = bf16hi(c.y);
+            f[2].x = bf16lo(c.z); f[2].y = bf16hi(c.z); f[3].x = bf16lo(c.w); f[3].y = bf16hi(c.w);
+        } else {
+            f[0].x = __uint_as_float(c.x); f[0].y = __uint_as_float(c.y); f[1].x = __uint_as_float(c.z); f[1].y = __uint_as_float(c.w);
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t < ntiles) stage(t, smem);
+    for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+        char* tile = smem + (size_t)(it & 1) * buf_bytes;
+        const float* wl = reinterpret_cast<const float*>(tile + tile_bytes);
+        cf_sync_lds_dma();          // tile t has landed for every wave, and every wave is done with tile t - 1 (the other buffer)
+        if (t + (int)gridDim.x < ntiles) stage(t + gridDim.x, smem + (size_t)((it + 1) & 1) * buf_bytes);
+        int b, c0, y0, x0; decode(t, b, c0, y0, x0);
+        const int nitem = TH * NSTRIP * g.cpp;
+        for (int v = tid; v < nitem; v += nthr) {
+            const int sidx = (g.cpp == 1 ? v : (int)__umulhi((unsigned)v, (unsigned)g.magic_cpp));
+            const int cg = v - sidx * g.cpp;
+            const int oy = sidx / NSTRIP, xs = sidx - oy * NSTRIP;
+            const int gy = y0 + oy, gx0 = x0 + xs * SX;
+            if (gy >= p.Ho || gx0 >= p.Wo) continue;
+            const char* tb = tile + ((size_t)((oy * S) * IW + xs * SX * S) * g.cpp + cg) * 16;
+            const float* wb = wl + cg * P;
+            f32x2 acc[SX][H2];
+            // (one kernel row at a time: fully unrolled, the compiler hoists every row's window and weights -- 460 VGPRs at 5x5, one wave per SIMD)
+#pragma unroll 1
+            for (int ky = 0; ky < KS; ++ky) {
+                f32x2 xw[WIN][H2];
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
+                for (int c = 0; c < WIN; ++c) unpack2(ld16(tb + (size_t)(ky * IW + c) * g.cpp * 16), xw[c]);
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                float ev[P], wv[P];
-                unpack16<T>(ld16(tb + (size_t)(ky * IW + kx) * g.cpp * 16), ev);
-                const float* wt = wb + (ky * KS + kx) * g.Cc;
-                unpack16<float>(ld16(wt), wv);
-                if constexpr (P == 8) unpack16<float>(ld16(wt + 4), wv + 4);
-                if (ky == 0 && kx == 0) {
+                for (int kx = 0; kx < KS; ++kx) {
+                    const float* wt = wb + (ky * KS + kx) * g.Cc;
+                    f32x2 w2[H2];
+                    {
+                        const u32x4 w0 = ld16(wt);
+                        w2[0].x = __uint_as_float(w0.x); w2[0].y = __uint_as_float(w0.y); w2[1].x = __uint_as_float(w0.z); w2[1].y = __uint_as_float(w0.w);
+                        if constexpr (P == 8) {
+                            const u32x4 w1 = ld16(wt + 4);
+                            w2[2].x = __uint_as_float(w1.x); w2[2].y = __uint_as_float(w1.y); w2[3].x = __uint_as_float(w1.z); w2[3].y = __uint_as_float(w1.w);
+                        }
+                    }
 #pragma unroll
-                    for (int e = 0; e < P; ++e) d[e] = ev[e] * wv[e];
-                } else {
+                    for (int j = 0; j < SX; ++j)
 #pragma unroll
-                    for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
+                        for (int h = 0; h < H2; ++h) {
+                            if (ky == 0 && kx == 0) acc[j][h] = xw[j * S + kx][h] * w2[h];
+                            else acc[j][h] = fma2(xw[j * S + kx][h], w2[h], acc[j][h]);
+                        }
                 }
             }
-        const int ch = c0 + cg * P;
+            const int ch = c0 + cg * P;
+            float bv[P];
 #pragma unroll
-        for (int e = 0; e < P; ++e) d[e] = d[e] + (BIAS ? p.bias[ch + e] : 0.0f);
-        act_arr<ACT, P>(d);
-        u32x4* dstp = reinterpret_cast<u32x4*>((char*)p.y + ((((size_t)b * p.Ho + gy) * p.Wo + gx) * p.C + ch) * sizeof(T));
-        if (g.nt & 2) __builtin_nontemporal_store(pack16<T>(d), dstp);
-        else *dstp = pack16<T>(d);
+            for (int e = 0; e < P; ++e) bv[e] = p.bias ? p.bias[ch + e] : 0.0f;
+            char* yrow = (char*)p.y + ((((size_t)b * p.Ho + gy) * p.Wo + gx0) * p.C + ch) * sizeof(T);
+#pragma unroll
+            for (int j = 0; j < SX; ++j) {
+                if (gx0 + j >= p.Wo) break;
+                float d[P];
+#pragma unroll
+                for (int h = 0; h < H2; ++h) { d[2 * h] = acc[j][h].x + bv[2 * h]; d[2 * h + 1] = acc[j][h].y + bv[2 * h + 1]; }
+                if (p.act == 1) act_arr<1, P>(d);
+                *reinterpret_cast<u32x4*>(yrow + (size_t)j * p.C * sizeof(T)) = pack16<T>(d);
+            }
+        }
     }
 }
 
-static int magic_div(int d) { return (int)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }   // exact for n < 2^16
-
+struct DwTileCfg { int th, tw; };
 template <typename T, int KS, int S, int TH, int TW>
-static hipError_t dw_lds_dispatch(hipStream_t s, const DwParams& p) {
-    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
-    constexpr int P = 16 / (int)sizeof(T);
-    // channel chunk: largest divisor of C (multiple of one 16-byte group) whose tile fits 48 KiB (tile + tap weights stay under the 64 KiB default dynamic-LDS limit)
-    int Cc = 0;
-    for (int c = p.C; c >= P; c -= P)
-        if (p.C % c == 0 && (size_t)IH * IW * c * sizeof(T) <= 48 * 1024) { Cc = c; break; }
-    if (!Cc) return hipErrorInvalidValue;
-    DwLdsGeom g;
-    g.Cc = Cc; g.nchunk = p.C / Cc; g.cpp = Cc / P; g.rc = IW * g.cpp; g.nch = IH * g.rc;
-    if (g.nch >= 65536) return hipErrorInvalidValue;
-    g.magic_rc = magic_div(g.rc); g.magic_cpp = magic_div(g.cpp);
-    { static const int nt_env = cf_ab_int("CF_DW_NT", 0); g.nt = nt_env; }
-    g.lds_bytes = (((size_t)g.nch * 16 + 1023) / 1024) * 1024 + (size_t)KS * KS * Cc * 4;
-    dim3 grid((p.Wo + TW - 1) / TW, (p.Ho + TH - 1) / TH, p.B * g.nchunk), blk(256);
-    const bool bias = p.bias != nullptr;
-    set_kernel_tag("void cf::dw_lds_kernel<%s, %d, %d, %d, %d, %d, %s>(cf::DwParams, cf::DwLdsGeom)", type_tag<T>(), KS, S, TH, TW,
-                   p.act, bias ? "true" : "false");
-#define CF_DW_LAUNCH(ACT, BIAS) \
-    hipLaunchKernelGGL((dw_lds_kernel<T, KS, S, TH, TW, ACT, BIAS>), grid, blk, g.lds_bytes, s, p, g); return hipGetLastError();
-    if (p.act == 1 && !bias) { CF_DW_LAUNCH(1, false) }
-    if (p.act == 0 && bias) { CF_DW_LAUNCH(0, true) }
-    if (p.act == 0 && !bias) { CF_DW_LAUNCH(0, false) }
-    CF_DW_LAUNCH(1, true)
-#undef CF_DW_LAUNCH
+static hipError_t dw_strip_launch(hipStream_t s, const DwParams& p, const DwLdsGeom& g, int threads) {
+    auto kfn = dw_strip_kernel<T, KS, S, TH, TW>;
+    static thread_local bool big[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (!big[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return e;
+        big[dev & 63] = true;
+    }
+    const int ntx = (p.Wo + TW - 1) / TW, nty = (p.Ho + TH - 1) / TH;
+    const long long nt = (long long)p.B * g.nchunk * nty * ntx;
+    if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
+    // CF_DW_WGS = n > 0: n PERSISTENT workgroups per CU, each walking tiles with two LDS buffers (the DMA of the next tile under the arithmetic of
+    // this one); 0: one workgroup per tile, one buffer -- the overlap comes from the other workgroups of the CU
+    static const int per_cu = cf_ab_int("CF_DW_WGS", 0);
+    int ncu = 256; { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+    const bool persist = per_cu > 0 && nt > (long long)ncu * per_cu;
+    const int nwg = persist ? ncu * per_cu : (int)nt;
+    set_kernel_tag("void cf::dw_strip_kernel<%s, %d, %d, %d, %d>(cf::DwParams, cf::DwLdsGeom, int, int, int)", type_tag<T>(), KS, S, TH, TW);
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(threads), (persist ? 2 : 1) * g.lds_bytes, s, p, g, ntx, nty, (int)nt);
+    return hipGetLastError();
 }
 
+// geometry of one candidate tile: the largest channel chunk (a divisor of C, whole 16-byte groups) whose tile + tap weights fit `cap`
 template <typename T>
-static hipError_t dw_lds_by_shape(hipStream_t s, const DwParams& p) {
-    static const int tv = cf_ab_int("CF_DW_TILE", 0);     // A/B of tile shapes
-    if (tv == 1) {
-        if (p.k == 3 && p.s == 1) return dw_lds_dispatch<T, 3, 1, 16, 16>(s, p);
-        if (p.k == 3 && p.s == 2) return dw_lds_dispatch<T, 3, 2, 8, 16>(s, p);
-        if (p.k == 5 && p.s == 1) return dw_lds_dispatch<T, 5, 1, 16, 16>(s, p);
-        if (p.k == 5 && p.s == 2) return dw_lds_dispatch<T, 5, 2, 8, 16>(s, p);
+static bool dw_strip_geom(const DwParams& p, int TH, int TW, size_t cap, DwLdsGeom& g, int& threads, double& score) {
+    constexpr int P = 16 / (int)sizeof(T);
+    const int IH = (TH - 1) * p.s + p.k, IW = (TW - 1) * p.s + p.k;
+    int Cc = 0;
+    for (int c = p.C; c >= P; c -= P) {
+        if (p.C % c) continue;
+        const size_t bytes = (((size_t)IH * IW * (c / P) * 16 + 1023) / 1024) * 1024 + (((size_t)p.k * p.k * c * 4 + 1023) / 1024) * 1024;
+        if (bytes <= cap && (size_t)IH * IW * (c / P) < 65536) { Cc = c; break; }
     }
-    if (tv == 2) {
-        if (p.k == 3 && p.s == 1) return dw_lds_dispatch<T, 3, 1, 8, 32>(s, p);
-        if (p.k == 3 && p.s == 2) return dw_lds_dispatch<T, 3, 2, 4, 32>(s, p);
-        if (p.k == 5 && p.s == 1) return dw_lds_dispatch<T, 5, 1, 8, 32>(s, p);
-        if (p.k == 5 && p.s == 2) return dw_lds_dispatch<T, 5, 2, 4, 32>(s, p);
+    if (!Cc) return false;
+    g.Cc = Cc; g.nchunk = p.C / Cc; g.cpp = Cc / P; g.rc = IW * g.cpp; g.nch = IH * g.rc;
+    g.magic_rc = magic_div(g.rc); g.magic_cpp = magic_div(g.cpp); g.nt = 0;
+    g.lds_bytes = (((size_t)g.nch * 16 + 1023) / 1024) * 1024 + (((size_t)p.k * p.k * Cc * 4 + 1023) / 1024) * 1024;
+    const int items = TH * (TW / 4) * g.cpp;
+    threads = items >= 256 ? 256 : (items + 63) / 64 * 64;
+    const int passes = (items + threads - 1) / threads;
+    const double eff_thr = (double)items / ((double)passes * threads);
+    const int nty = (p.Ho + TH - 1) / TH, ntx = (p.Wo + TW - 1) / TW;
+    const double eff_sp = (double)p.Ho * p.Wo / ((double)nty * TH * ntx * TW);
+    const double halo = (double)(TH * p.s) * (TW * p.s) / ((double)IH * IW);
+    const double run = g.cpp >= 4 ? 1.0 : 0.6 + 0.1 * g.cpp;                  // short DMA runs (one or two chunks per pixel) waste line fetches
+    const double fill = threads >= 256 ? 1.0 : 0.85;
+    score = eff_thr * eff_sp * (0.5 + 0.5 * halo) * run * fill;
+    return true;
+}
+
+#define CF_DW_TILES(X) X(4, 16) X(4, 32) X(8, 16) X(8, 32) X(16, 16) X(16, 32) X(8, 40) X(10, 20) X(20, 20)
+// Tile and LDS budget per shape class: the best of an exhaustive sweep (nine tiles x five LDS caps per layer of the 640x640 network at B = 64,
+// tools/dw_sweep2.sh, profiles/r06_dw_strip.md); shapes the table does not fit fall back to the score of dw_strip_geom.
+static void dw_strip_table(int k, int s, int Wo, int& th, int& tw, int& cap_kb) {
+    if (k == 3 && s == 1) { if (Wo >= 256) { th = 16; tw = 32; cap_kb = 60; } else if (Wo >= 96) { th = 8; tw = 40; cap_kb = 48; } else { th = 10; tw = 20; cap_kb = 48; } }
+    else if (k == 3) { if (Wo >= 96) { th = 8; tw = 32; cap_kb = 32; } else { th = 10; tw = 20; cap_kb = 24; } }
+    else if (s == 1) { if (Wo >= 64) { th = 16; tw = 16; cap_kb = 32; } else if (Wo >= 32) { th = 20; tw = 20; cap_kb = 48; } else { th = 10; tw = 20; cap_kb = 32; } }
+    else { if (Wo >= 64) { th = 16; tw = 16; cap_kb = 24; } else { th = 20; tw = 20; cap_kb = 48; } }
+}
+template <typename T, int KS, int S>
+static hipError_t dw_strip_pick(hipStream_t s, const DwParams& p) {
+    static const int force = cf_ab_int("CF_DW_TILE", -1);           // A/B: index into the tile list
+    static const int cap_env = cf_ab_int("CF_DW_CAP", 0);           //      LDS budget of the tile buffer in KB
+    int tth = 0, ttw = 0, tcap = 48;
+    dw_strip_table(KS, S, p.Wo, tth, ttw, tcap);
+    int best = -1, bthreads = 0, idx = 0; double bscore = -1.0; DwLdsGeom bg{};
+    // first choice: the table's tile; otherwise (or when the table's tile cannot hold one 16-byte channel group) the best score
+    for (int pass = 0; pass < 2 && best < 0; ++pass) {
+        const size_t cap = (size_t)(cap_env > 0 ? cap_env : (pass == 0 ? tcap : 48)) * 1024;
+        idx = 0;
+#define CF_DW_TRY(TH_, TW_) { DwLdsGeom g{}; int th = 0; double sc = 0; \
+            const bool want = force >= 0 ? idx == force : (pass == 0 ? (TH_ == tth && TW_ == ttw) : true); \
+            if (want && dw_strip_geom<T>(p, TH_, TW_, cap, g, th, sc) && (force >= 0 || pass == 0 || sc > bscore)) { best = idx; bscore = sc; bg = g; bthreads = th; } ++idx; }
+        CF_DW_TILES(CF_DW_TRY)
+#undef CF_DW_TRY
+        if (force >= 0) break;
     }
-    // small late maps (20x20 at 640x640 input): one tile = the whole map (no spatial padding waste)
-    if (p.Ho <= 20 && p.Wo <= 20 && p.Ho > 8) {
-        if (p.k == 3 && p.s == 1) return dw_lds_dispatch<T, 3, 1, 20, 20>(s, p);
-        if (p.k == 5 && p.s == 1) return dw_lds_dispatch<T, 5, 1, 20, 20>(s, p);
-        if (p.k == 3 && p.s == 2) return dw_lds_dispatch<T, 3, 2, 10, 20>(s, p);
-        // 5x5 stride 2: the 43-wide halo tile forces a 24-channel chunk; 4x32 tiles measured faster
-    }
-    // measured on MI355X, B=64 (profiles/r01_dw_variants.md): wide tiles for the big early maps
-    // (less halo per byte), smaller ones where the channel chunk would otherwise drop below a pixel
-    if (p.k == 3 && p.s == 1) return p.C <= 32 ? dw_lds_dispatch<T, 3, 1, 16, 16>(s, p) : dw_lds_dispatch<T, 3, 1, 8, 16>(s, p);
-    if (p.k == 3 && p.s == 2) return p.Wo >= 64 ? dw_lds_dispatch<T, 3, 2, 4, 32>(s, p) : dw_lds_dispatch<T, 3, 2, 4, 16>(s, p);
-    if (p.k == 5 && p.s == 1) return p.Wo >= 32 ? dw_lds_dispatch<T, 5, 1, 16, 16>(s, p) : dw_lds_dispatch<T, 5, 1, 8, 32>(s, p);
-    if (p.k == 5 && p.s == 2) return p.Wo >= 64 ? dw_lds_dispatch<T, 5, 2, 4, 16>(s, p) : dw_lds_dispatch<T, 5, 2, 4, 32>(s, p);
+    if (best < 0) return hipErrorInvalidValue;
+    idx = 0;
+#define CF_DW_GO(TH_, TW_) if (idx++ == best) return dw_strip_launch<T, KS, S, TH_, TW_>(s, p, bg, bthreads);
+    CF_DW_TILES(CF_DW_GO)
+#undef CF_DW_GO
+    return hipErrorInvalidValue;
+}
+template <typename T>
+static hipError_t dw_strip_by_shape(hipStream_t s, const DwParams& p) {
+    if (p.k == 3 && p.s == 1) return dw_strip_pick<T, 3, 1>(s, p);
+    if (p.k == 3 && p.s == 2) return dw_strip_pick<T, 3, 2>(s, p);
+    if (p.k == 5 && p.s == 1) return dw_strip_pick<T, 5, 1>(s, p);
+    if (p.k == 5 && p.s == 2) return dw_strip_pick<T, 5, 2>(s, p);
     return hipErrorInvalidValue;
 }
 
-template <typename T, int VEC3, int VEC5>
-static hipError_t dw_by_shape(hipStream_t s, const DwParams& p) {
-    if (p.k == 3 && p.s == 1) return dw_dispatch<T, 3, 1, VEC3, 8>(s, p);
-    if (p.k == 3 && p.s == 2) return dw_dispatch<T, 3, 2, VEC3, 4>(s, p);
-    if (p.k == 5 && p.s == 1) return dw_dispatch<T, 5, 1, VEC5, 8>(s, p);
-    if (p.k == 5 && p.s == 2) return dw_dispatch<T, 5, 2, VEC5, 4>(s, p);
-    return hipErrorInvalidValue;
-}
+#include CF_EXP_INC(cf_dw_2)   // ... and their per-shape dispatch
 
 hipError_t launch_dw(hipStream_t s, int dtype, const DwParams& p) {
     if (p.B <= 0) return hipSuccess;
     if (p.C % 8) return hipErrorInvalidValue;
-    // CF_DW_MARCH=1 (experiments build) selects the register-marching kernel (A/B against the LDS-staged one)
-    static const bool march = cf_ab_int("CF_DW_MARCH", 0) == 1;
-    if (march) {
-        if (dtype != 1) return dw_by_shape<float, 4, 4>(s, p);
-        return dw_by_shape<bf16_t, 8, 4>(s, p);
-    }
-    return dtype != 1 ? dw_lds_by_shape<float>(s, p) : dw_lds_by_shape<bf16_t>(s, p);      // dtype 2: fp32 storage, no GEMM here
+#include CF_EXP_INC(cf_dw_3)   // CF_DW_MARCH=1 / CF_DW_STRIP=0: the older kernels, for A/B runs
+    return dtype != 1 ? dw_strip_by_shape<float>(s, p) : dw_strip_by_shape<bf16_t>(s, p);      // dtype 2: fp32 storage, no GEMM here
 }
 
 }  // namespace cf
