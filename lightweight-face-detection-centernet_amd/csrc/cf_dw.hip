@@ -7,11 +7,11 @@
 // The op is pure streaming (1.8 - 12.5 flop/B): the design goal is HBM bandwidth.
 //  * the halo tile of one channel chunk is copied HBM -> LDS by the DMA path (global_load_lds_dwordx4), out-of-image chunks from a
 //    zero constant (= ZeroPad2d), the chunk's tap weights (fp32) next to it;
-//  * the compute phase works on strips of four output pixels per 16-byte channel group (dw_strip_kernel below: what it reads from LDS
-//    and how many VALU operations it spends per output element, against round 1's one-vector-per-item form);
+//  * stride 1: the compute phase works on strips of four output pixels per 16-byte channel group (dw_strip_kernel below: what it reads
+//    from LDS and how many VALU operations it spends per output element); stride 2: one output vector per work item (dw_lds_kernel);
 //  * ZeroPad2d, bias, Swish and the bf16 pack are fused: the op reads its unpadded input once and writes its output once.
-// Measured per layer of the 640x640 network at B = 64 (profiles/r06_dw_strip.md): 3x3 stride 2 5.57 TB/s = 70 % of the 8 TB/s spec
-// (layer1.0; round 1: 4.63), 3x3 stride 1 3.3-4.2 TB/s, 5x5 1.9-3.7 TB/s (round 1: 1.3-2.7; VALU-bound: 25 taps per output element).
+// Measured per layer of the 640x640 network at B = 64 (profiles/r06_dw_strip.md): 3x3 stride 1 3.3-4.2 TB/s (round 1: 2.5-3.8), 5x5 stride 1
+// 1.9-2.3 TB/s (1.3-1.7; VALU-bound: 25 taps per output element), stride 2 on round 1's form (4.63 TB/s = 58 % of the 8 TB/s spec on layer1.0).
 // The product path fuses this op into the MBConv kernels (the depthwise tensor never reaches HBM); it runs standalone in the
 // unfused path (CF_FLAG_NO_FUSE), in cf_op_dwconv and in the ShuffleV2 block.
 #include "cf_exp.h"
@@ -41,7 +41,113 @@ __device__ __attribute__((aligned(16))) const uint32_t g_dw_zero16[4] = {0u, 0u,
 struct DwLdsGeom { int Cc, nchunk, cpp, rc, nch, magic_rc, magic_cpp, nt; size_t lds_bytes; };
 static int magic_div(int d) { return (int)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }   // exact for n < 2^16, d >= 2 (d = 1 does not fit 32 bits: the kernels test for it)
 
-#include CF_EXP_INC(cf_dw_1)   // round 1's one-output-vector-per-item compute phase (CF_DW_STRIP=0)
+// ---- one output vector per work item (round 1): the form the STRIDE-2 layers keep (dw_by_stride below)
+template <typename T, int KS, int S, int TH, int TW, int ACT, bool BIAS>
+__global__ __launch_bounds__(256) void dw_lds_kernel(DwParams p, DwLdsGeom g) {
+    constexpr int P = Elem<T>::PER16;
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tile = smem;                                            // [IH][IW][Cc] T, linear 16-byte chunks
+    float* wl = reinterpret_cast<float*>(smem + (((size_t)g.nch * 16 + 1023) / 1024) * 1024);   // [k*k][Cc]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int b = blockIdx.z / g.nchunk, c0 = (blockIdx.z - b * g.nchunk) * g.Cc;
+    const int iy0 = y0 * S - p.pad_lo, ix0 = x0 * S - p.pad_lo;
+    const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.C + c0) * sizeof(T);
+
+    // ---- DMA the tile: chunk q -> (row, pixel, part); LDS address = q * 16 (lane-linear per wave)
+    const int ngroups = (g.nch + 63) >> 6;
+    for (int grp = wave; grp < ngroups; grp += 4) {
+        const int q = grp * 64 + lane;
+        const int row = __umulhi((unsigned)q, (unsigned)g.magic_rc);
+        const int rem = q - row * g.rc;
+        const int px = (g.cpp == 1 ? rem : (int)__umulhi((unsigned)rem, (unsigned)g.magic_cpp));
+        const int part = rem - px * g.cpp;
+        const int gy = iy0 + row, gx = ix0 + px;
+        const bool ok = q < g.nch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const char* src = ok ? xb + ((size_t)gy * p.W + gx) * p.C * sizeof(T) + part * 16
+                             : reinterpret_cast<const char*>(g_dw_zero16);
+        if (g.nt & 1)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tile + grp * 1024), 16, 0, 2);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tile + grp * 1024), 16, 0, 0);
+    }
+    for (int i = tid; i < KS * KS * (g.Cc / 4); i += 256) {       // tap weights of this channel chunk
+        const int t = i / (g.Cc / 4), c4 = i - t * (g.Cc / 4);
+        st16(wl + t * g.Cc + c4 * 4, ld16(p.w + (size_t)t * p.C + c0 + c4 * 4));
+    }
+    cf_sync_lds_dma();                                            // every wave drains its DMAs (vmcnt), then the barrier
+
+    // ---- compute: output vector v -> (pixel, channel group)
+    const int nvec = TH * TW * g.cpp;
+    for (int v = tid; v < nvec; v += 256) {
+        const int opx = (g.cpp == 1 ? v : (int)__umulhi((unsigned)v, (unsigned)g.magic_cpp));
+        const int cg = v - opx * g.cpp;
+        const int oy = opx / TW, ox = opx % TW;
+        const int gy = y0 + oy, gx = x0 + ox;
+        if (gy >= p.Ho || gx >= p.Wo) continue;
+        const char* tb = tile + ((size_t)((oy * S) * IW + ox * S) * g.cpp + cg) * 16;
+        const float* wb = wl + cg * P;
+        float d[P];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                float ev[P], wv[P];
+                unpack16<T>(ld16(tb + (size_t)(ky * IW + kx) * g.cpp * 16), ev);
+                const float* wt = wb + (ky * KS + kx) * g.Cc;
+                unpack16<float>(ld16(wt), wv);
+                if constexpr (P == 8) unpack16<float>(ld16(wt + 4), wv + 4);
+                if (ky == 0 && kx == 0) {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) d[e] = ev[e] * wv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < P; ++e) d[e] = fmaf(ev[e], wv[e], d[e]);
+                }
+            }
+        const int ch = c0 + cg * P;
+#pragma unroll
+        for (int e = 0; e < P; ++e) d[e] = d[e] + (BIAS ? p.bias[ch + e] : 0.0f);
+        act_arr<ACT, P>(d);
+        u32x4* dstp = reinterpret_cast<u32x4*>((char*)p.y + ((((size_t)b * p.Ho + gy) * p.Wo + gx) * p.C + ch) * sizeof(T));
+        if (g.nt & 2) __builtin_nontemporal_store(pack16<T>(d), dstp);
+        else *dstp = pack16<T>(d);
+    }
+}
+
+
+template <typename T, int KS, int S, int TH, int TW>
+static hipError_t dw_lds_dispatch(hipStream_t s, const DwParams& p) {
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int P = 16 / (int)sizeof(T);
+    // channel chunk: largest divisor of C (multiple of one 16-byte group) whose tile fits 48 KiB (tile + tap weights stay under the 64 KiB default dynamic-LDS limit)
+    int Cc = 0;
+    for (int c = p.C; c >= P; c -= P)
+        if (p.C % c == 0 && (size_t)IH * IW * c * sizeof(T) <= 48 * 1024) { Cc = c; break; }
+    if (!Cc) return hipErrorInvalidValue;
+    DwLdsGeom g;
+    g.Cc = Cc; g.nchunk = p.C / Cc; g.cpp = Cc / P; g.rc = IW * g.cpp; g.nch = IH * g.rc;
+    if (g.nch >= 65536) return hipErrorInvalidValue;
+    g.magic_rc = magic_div(g.rc); g.magic_cpp = magic_div(g.cpp);
+    { static const int nt_env = cf_ab_int("CF_DW_NT", 0); g.nt = nt_env; }
+    g.lds_bytes = (((size_t)g.nch * 16 + 1023) / 1024) * 1024 + (size_t)KS * KS * Cc * 4;
+    dim3 grid((p.Wo + TW - 1) / TW, (p.Ho + TH - 1) / TH, p.B * g.nchunk), blk(256);
+    const bool bias = p.bias != nullptr;
+    set_kernel_tag("void cf::dw_lds_kernel<%s, %d, %d, %d, %d, %d, %s>(cf::DwParams, cf::DwLdsGeom)", type_tag<T>(), KS, S, TH, TW,
+                   p.act, bias ? "true" : "false");
+#define CF_DW_LAUNCH(ACT, BIAS) \
+    hipLaunchKernelGGL((dw_lds_kernel<T, KS, S, TH, TW, ACT, BIAS>), grid, blk, g.lds_bytes, s, p, g); return hipGetLastError();
+    if (p.act == 1 && !bias) { CF_DW_LAUNCH(1, false) }
+    if (p.act == 0 && bias) { CF_DW_LAUNCH(0, true) }
+    if (p.act == 0 && !bias) { CF_DW_LAUNCH(0, false) }
+    CF_DW_LAUNCH(1, true)
+#undef CF_DW_LAUNCH
+}
+
 
 // ================================================================== LDS-staged, strip form (round 6)
 // Same staging as dw_lds_kernel (the halo tile of one channel chunk by LDS DMA, tap weights as fp32 next to it); the compute phase is
@@ -231,10 +337,9 @@ static bool dw_strip_geom(const DwParams& p, int TH, int TW, size_t cap, DwLdsGe
 // Tile and LDS budget per shape class: the best of an exhaustive sweep (nine tiles x five LDS caps per layer of the 640x640 network at B = 64,
 // tools/dw_sweep2.sh, profiles/r06_dw_strip.md); shapes the table does not fit fall back to the score of dw_strip_geom.
 static void dw_strip_table(int k, int s, int Wo, int& th, int& tw, int& cap_kb) {
-    if (k == 3 && s == 1) { if (Wo >= 256) { th = 16; tw = 32; cap_kb = 60; } else if (Wo >= 96) { th = 8; tw = 40; cap_kb = 48; } else { th = 10; tw = 20; cap_kb = 48; } }
-    else if (k == 3) { if (Wo >= 96) { th = 8; tw = 32; cap_kb = 32; } else { th = 10; tw = 20; cap_kb = 24; } }
-    else if (s == 1) { if (Wo >= 64) { th = 16; tw = 16; cap_kb = 32; } else if (Wo >= 32) { th = 20; tw = 20; cap_kb = 48; } else { th = 10; tw = 20; cap_kb = 32; } }
-    else { if (Wo >= 64) { th = 16; tw = 16; cap_kb = 24; } else { th = 20; tw = 20; cap_kb = 48; } }
+    (void)s;                                                         // (stride 1 only: dw_by_stride)
+    if (k == 3) { if (Wo >= 256) { th = 16; tw = 32; cap_kb = 60; } else if (Wo >= 96) { th = 8; tw = 40; cap_kb = 48; } else { th = 10; tw = 20; cap_kb = 48; } }
+    else { if (Wo >= 64) { th = 16; tw = 16; cap_kb = 32; } else if (Wo >= 32) { th = 20; tw = 20; cap_kb = 48; } else { th = 10; tw = 20; cap_kb = 32; } }
 }
 template <typename T, int KS, int S>
 static hipError_t dw_strip_pick(hipStream_t s, const DwParams& p) {
@@ -261,12 +366,18 @@ static hipError_t dw_strip_pick(hipStream_t s, const DwParams& p) {
 #undef CF_DW_GO
     return hipErrorInvalidValue;
 }
+// Stride 1: the strip form (3.3-4.2 TB/s at 3x3 against 2.5-3.8, 1.9-2.3 TB/s at 5x5 against 1.3-1.7).  Stride 2: round 1's one-vector form -- a strip of four
+// stride-2 outputs sits on 9 / 11 input columns per row, the reuse is small and the work items are four times fewer: measured 4.18 / 2.73 / 3.73 / 1.84 TB/s
+// (layer1.0 / 2.0 / 3.0 / 5.0, best of 45 tile x LDS-budget combinations each) against 4.63 / 2.70 / 3.97 / 1.98 (profiles/r06_dw_strip.md).
 template <typename T>
-static hipError_t dw_strip_by_shape(hipStream_t s, const DwParams& p) {
+static hipError_t dw_by_stride(hipStream_t s, const DwParams& p) {
     if (p.k == 3 && p.s == 1) return dw_strip_pick<T, 3, 1>(s, p);
-    if (p.k == 3 && p.s == 2) return dw_strip_pick<T, 3, 2>(s, p);
     if (p.k == 5 && p.s == 1) return dw_strip_pick<T, 5, 1>(s, p);
-    if (p.k == 5 && p.s == 2) return dw_strip_pick<T, 5, 2>(s, p);
+    if (p.k == 3 && p.s == 2) {
+        if (p.Ho <= 20 && p.Wo <= 20 && p.Ho > 8) return dw_lds_dispatch<T, 3, 2, 10, 20>(s, p);      // small late maps: one tile = the whole map
+        return p.Wo >= 64 ? dw_lds_dispatch<T, 3, 2, 4, 32>(s, p) : dw_lds_dispatch<T, 3, 2, 4, 16>(s, p);
+    }
+    if (p.k == 5 && p.s == 2) return p.Wo >= 64 ? dw_lds_dispatch<T, 5, 2, 4, 16>(s, p) : dw_lds_dispatch<T, 5, 2, 4, 32>(s, p);
     return hipErrorInvalidValue;
 }
 
@@ -276,7 +387,7 @@ hipError_t launch_dw(hipStream_t s, int dtype, const DwParams& p) {
     if (p.B <= 0) return hipSuccess;
     if (p.C % 8) return hipErrorInvalidValue;
 #include CF_EXP_INC(cf_dw_3)   // CF_DW_MARCH=1 / CF_DW_STRIP=0: the older kernels, for A/B runs
-    return dtype != 1 ? dw_strip_by_shape<float>(s, p) : dw_strip_by_shape<bf16_t>(s, p);      // dtype 2: fp32 storage, no GEMM here
+    return dtype != 1 ? dw_by_stride<float>(s, p) : dw_by_stride<bf16_t>(s, p);      // dtype 2: fp32 storage, no GEMM here
 }
 
 }  // namespace cf
