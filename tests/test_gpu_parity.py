@@ -76,6 +76,26 @@ def test_conv_swish_flavours_vs_reference(golden, dtype):
         np.testing.assert_allclose(y, g["cr5_y"], **_tol(dtype))
 
 
+@pytest.mark.parametrize("k,s", [(3, 1), (5, 1), (3, 2), (5, 2)])
+@pytest.mark.parametrize("C", [8, 16, 40])
+def test_depthwise_narrow_channel_chunks_vs_oracle(C, k, s):
+    """cf_dw.hip with channel chunks of ONE or two 16-byte groups (C = 8: cpp == 1 in bf16; C = 16 / 40: 2 / 5 groups, fp32: 2 / 4 / 10): round 6 found
+    that `magic_div(1)` does not fit 32 bits -- every chunk fetched from pixel 0, wrong and fast -- in the strip kernel AND latent in round 1's kernel.
+    Both dtypes, both kernels (stride 1: strip form, stride 2: one-vector form), maps that are not multiples of any tile, a batch."""
+    rng = np.random.default_rng(C * 100 + k * 10 + s)
+    x = rng.standard_normal((3, C, 37, 53)).astype(np.float32)
+    w = (rng.standard_normal((C, 1, k, k)) * 0.3).astype(np.float32)
+    ref = O.swish(torch.nn.functional.conv2d(torch.nn.functional.pad(torch.from_numpy(x), _same_pad(k, s)), torch.from_numpy(w), None, s, 0, 1, C)).numpy()
+    y = ops.conv_dw(x, w, k, s, dtype="fp32")
+    np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
+    _emu_close(ops.conv_dw(x, w, k, s, dtype="bf16"), E.dw_op(x, w, k, s), "dw C=%d k=%d s=%d" % (C, k, s))
+
+
+def _same_pad(k, s):
+    p = max(k - s, 0)
+    return [p // 2, p - p // 2, p // 2, p - p // 2]
+
+
 def _mbconv_gpu(x, sd, cin, cout, t, k, s, dtype):
     y, j = x, 0
     if t != 1:
