@@ -38,7 +38,15 @@ void dw_pack_weights(const float* w, int C, int k, float* out_host) {
 // pixel, so LDS reads are conflict-free and global stores are whole pixels' worth of contiguous bytes.
 __device__ __attribute__((aligned(16))) const uint32_t g_dw_zero16[4] = {0u, 0u, 0u, 0u};
 
-struct DwLdsGeom { int Cc, nchunk, cpp, rc, nch, magic_rc, magic_cpp, nt; size_t lds_bytes; };
+struct DwLdsGeom { int Cc, nchunk, cpp, rc, nch, magic_rc, magic_cpp, nt, xcd; size_t lds_bytes; };
+// Workgroups are dealt to the eight XCDs round-robin by their linear id, and each XCD has an L2 of its own: with the plain order
+// the tile below (its first halo rows = this tile's last ones) and the other channel chunks of the same pixels (the other half of
+// the same 128-byte lines) run on OTHER XCDs and fetch those lines again (round 6, PMC: 1.22x the input bytes on layer1.0).  The
+// remap gives XCD k the k-th contiguous eighth of the work list, ordered channel chunk -> tile column -> tile row -> image.
+__device__ __forceinline__ unsigned dw_xcd_remap(unsigned l, unsigned n) {
+    const unsigned q = n >> 3, r = n & 7u, k = l & 7u;
+    return k * q + (k < r ? k : r) + (l >> 3);
+}
 static int magic_div(int d) { return (int)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }   // exact for n < 2^16, d >= 2 (d = 1 does not fit 32 bits: the kernels test for it)
 
 // ---- one output vector per work item (round 1): the form the STRIDE-2 layers keep (dw_by_stride below)
@@ -51,8 +59,17 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(DwParams p, DwLdsGeom g) {
     float* wl = reinterpret_cast<float*>(smem + (((size_t)g.nch * 16 + 1023) / 1024) * 1024);   // [k*k][Cc]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int b = blockIdx.z / g.nchunk, c0 = (blockIdx.z - b * g.nchunk) * g.Cc;
+    int x0, y0, b, c0;
+    if (g.xcd) {
+        unsigned l = dw_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+        const unsigned ck = l % (unsigned)g.nchunk; l /= (unsigned)g.nchunk;
+        const unsigned tx = l % gridDim.x; l /= gridDim.x;
+        const unsigned ty = l % gridDim.y;
+        x0 = tx * TW; y0 = ty * TH; b = l / gridDim.y; c0 = ck * g.Cc;
+    } else {
+        x0 = blockIdx.x * TW; y0 = blockIdx.y * TH;
+        b = blockIdx.z / g.nchunk; c0 = (blockIdx.z - b * g.nchunk) * g.Cc;
+    }
     const int iy0 = y0 * S - p.pad_lo, ix0 = x0 * S - p.pad_lo;
     const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.C + c0) * sizeof(T);
 
@@ -134,6 +151,7 @@ static hipError_t dw_lds_dispatch(hipStream_t s, const DwParams& p) {
     if (g.nch >= 65536) return hipErrorInvalidValue;
     g.magic_rc = magic_div(g.rc); g.magic_cpp = magic_div(g.cpp);
     { static const int nt_env = cf_ab_int("CF_DW_NT", 0); g.nt = nt_env; }
+    { static const int xcd_env = cf_ab_int("CF_DW_XCD", 1); g.xcd = xcd_env; }
     g.lds_bytes = (((size_t)g.nch * 16 + 1023) / 1024) * 1024 + (size_t)KS * KS * Cc * 4;
     dim3 grid((p.Wo + TW - 1) / TW, (p.Ho + TH - 1) / TH, p.B * g.nchunk), blk(256);
     const bool bias = p.bias != nullptr;
@@ -175,6 +193,14 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(DwParams p, DwLdsGeom g, 
 
     // tile t -> (image, channel chunk, tile row, tile column); x fastest, so the tiles in flight at any moment are neighbours (shared halo lines in L2)
     auto decode = [&](int t, int& b, int& c0, int& y0, int& x0) {
+        if (g.xcd && (int)gridDim.x == ntiles) {                      // one workgroup per tile: XCD-contiguous work list (dw_xcd_remap)
+            t = (int)dw_xcd_remap((unsigned)t, (unsigned)ntiles);
+            const int ck = t % g.nchunk; t /= g.nchunk;
+            const int tx = t % ntx; t /= ntx;
+            const int ty = t % nty; b = t / nty;
+            c0 = ck * g.Cc; y0 = ty * TH; x0 = tx * TW;
+            return;
+        }
         const int tx = t % ntx; t /= ntx;
         const int ty = t % nty; t /= nty;
         const int ck = t % g.nchunk; b = t / g.nchunk;
@@ -319,6 +345,7 @@ static bool dw_strip_geom(const DwParams& p, int TH, int TW, size_t cap, DwLdsGe
     if (!Cc) return false;
     g.Cc = Cc; g.nchunk = p.C / Cc; g.cpp = Cc / P; g.rc = IW * g.cpp; g.nch = IH * g.rc;
     g.magic_rc = magic_div(g.rc); g.magic_cpp = magic_div(g.cpp); g.nt = 0;
+    { static const int xcd_env = cf_ab_int("CF_DW_XCD", 1); g.xcd = xcd_env; }
     g.lds_bytes = (((size_t)g.nch * 16 + 1023) / 1024) * 1024 + (((size_t)p.k * p.k * Cc * 4 + 1023) / 1024) * 1024;
     const int items = TH * (TW / 4) * g.cpp;
     threads = items >= 256 ? 256 : (items + 63) / 64 * 64;
