@@ -138,13 +138,16 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(DwParams p, DwLdsGeom g) {
 
 
 template <typename T, int KS, int S, int TH, int TW>
-static hipError_t dw_lds_dispatch(hipStream_t s, const DwParams& p) {
+static hipError_t dw_lds_dispatch(hipStream_t s, const DwParams& p, int cap_default = 48) {
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
     constexpr int P = 16 / (int)sizeof(T);
-    // channel chunk: largest divisor of C (multiple of one 16-byte group) whose tile fits 48 KiB (tile + tap weights stay under the 64 KiB default dynamic-LDS limit)
+    // channel chunk: largest divisor of C (multiple of one 16-byte group) whose tile fits the budget (48 KiB unless the caller's table says otherwise: tile +
+    // tap weights stay under the 64 KiB default dynamic-LDS limit; a smaller budget = more workgroups per CU, shorter DMA runs per pixel)
     int Cc = 0;
+    static const int cap_env = cf_ab_int("CF_DW_CAP2", 0);           // A/B: LDS budget of the tile in KB
+    const int cap_kb = cap_env > 0 ? cap_env : cap_default;
     for (int c = p.C; c >= P; c -= P)
-        if (p.C % c == 0 && (size_t)IH * IW * c * sizeof(T) <= 48 * 1024) { Cc = c; break; }
+        if (p.C % c == 0 && (size_t)IH * IW * c * sizeof(T) <= (size_t)cap_kb * 1024) { Cc = c; break; }
     if (!Cc) return hipErrorInvalidValue;
     DwLdsGeom g;
     g.Cc = Cc; g.nchunk = p.C / Cc; g.cpp = Cc / P; g.rc = IW * g.cpp; g.nch = IH * g.rc;
@@ -400,11 +403,14 @@ template <typename T>
 static hipError_t dw_by_stride(hipStream_t s, const DwParams& p) {
     if (p.k == 3 && p.s == 1) return dw_strip_pick<T, 3, 1>(s, p);
     if (p.k == 5 && p.s == 1) return dw_strip_pick<T, 5, 1>(s, p);
+#include CF_EXP_INC(cf_dw_4)   // CF_DW2_TILE: tile sweep of the stride-2 form
     if (p.k == 3 && p.s == 2) {
         if (p.Ho <= 20 && p.Wo <= 20 && p.Ho > 8) return dw_lds_dispatch<T, 3, 2, 10, 20>(s, p);      // small late maps: one tile = the whole map
-        return p.Wo >= 64 ? dw_lds_dispatch<T, 3, 2, 4, 32>(s, p) : dw_lds_dispatch<T, 3, 2, 4, 16>(s, p);
+        // (tile x LDS budget sweep with the XCD-contiguous order, gpurun_out/r06q_sweep_s2.txt: layer3.0 3.77 -> 4.33 TB/s at 24 KB)
+        return p.Wo >= 64 ? dw_lds_dispatch<T, 3, 2, 4, 32>(s, p, 48) : dw_lds_dispatch<T, 3, 2, 4, 16>(s, p, 24);
     }
-    if (p.k == 5 && p.s == 2) return p.Wo >= 64 ? dw_lds_dispatch<T, 5, 2, 4, 16>(s, p) : dw_lds_dispatch<T, 5, 2, 4, 32>(s, p);
+    // (same sweep: layer2.0 2.55 -> 2.93 TB/s on 8x16 tiles at 24 KB, layer5.0 1.94 -> 2.16 at 32 KB)
+    if (p.k == 5 && p.s == 2) return p.Wo >= 64 ? dw_lds_dispatch<T, 5, 2, 8, 16>(s, p, 24) : dw_lds_dispatch<T, 5, 2, 4, 32>(s, p, 32);
     return hipErrorInvalidValue;
 }
 
