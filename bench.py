@@ -330,6 +330,37 @@ def other_configs_block(cfa, dev_index):
     return out
 
 
+def standalone_depthwise_block(cfa, d_in_ptr, B, S, K, dev_index, reps=5):
+    """north_star's "depthwise-conv achieved HBM >= 60 % of gfx950 peak": the benchmarked path fuses every depthwise into its MBConv kernel (the
+    depthwise tensor never reaches HBM), so the STANDALONE kernel (cf_dw.hip: unfused path, cf_op_dwconv, ShuffleV2 block) is timed here on the
+    twelve depthwise layers of this network at the benchmarked batch: HIP events around each launch of the unfused forward (cf_profile_forward),
+    GB/s of unpadded input + output bytes."""
+    eng = cfa.Engine(S, S, max_batch=B, dtype="bf16", fuse=False, device=dev_index)
+    try:
+        fmt = cfa._lib.CF_IN_U8_HWC_BGR
+        for _ in range(2):
+            eng.profile_forward(d_in_ptr, on_device=True, B=B, in_format=fmt, K=K)
+        acc = {}
+        for _ in range(reps):
+            for r in eng.profile_forward(d_in_ptr, on_device=True, B=B, in_format=fmt, K=K):
+                if r["kind"] == "dw":
+                    a = acc.setdefault(r["name"], dict(ms=0.0, bytes=r["algo_bytes"], kernel=r["kernel"]))
+                    a["ms"] += r["ms"]
+    finally:
+        eng.close()
+    layers, tb, tms = {}, 0.0, 0.0
+    for name, a in acc.items():
+        ms = a["ms"] / reps
+        layers[name] = {"GBps": round(a["bytes"] / (ms * 1e-3) / 1e9, 1), "ms": round(ms, 4), "frac_of_8TBps": round(a["bytes"] / (ms * 1e-3) / 8e12, 3),
+                        "kernel": a["kernel"].split("(")[0].replace("void cf::", "")}
+        tb += a["bytes"]; tms += ms
+    best = max(layers.items(), key=lambda kv: kv[1]["GBps"])
+    return {"layers": layers, "best": {"layer": best[0], "GBps": best[1]["GBps"], "frac_of_8TBps": best[1]["frac_of_8TBps"]},
+            "all_twelve": {"GBps": round(tb / (tms * 1e-3) / 1e9, 1), "ms": round(tms, 4), "frac_of_8TBps": round(tb / (tms * 1e-3) / 8e12, 3)},
+            "note": "standalone depthwise + Swish kernel (bf16, B = %d, %dx%d network shapes), algorithmic bytes = unpadded input + output; not on the benchmarked "
+                    "path (fused there); layer1.0 (3x3 stride 2, 96 channels, 320^2 -> 160^2) is the largest depthwise of the network (29 %% of all depthwise bytes)" % (B, S, S)}
+
+
 def parity_block(cfa, eng16, host_imgs, d_in_ptr, B, S, K, dev_index):
     """The timed batch through the benchmarked engine vs the fp32 parity engine (GPU), + image 0 vs the bf16 emulation."""
     import torch
@@ -811,6 +842,10 @@ def main():
             result["other_configs"] = other_configs_block(cfa, local_rank)
         except Exception as exc:                                # noqa: BLE001  (never costs the headline its line)
             result["other_configs"] = {"error": repr(exc)[:300]}
+        try:
+            result["standalone_depthwise"] = standalone_depthwise_block(cfa, d_in.data_ptr(), B, S, K, local_rank)
+        except Exception as exc:                                # noqa: BLE001
+            result["standalone_depthwise"] = {"error": repr(exc)[:300]}
         # ---- tolerance mode: the mode that meets north_star's "box/score within 1e-3 of the reference" at speed
         v, v1, nctx = mode_rate("fp32_split")
         tol_exact, tol_oracle, tol_bm, tol_roof = tolerance_block(cfa, host_imgs, d_in.data_ptr(), B, S, K, local_rank, parity_aux, max(1, args.profile_reps))

@@ -527,6 +527,18 @@ def test_bench_other_configs_block_runs():
     assert s4["images_per_s"] > 500 and s4["contexts"] == 3 and s4["batch"] == 4 and s4["topk"] == 1000
 
 
+def test_bench_standalone_depthwise_block_runs():
+    """bench.py's `standalone_depthwise` extra (north_star's depthwise-conv HBM fraction, measured on the standalone kernel over the unfused forward): twelve
+    depthwise layers with a rate each, the aggregate and the best layer; small batch here, the rates themselves are the bench run's business."""
+    import torch
+    sys.path.insert(0, REPO)
+    import bench
+    x = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (8, 640, 640, 3), dtype=np.uint8)).to("cuda:0")
+    o = bench.standalone_depthwise_block(cfa, x.data_ptr(), 8, 640, 100, 0, reps=2)
+    assert len(o["layers"]) == 12 and all(v["GBps"] > 100 and "dw_" in v["kernel"] for v in o["layers"].values()), o
+    assert o["best"]["layer"] in o["layers"] and 0 < o["all_twelve"]["frac_of_8TBps"] < 1 and 0 < o["best"]["frac_of_8TBps"] < 1
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields():
     """bench.py as the driver runs it (small workload): exactly one line on stdout, the contract's fields, roofline and
     the per-run consistency the judge checks (value = images of the median window / its time)."""
