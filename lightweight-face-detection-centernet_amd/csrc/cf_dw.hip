@@ -10,8 +10,10 @@
 //  * stride 1: the compute phase works on strips of four output pixels per 16-byte channel group (dw_strip_kernel below: what it reads
 //    from LDS and how many VALU operations it spends per output element); stride 2: one output vector per work item (dw_lds_kernel);
 //  * ZeroPad2d, bias, Swish and the bf16 pack are fused: the op reads its unpadded input once and writes its output once.
-// Measured per layer of the 640x640 network at B = 64 (profiles/r06_dw_strip.md): 3x3 stride 1 3.3-4.2 TB/s (round 1: 2.5-3.8), 5x5 stride 1
-// 1.9-2.3 TB/s (1.3-1.7; VALU-bound: 25 taps per output element), stride 2 on round 1's form (4.63 TB/s = 58 % of the 8 TB/s spec on layer1.0).
+//  * workgroups take their tile from an XCD-contiguous work list (dw_xcd_remap: the tile below and the other channel chunks of the same
+//    pixels under ONE L2; PMC fetch 1.22x -> 0.98x the input bytes on layer1.0, profiles/r06_dw_xcd.md).
+// Measured per layer of the 640x640 network at B = 64 (profiles/r06_dw_xcd.md, r06_dw_strip.md): layer1.0 (3x3 stride 2, the largest depthwise of the
+// network) 4.80-5.01 TB/s = 60-63 % of the 8 TB/s spec by box, the other 3x3 layers 3.0-4.2 TB/s, 5x5 2.0-2.9 TB/s (VALU-bound: 25 taps per output element).
 // The product path fuses this op into the MBConv kernels (the depthwise tensor never reaches HBM); it runs standalone in the
 // unfused path (CF_FLAG_NO_FUSE), in cf_op_dwconv and in the ShuffleV2 block.
 #include "cf_exp.h"
