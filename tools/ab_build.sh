@@ -20,6 +20,7 @@ done
 for f in $FILES; do
   b=$(basename "$f" .hip)
   EX=""; [ "$b" = cf_decode ] || [ "$b" = cf_loss ] || [ "$b" = cf_util ] && EX="-ffp-contract=off"
+  case "$b" in *_ilp) EX="-mllvm -amdgpu-sched-strategy=max-ilp";; esac
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 -I"$ROOT/include" -I"$SRC" $EX $FLAGS -c "$SRC/$f" -o "$OUT/$b.o"
   OBJS="$OBJS $OUT/$b.o"
 done
