@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace cf {
 
@@ -266,9 +267,11 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(DwParams p, DwLdsGeom g, 
             const char* tb = tile + ((size_t)((oy * S) * IW + xs * SX * S) * g.cpp + cg) * 16;
             const float* wb = wl + cg * P;
             f32x2 acc[SX][H2];
-            // (one kernel row at a time: fully unrolled, the compiler hoists every row's window and weights -- 460 VGPRs at 5x5, one wave per SIMD)
-#pragma unroll 1
-            for (int ky = 0; ky < KS; ++ky) {
+            // One kernel row at a time: fully unrolled, the compiler hoists every row's window and weights (460 VGPRs at 5x5, one wave per SIMD).  The FIRST
+            // row is peeled off the rolled loop: its first tap is a plain multiply (the order dw_lds_kernel fixes), and with `ky == 0` a run-time test inside
+            // the loop the compiler issued BOTH forms for every kx = 0 tap of every row and selected between them -- 16 v_pk_mul_f32 + 32 v_cndmask_b32 per
+            // row next to the row's 48 (3x3) / 80 (5x5) v_pk_fma_f32 (ISA of round 6's first version; same results, a third fewer tap instructions)
+            auto row = [&](auto first, int ky) {
                 f32x2 xw[WIN][H2];
 #pragma unroll
                 for (int c = 0; c < WIN; ++c) unpack2(ld16(tb + (size_t)(ky * IW + c) * g.cpp * 16), xw[c]);
@@ -288,11 +291,14 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(DwParams p, DwLdsGeom g, 
                     for (int j = 0; j < SX; ++j)
 #pragma unroll
                         for (int h = 0; h < H2; ++h) {
-                            if (ky == 0 && kx == 0) acc[j][h] = xw[j * S + kx][h] * w2[h];
+                            if (decltype(first)::value && kx == 0) acc[j][h] = xw[j * S + kx][h] * w2[h];
                             else acc[j][h] = fma2(xw[j * S + kx][h], w2[h], acc[j][h]);
                         }
                 }
-            }
+            };
+            row(std::true_type{}, 0);
+#pragma unroll 1
+            for (int ky = 1; ky < KS; ++ky) row(std::false_type{}, ky);
             const int ch = c0 + cg * P;
             float bv[P];
 #pragma unroll
