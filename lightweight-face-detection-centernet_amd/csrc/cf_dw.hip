@@ -41,7 +41,12 @@ void dw_pack_weights(const float* w, int C, int k, float* out_host) {
 // pixel, so LDS reads are conflict-free and global stores are whole pixels' worth of contiguous bytes.
 __device__ __attribute__((aligned(16))) const uint32_t g_dw_zero16[4] = {0u, 0u, 0u, 0u};
 
-struct DwLdsGeom { int Cc, nchunk, cpp, rc, nch, magic_rc, magic_cpp, nt, xcd; size_t lds_bytes; };
+struct DwLdsGeom { int Cc, nchunk, cpp, rc, nch, magic_rc, magic_cpp, nt, xcd; size_t lds_bytes;
+                   int srow, spx, spart; };      // one pass of the workgroup through the chunk list (blockDim chunks) = srow tile rows + spx pixels + spart chunks
+static void dw_set_step(DwLdsGeom& g, int threads) {
+    g.srow = threads / g.rc; const int r1 = threads - g.srow * g.rc;
+    g.spx = r1 / g.cpp; g.spart = r1 - g.spx * g.cpp;
+}
 // Workgroups are dealt to the eight XCDs round-robin by their linear id, and each XCD has an L2 of its own: with the plain order
 // the tile below (its first halo rows = this tile's last ones) and the other channel chunks of the same pixels (the other half of
 // the same 128-byte lines) run on OTHER XCDs and fetch those lines again (round 6, PMC: 1.22x the input bytes on layer1.0).  The
@@ -49,6 +54,38 @@ struct DwLdsGeom { int Cc, nchunk, cpp, rc, nch, magic_rc, magic_cpp, nt, xcd; s
 __device__ __forceinline__ unsigned dw_xcd_remap(unsigned l, unsigned n) {
     const unsigned q = n >> 3, r = n & 7u, k = l & 7u;
     return k * q + (k < r ? k : r) + (l >> 3);
+}
+
+// The halo tile of one channel chunk, HBM -> LDS by DMA: chunk q = (tile row, pixel, 16-byte part) lands at tile + 16 q; a chunk outside the image comes from the
+// zero constant (= ZeroPad2d).  A thread owns chunks tid, tid + blockDim, ...: (row, pixel, part) are taken apart ONCE (two magic divisions) and then advanced by
+// the workgroup's step (DwLdsGeom::srow / spx / spart) with adds and two wrap tests, the byte offset inside the image stays in 32 bits.  (Round 6's PMC counts:
+// with the divisions, the 64-bit products and a two-way branch per chunk the staging of a stride-2 tile cost as many VALU instructions as its arithmetic,
+// several of them quarter-rate integer multiplies.)  The image must be smaller than 4 GiB (launch_dw checks).
+template <typename T, int IW>
+__device__ __forceinline__ void dw_stage_tile(const DwParams& p, const DwLdsGeom& g, const char* xb, int iy0, int ix0, char* tile, int tid, int nthr) {
+    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    const int ngroups = (g.nch + 63) >> 6;
+    int q = tid;
+    int row = (int)__umulhi((unsigned)q, (unsigned)g.magic_rc);
+    const int rem = q - row * g.rc;
+    int px = (g.cpp == 1 ? rem : (int)__umulhi((unsigned)rem, (unsigned)g.magic_cpp));
+    int part = rem - px * g.cpp;
+    const unsigned pxb = (unsigned)p.C * (unsigned)sizeof(T), rowb = (unsigned)p.W * pxb;
+    unsigned rowoff = (unsigned)(iy0 + row) * rowb;                 // (wraps for rows above the image: never used there)
+    const unsigned srowb = (unsigned)g.srow * rowb;
+    const char* zsrc = reinterpret_cast<const char*>(g_dw_zero16);
+    (void)lane;
+    for (int grp = wave; grp < ngroups; grp += nwave) {
+        const int gy = iy0 + row, gx = ix0 + px;
+        const bool ok = (q < g.nch) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);      // (bitwise: no short-circuit branches)
+        const unsigned off = rowoff + __umul24((unsigned)gx, pxb) + (unsigned)part * 16u;
+        const char* src = ok ? xb + off : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tile + grp * 1024), 16, 0, 0);
+        q += nthr; part += g.spart; px += g.spx; row += g.srow; rowoff += srowb;
+        if (part >= g.cpp) { part -= g.cpp; px += 1; }
+        if (px >= IW) { px -= IW; row += 1; rowoff += rowb; }
+    }
 }
 static int magic_div(int d) { return (int)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }   // exact for n < 2^16, d >= 2 (d = 1 does not fit 32 bits: the kernels test for it)
 
@@ -77,24 +114,7 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(DwParams p, DwLdsGeom g) {
     const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.C + c0) * sizeof(T);
 
     // ---- DMA the tile: chunk q -> (row, pixel, part); LDS address = q * 16 (lane-linear per wave)
-    const int ngroups = (g.nch + 63) >> 6;
-    for (int grp = wave; grp < ngroups; grp += 4) {
-        const int q = grp * 64 + lane;
-        const int row = __umulhi((unsigned)q, (unsigned)g.magic_rc);
-        const int rem = q - row * g.rc;
-        const int px = (g.cpp == 1 ? rem : (int)__umulhi((unsigned)rem, (unsigned)g.magic_cpp));
-        const int part = rem - px * g.cpp;
-        const int gy = iy0 + row, gx = ix0 + px;
-        const bool ok = q < g.nch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        const char* src = ok ? xb + ((size_t)gy * p.W + gx) * p.C * sizeof(T) + part * 16
-                             : reinterpret_cast<const char*>(g_dw_zero16);
-        if (g.nt & 1)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tile + grp * 1024), 16, 0, 2);
-        else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tile + grp * 1024), 16, 0, 0);
-    }
+    dw_stage_tile<T, IW>(p, g, xb, iy0, ix0, tile, tid, 256);
     for (int i = tid; i < KS * KS * (g.Cc / 4); i += 256) {       // tap weights of this channel chunk
         const int t = i / (g.Cc / 4), c4 = i - t * (g.Cc / 4);
         st16(wl + t * g.Cc + c4 * 4, ld16(p.w + (size_t)t * p.C + c0 + c4 * 4));
@@ -134,8 +154,7 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(DwParams p, DwLdsGeom g) {
         for (int e = 0; e < P; ++e) d[e] = d[e] + (BIAS ? p.bias[ch + e] : 0.0f);
         act_arr<ACT, P>(d);
         u32x4* dstp = reinterpret_cast<u32x4*>((char*)p.y + ((((size_t)b * p.Ho + gy) * p.Wo + gx) * p.C + ch) * sizeof(T));
-        if (g.nt & 2) __builtin_nontemporal_store(pack16<T>(d), dstp);
-        else *dstp = pack16<T>(d);
+        *dstp = pack16<T>(d);
     }
 }
 
@@ -156,7 +175,8 @@ static hipError_t dw_lds_dispatch(hipStream_t s, const DwParams& p, int cap_defa
     g.Cc = Cc; g.nchunk = p.C / Cc; g.cpp = Cc / P; g.rc = IW * g.cpp; g.nch = IH * g.rc;
     if (g.nch >= 65536) return hipErrorInvalidValue;
     g.magic_rc = magic_div(g.rc); g.magic_cpp = magic_div(g.cpp);
-    { static const int nt_env = cf_ab_int("CF_DW_NT", 0); g.nt = nt_env; }
+    g.nt = 0;          // (non-temporal DMA loads cost 8-35 %, non-temporal stores nothing: profiles/r01_dw_variants.md, r06_dw_xcd.md)
+    dw_set_step(g, 256);
     { static const int xcd_env = cf_ab_int("CF_DW_XCD", 1); g.xcd = xcd_env; }
     g.lds_bytes = (((size_t)g.nch * 16 + 1023) / 1024) * 1024 + (size_t)KS * KS * Cc * 4;
     dim3 grid((p.Wo + TW - 1) / TW, (p.Ho + TH - 1) / TH, p.B * g.nchunk), blk(256);
@@ -216,19 +236,7 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(DwParams p, DwLdsGeom g, 
         int b, c0, y0, x0; decode(t, b, c0, y0, x0);
         const int iy0 = y0 * S - p.pad_lo, ix0 = x0 * S - p.pad_lo;
         const char* xb = (const char*)p.x + ((size_t)b * p.H * p.W * p.C + c0) * sizeof(T);
-        for (int grp = wave; grp < ngroups; grp += nwave) {
-            const int q = grp * 64 + lane;
-            const int row = __umulhi((unsigned)q, (unsigned)g.magic_rc);
-            const int rem = q - row * g.rc;
-            const int px = (g.cpp == 1 ? rem : (int)__umulhi((unsigned)rem, (unsigned)g.magic_cpp));
-            const int part = rem - px * g.cpp;
-            const int gy = iy0 + row, gx = ix0 + px;
-            const bool ok = q < g.nch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            const char* src = ok ? xb + ((size_t)gy * p.W + gx) * p.C * sizeof(T) + part * 16
-                                 : reinterpret_cast<const char*>(g_dw_zero16);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(buf + grp * 1024), 16, 0, 0);
-        }
+        dw_stage_tile<T, IW>(p, g, xb, iy0, ix0, buf, tid, nthr);
         // tap weights of the tile's channel chunk: whole 1 KiB groups by DMA as well ([k*k][Cc] fp32 = k*k*Cc/4 chunks of 16 bytes)
         char* wdst = buf + tile_bytes;
         const int nwch = KS * KS * (g.Cc / 4), nwg = (nwch + 63) >> 6;
@@ -338,7 +346,8 @@ static hipError_t dw_strip_launch(hipStream_t s, const DwParams& p, const DwLdsG
     const bool persist = per_cu > 0 && nt > (long long)ncu * per_cu;
     const int nwg = persist ? ncu * per_cu : (int)nt;
     set_kernel_tag("void cf::dw_strip_kernel<%s, %d, %d, %d, %d>(cf::DwParams, cf::DwLdsGeom, int, int, int)", type_tag<T>(), KS, S, TH, TW);
-    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(threads), (persist ? 2 : 1) * g.lds_bytes, s, p, g, ntx, nty, (int)nt);
+    DwLdsGeom gs = g; dw_set_step(gs, threads);
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(threads), (persist ? 2 : 1) * g.lds_bytes, s, p, gs, ntx, nty, (int)nt);
     return hipGetLastError();
 }
 
@@ -427,6 +436,7 @@ static hipError_t dw_by_stride(hipStream_t s, const DwParams& p) {
 hipError_t launch_dw(hipStream_t s, int dtype, const DwParams& p) {
     if (p.B <= 0) return hipSuccess;
     if (p.C % 8) return hipErrorInvalidValue;
+    if ((unsigned long long)p.H * p.W * p.C * (dtype != 1 ? 4ull : 2ull) >= (1ull << 32)) return hipErrorInvalidValue;       // 32-bit byte offsets inside an image (dw_stage_tile)
 #include CF_EXP_INC(cf_dw_3)   // CF_DW_MARCH=1 / CF_DW_STRIP=0: the older kernels, for A/B runs
     return dtype != 1 ? dw_by_stride<float>(s, p) : dw_by_stride<bf16_t>(s, p);      // dtype 2: fp32 storage, no GEMM here
 }
