@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256) void dw_strip_kernel(DwParams p, DwLdsGeom g, 
     }
 }
 
+#include CF_EXP_INC(cf_dw_5)   // the strip form in two row bands (dw_band_kernel): measured, +2-7 % on some layers, -7 % on others -- experiments build only
 struct DwTileCfg { int th, tw; };
 template <typename T, int KS, int S, int TH, int TW>
 static hipError_t dw_strip_launch(hipStream_t s, const DwParams& p, const DwLdsGeom& g, int threads) {
@@ -339,6 +340,7 @@ static hipError_t dw_strip_launch(hipStream_t s, const DwParams& p, const DwLdsG
     const int ntx = (p.Wo + TW - 1) / TW, nty = (p.Ho + TH - 1) / TH;
     const long long nt = (long long)p.B * g.nchunk * nty * ntx;
     if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
+#include CF_EXP_INC(cf_dw_6)   // CF_DW_BAND=1: dw_band_kernel
     // CF_DW_WGS = n > 0: n PERSISTENT workgroups per CU, each walking tiles with two LDS buffers (the DMA of the next tile under the arithmetic of
     // this one); 0: one workgroup per tile, one buffer -- the overlap comes from the other workgroups of the CU
     static const int per_cu = cf_ab_int("CF_DW_WGS", 0);
