@@ -91,6 +91,19 @@ def test_depthwise_narrow_channel_chunks_vs_oracle(C, k, s):
     _emu_close(ops.conv_dw(x, w, k, s, dtype="bf16"), E.dw_op(x, w, k, s), "dw C=%d k=%d s=%d" % (C, k, s))
 
 
+@pytest.mark.parametrize("C,k,s,H", [(96, 3, 2, 320), (32, 3, 1, 320), (144, 3, 1, 160), (192, 5, 1, 80), (144, 5, 2, 160), (960, 3, 1, 20)])
+def test_depthwise_production_shapes_vs_oracle(C, k, s, H):
+    """The standalone depthwise at the network's own shapes (layer1.0 / 0.0 / 1.1 / 2.1 / 2.0 / 6.0 of a 640x640 input), a batch of three: several channel
+    chunks per tile, hundreds of tiles, a workgroup count that is not a multiple of eight -- the XCD-contiguous work order (dw_xcd_remap), the incremental
+    chunk addressing of the staging loop and the per-shape tile table, in both storage types."""
+    rng = np.random.default_rng(C + 7 * k + s)
+    x = rng.standard_normal((3, C, H, H)).astype(np.float32)
+    w = (rng.standard_normal((C, 1, k, k)) * 0.3).astype(np.float32)
+    ref = O.swish(torch.nn.functional.conv2d(torch.nn.functional.pad(torch.from_numpy(x), _same_pad(k, s)), torch.from_numpy(w), None, s, 0, 1, C)).numpy()
+    np.testing.assert_allclose(ops.conv_dw(x, w, k, s, dtype="fp32"), ref, rtol=2e-5, atol=2e-5)
+    _emu_close(ops.conv_dw(x, w, k, s, dtype="bf16"), E.dw_op(x, w, k, s), "dw C=%d k=%d s=%d H=%d" % (C, k, s, H))
+
+
 def _same_pad(k, s):
     p = max(k - s, 0)
     return [p // 2, p - p // 2, p // 2, p - p // 2]
