@@ -13,7 +13,7 @@
 //  * workgroups take their tile from an XCD-contiguous work list (dw_xcd_remap: the tile below and the other channel chunks of the same
 //    pixels under ONE L2; PMC fetch 1.22x -> 0.98x the input bytes on layer1.0, profiles/r06_dw_xcd.md).
 // Measured per layer of the 640x640 network at B = 64 (profiles/r06_dw_xcd.md, r06_dw_strip.md): layer1.0 (3x3 stride 2, the largest depthwise of the
-// network) 4.80-5.01 TB/s = 60-63 % of the 8 TB/s spec by box, the other 3x3 layers 3.0-4.2 TB/s, 5x5 2.0-2.9 TB/s (VALU-bound: 25 taps per output element).
+// network) 4.77-5.02 TB/s = 60-63 % of the 8 TB/s spec by box, layer0.0 (3x3 stride 1) 4.41-4.80, the other 3x3 layers 3.1-4.6 TB/s, 5x5 2.1-3.0 TB/s.
 // The product path fuses this op into the MBConv kernels (the depthwise tensor never reaches HBM); it runs standalone in the
 // unfused path (CF_FLAG_NO_FUSE), in cf_op_dwconv and in the ShuffleV2 block.
 #include "cf_exp.h"
