@@ -352,7 +352,8 @@ int cf_memcpy_d2h(cf_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 const char* cf_op_last_error(void);      /* text of the last failing cf_op_* call on this thread */
 /* ConvReLU depthwise / ShuffleV2 dw: pad -> conv2d(groups=C, bias=False) -> act.
  * x [B,C,H,W], w [C,1,k,k], y [B,C,Ho,Wo]; pad_lo/pad_hi as ZeroPad2d (model/centernet.py:63,68-70;
- * model/blocks.py:28); act: 0 none, 1 swish.  bias may be NULL (folded BN shift, blocks.py:29). */
+ * model/blocks.py:28); act: 0 none, 1 swish.  bias may be NULL (folded BN shift, blocks.py:29).
+ * C a multiple of 8; one image (H x W x C in the storage type) smaller than 4 GiB (CF_EINVAL otherwise). */
 int cf_op_dwconv(int device, int dtype, const float* x, const float* w, const float* bias, float* y,
                  int B, int C, int H, int W, int k, int stride, int pad_lo, int pad_hi, int act);
 /* 1x1 conv [+bias] [+act] [+residual]: x [B,Cin,H,W], w [Cout,Cin], y [B,Cout,H,W]
